@@ -1,0 +1,668 @@
+/*
+ * sdn_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the arithmetic of the reference's native kernels for
+ * the dynamic-NeRF rendering path.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library; the product (the HIP
+ * library under seald-nerf_amd/) never links or calls it.
+ *
+ * Numeric contract (see DESIGN.md "Oracle semantics"):
+ *   - every C operation is rounded individually (build with -ffp-contract=off,
+ *     no -ffast-math, no -march=native) -- the reference's nvcc build fuses
+ *     a*b+c into FMAs in a compiler-chosen pattern that cannot be reproduced;
+ *   - CUDA fast intrinsics (__expf, __sinf) are replaced by the correctly
+ *     rounded value, computed in double and rounded once to float;
+ *   - atomics in kernel_march_rays_train are serialised in ray order
+ *     (the order a sequential execution of the kernel yields);
+ *   - half precision is emulated bit-exactly (round-to-nearest-even) at every
+ *     point where the reference's at::Half operators round.
+ *
+ * Parity pin: the reference ships no golden vectors for these kernels
+ * (testing/test_raymarching.py is empty); see tests/golden/README.md for what
+ * is pinned (freq via encoding.FreqEncoder, SH via the reference's closed
+ * forms, grid via float64 gradcheck) and what is "parity unpinned".
+ *
+ * Each function cites the reference file:line it follows
+ * (paths relative to /root/reference).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+/* ------------------------------------------------------------------------- */
+/* half <-> float, IEEE binary16, round-to-nearest-even                      */
+/* ------------------------------------------------------------------------- */
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+float orc_h2f(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1Fu;
+    uint32_t man = h & 0x3FFu;
+    if (exp == 0) {
+        if (man == 0) return u2f(sign);
+        /* subnormal: value = man * 2^-24 */
+        float v = (float)man * 5.9604644775390625e-08f;
+        return sign ? -v : v;
+    }
+    if (exp == 31) return u2f(sign | 0x7F800000u | (man << 13));
+    return u2f(sign | ((exp + 112u) << 23) | (man << 13));
+}
+
+uint16_t orc_f2h(float f) {
+    uint32_t x = f2u(f);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t ax = x & 0x7FFFFFFFu;
+    if (ax >= 0x7F800000u) { /* inf / nan */
+        if (ax > 0x7F800000u) return (uint16_t)(sign | 0x7E00u | ((ax >> 13) & 0x3FFu));
+        return (uint16_t)(sign | 0x7C00u);
+    }
+    if (ax >= 0x477FF000u) { /* >= 65520 rounds to inf */
+        return (uint16_t)(sign | 0x7C00u);
+    }
+    if (ax < 0x38800000u) { /* < 2^-14: subnormal half (or zero) */
+        if (ax < 0x33000000u) return (uint16_t)sign; /* < 2^-25 -> 0 (2^-25 exactly ties to even = 0) */
+        /* value * 2^24 rounded to nearest even integer */
+        float v = u2f(ax) * 16777216.0f; /* exact scaling */
+        float r = nearbyintf(v);         /* default rounding mode = RNE */
+        return (uint16_t)(sign | (uint32_t)r);
+    }
+    /* normal */
+    uint32_t mant = ax & 0x7FFFFFu;
+    uint32_t e = (ax >> 23) - 112u;
+    uint32_t h = (e << 10) | (mant >> 13);
+    uint32_t rem = mant & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+    return (uint16_t)(sign | h);
+}
+
+static inline float rh(float f) { return orc_h2f(orc_f2h(f)); } /* round through half */
+
+/* ------------------------------------------------------------------------- */
+/* raymarching helpers  (raymarching/src/raymarching.cu:19-81)               */
+/* ------------------------------------------------------------------------- */
+#define ORC_SQRT3 1.7320508075688772f
+#define ORC_RPI 0.3183098861837907f
+
+static inline float signf_(float x) { return copysignf(1.0f, x); }
+static inline float clampf_(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+
+/* raymarching.cu:42-47 */
+static inline int mip_from_pos(float x, float y, float z, float max_cascade) {
+    const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    int exponent;
+    frexpf(mx, &exponent);
+    return (int)fminf(max_cascade - 1, fmaxf(0, (float)exponent));
+}
+
+/* raymarching.cu:49-54 (dt * H is float, * 0.5 is a double literal) */
+static inline int mip_from_dt(float dt, float H, float max_cascade) {
+    const float mx = (float)((double)(dt * H) * 0.5);
+    int exponent;
+    frexpf(mx, &exponent);
+    return (int)fminf(max_cascade - 1, fmaxf(0, (float)exponent));
+}
+
+/* raymarching.cu:56-63 */
+static inline uint32_t expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+/* raymarching.cu:65-71 */
+static inline uint32_t morton3D_(uint32_t x, uint32_t y, uint32_t z) {
+    return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
+}
+/* raymarching.cu:73-81 */
+static inline uint32_t morton3D_invert_(uint32_t x) {
+    x = x & 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    x = (x | (x >> 16)) & 0x0000ffffu;
+    return x;
+}
+
+/* correctly rounded stand-in for CUDA __expf (raymarching.cu:542,645,860) */
+static inline float exp_cr(float x) { return (float)exp((double)x); }
+
+/* ------------------------------------------------------------------------- */
+/* near_far_from_aabb  (raymarching.cu:92-145)                               */
+/* ------------------------------------------------------------------------- */
+void orc_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb,
+                            uint32_t N, float min_near, float *nears, float *fars) {
+    for (uint32_t n = 0; n < N; n++) {
+        const float *o = rays_o + (size_t)n * 3, *d = rays_d + (size_t)n * 3;
+        const float ox = o[0], oy = o[1], oz = o[2];
+        const float rdx = 1 / d[0], rdy = 1 / d[1], rdz = 1 / d[2];
+        float near = (aabb[0] - ox) * rdx;
+        float far = (aabb[3] - ox) * rdx;
+        if (near > far) { float c = near; near = far; far = c; }
+        float near_y = (aabb[1] - oy) * rdy;
+        float far_y = (aabb[4] - oy) * rdy;
+        if (near_y > far_y) { float c = near_y; near_y = far_y; far_y = c; }
+        if (near > far_y || near_y > far) { nears[n] = fars[n] = FLT_MAX; continue; }
+        if (near_y > near) near = near_y;
+        if (far_y < far) far = far_y;
+        float near_z = (aabb[2] - oz) * rdz;
+        float far_z = (aabb[5] - oz) * rdz;
+        if (near_z > far_z) { float c = near_z; near_z = far_z; far_z = c; }
+        if (near > far_z || near_z > far) { nears[n] = fars[n] = FLT_MAX; continue; }
+        if (near_z > near) near = near_z;
+        if (far_z < far) far = far_z;
+        if (near < min_near) near = min_near;
+        nears[n] = near;
+        fars[n] = far;
+    }
+}
+
+/* sph_from_ray (raymarching.cu:163-198) */
+void orc_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords) {
+    for (uint32_t n = 0; n < N; n++) {
+        const float *o = rays_o + (size_t)n * 3, *d = rays_d + (size_t)n * 3;
+        const float ox = o[0], oy = o[1], oz = o[2];
+        const float dx = d[0], dy = d[1], dz = d[2];
+        const float A = dx * dx + dy * dy + dz * dz;
+        const float B = ox * dx + oy * dy + oz * dz;
+        const float C = ox * ox + oy * oy + oz * oz - radius * radius;
+        const float t = (-B + sqrtf(B * B - A * C)) / A;
+        const float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+        /* the reference calls the double overloads atan2(float,float) -> device float atan2f */
+        const float theta = atan2f(sqrtf(x * x + z * z), y);
+        const float phi = atan2f(z, x);
+        coords[(size_t)n * 2 + 0] = 2 * theta * ORC_RPI - 1;
+        coords[(size_t)n * 2 + 1] = phi * ORC_RPI;
+    }
+}
+
+/* morton3D / invert (raymarching.cu:214-254) */
+void orc_morton3D(const int32_t *coords, uint32_t N, int32_t *indices) {
+    for (uint32_t n = 0; n < N; n++)
+        indices[n] = (int32_t)morton3D_((uint32_t)coords[3 * (size_t)n], (uint32_t)coords[3 * (size_t)n + 1], (uint32_t)coords[3 * (size_t)n + 2]);
+}
+void orc_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords) {
+    for (uint32_t n = 0; n < N; n++) {
+        const int ind = indices[n];
+        coords[3 * (size_t)n + 0] = (int32_t)morton3D_invert_((uint32_t)(ind >> 0));
+        coords[3 * (size_t)n + 1] = (int32_t)morton3D_invert_((uint32_t)(ind >> 1));
+        coords[3 * (size_t)n + 2] = (int32_t)morton3D_invert_((uint32_t)(ind >> 2));
+    }
+}
+
+/* packbits (raymarching.cu:268-289) */
+void orc_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield) {
+    for (uint32_t n = 0; n < N; n++) {
+        const float *g = grid + (size_t)n * 8;
+        uint8_t bits = 0;
+        for (int i = 0; i < 8; i++) bits |= (g[i] > density_thresh) ? (uint8_t)(1u << i) : 0;
+        bitfield[n] = bits;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* shared ray-march stepper (the loop body at raymarching.cu:359-400,        */
+/* 427-479, 750-804 is the same code three times)                            */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, rH, H3;
+    float bound, dt_gamma, dt_min, dt_max, far;
+    uint32_t C, H;
+    const uint8_t *grid;
+} march_ctx;
+
+static void march_ctx_init(march_ctx *c, const float *o, const float *d, float bound, float dt_gamma,
+                           uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid, float far) {
+    c->ox = o[0]; c->oy = o[1]; c->oz = o[2];
+    c->dx = d[0]; c->dy = d[1]; c->dz = d[2];
+    c->rdx = 1 / c->dx; c->rdy = 1 / c->dy; c->rdz = 1 / c->dz;
+    c->rH = 1 / (float)H;
+    c->H3 = (float)(H * H * H);
+    c->bound = bound; c->dt_gamma = dt_gamma;
+    c->dt_min = 2 * ORC_SQRT3 / (float)max_steps;
+    c->dt_max = 2 * ORC_SQRT3 * (float)(1 << (C - 1)) / (float)H;
+    c->C = C; c->H = H; c->grid = grid; c->far = far;
+}
+
+/* One iteration of the while-loop body.  Returns 1 if the cell was occupied
+ * (then *px,*py,*pz,*pdt hold the sample and t has NOT been advanced), 0 if it
+ * was empty (then *t has been advanced past the voxel). */
+static inline int march_probe(const march_ctx *c, float *t, float *px, float *py, float *pz, float *pdt) {
+    const float x = clampf_(c->ox + *t * c->dx, -c->bound, c->bound);
+    const float y = clampf_(c->oy + *t * c->dy, -c->bound, c->bound);
+    const float z = clampf_(c->oz + *t * c->dz, -c->bound, c->bound);
+    const float dt = clampf_(*t * c->dt_gamma, c->dt_min, c->dt_max);
+    const int l0 = mip_from_pos(x, y, z, (float)c->C), l1 = mip_from_dt(dt, (float)c->H, (float)c->C);
+    const int level = l0 > l1 ? l0 : l1;
+    const float mip_bound = fminf(scalbnf(1.0f, level), c->bound);
+    const float mip_rbound = 1 / mip_bound;
+    /* 0.5 is a double literal in the reference: product in double, rounded to float by clamp() */
+    const int nx = (int)clampf_((float)(0.5 * (double)(x * mip_rbound + 1) * (double)c->H), 0.0f, (float)(c->H - 1));
+    const int ny = (int)clampf_((float)(0.5 * (double)(y * mip_rbound + 1) * (double)c->H), 0.0f, (float)(c->H - 1));
+    const int nz = (int)clampf_((float)(0.5 * (double)(z * mip_rbound + 1) * (double)c->H), 0.0f, (float)(c->H - 1));
+    /* int * float + uint32 is evaluated in float in the reference */
+    const uint32_t index = (uint32_t)((float)level * c->H3 + (float)morton3D_((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+    const int occ = c->grid[index / 8] & (1 << (index % 8));
+    if (occ) {
+        *px = x; *py = y; *pz = z; *pdt = dt;
+        return 1;
+    }
+    const float tx = (((nx + 0.5f + 0.5f * signf_(c->dx)) * c->rH * 2 - 1) * mip_bound - x) * c->rdx;
+    const float ty = (((ny + 0.5f + 0.5f * signf_(c->dy)) * c->rH * 2 - 1) * mip_bound - y) * c->rdy;
+    const float tz = (((nz + 0.5f + 0.5f * signf_(c->dz)) * c->rH * 2 - 1) * mip_bound - z) * c->rdz;
+    const float tt = *t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    do {
+        *t += clampf_(*t * c->dt_gamma, c->dt_min, c->dt_max);
+    } while (*t < tt);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* march_rays_train (raymarching.cu:312-480), atomics serialised in ray order */
+/* ------------------------------------------------------------------------- */
+void orc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound,
+                          float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                          const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
+                          int32_t *rays, int32_t *counter, const float *noises) {
+    for (uint32_t n = 0; n < N; n++) {
+        march_ctx c;
+        march_ctx_init(&c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid, fars[n]);
+        const float near = nears[n], far = fars[n], noise = noises[n];
+        float t0 = near;
+        t0 += clampf_(t0 * dt_gamma, c.dt_min, c.dt_max) * noise;
+        /* first pass */
+        float t = t0, x, y, z, dt;
+        uint32_t num_steps = 0;
+        while (t < far && num_steps < max_steps) {
+            if (march_probe(&c, &t, &x, &y, &z, &dt)) { num_steps++; t += dt; }
+        }
+        uint32_t point_index = (uint32_t)counter[0]; counter[0] += (int32_t)num_steps;
+        uint32_t ray_index = (uint32_t)counter[1]; counter[1] += 1;
+        rays[ray_index * 3] = (int32_t)n;
+        rays[ray_index * 3 + 1] = (int32_t)point_index;
+        rays[ray_index * 3 + 2] = (int32_t)num_steps;
+        if (num_steps == 0) continue;
+        if (point_index + num_steps > M) continue;
+        float *px = xyzs + (size_t)point_index * 3, *pd = dirs + (size_t)point_index * 3, *pl = deltas + (size_t)point_index * 2;
+        t = t0;
+        uint32_t step = 0;
+        float last_t = t;
+        while (t < far && step < num_steps) {
+            if (march_probe(&c, &t, &x, &y, &z, &dt)) {
+                px[0] = x; px[1] = y; px[2] = z;
+                pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
+                t += dt;
+                pl[0] = dt;
+                pl[1] = t - last_t;
+                last_t = t;
+                px += 3; pd += 3; pl += 2;
+                step++;
+            }
+        }
+    }
+}
+
+/* composite_rays_train_forward (raymarching.cu:501-577) */
+void orc_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,
+                                      uint32_t M, uint32_t N, float T_thresh, float *weights_sum, float *depth, float *image) {
+    for (uint32_t n = 0; n < N; n++) {
+        uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+        if (num_steps == 0 || offset + num_steps > M) {
+            weights_sum[index] = 0; depth[index] = 0;
+            image[index * 3] = 0; image[index * 3 + 1] = 0; image[index * 3 + 2] = 0;
+            continue;
+        }
+        const float *s = sigmas + offset, *c = rgbs + (size_t)offset * 3, *dl = deltas + (size_t)offset * 2;
+        uint32_t step = 0;
+        float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0;
+        while (step < num_steps) {
+            const float alpha = 1.0f - exp_cr(-s[0] * dl[0]);
+            const float weight = alpha * T;
+            r += weight * c[0]; g += weight * c[1]; b += weight * c[2];
+            t += dl[1];
+            d += weight * t;
+            ws += weight;
+            T *= 1.0f - alpha;
+            if (T < T_thresh) break;
+            s++; c += 3; dl += 2; step++;
+        }
+        weights_sum[index] = ws; depth[index] = d;
+        image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+    }
+}
+
+/* composite_rays_train_backward (raymarching.cu:602-682) */
+void orc_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_image, const float *sigmas,
+                                       const float *rgbs, const float *deltas, const int32_t *rays,
+                                       const float *weights_sum, const float *image, uint32_t M, uint32_t N,
+                                       float T_thresh, float *grad_sigmas, float *grad_rgbs) {
+    for (uint32_t n = 0; n < N; n++) {
+        uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+        if (num_steps == 0 || offset + num_steps > M) continue;
+        const float *gws = grad_weights_sum + index, *gi = grad_image + (size_t)index * 3;
+        const float *s = sigmas + offset, *c = rgbs + (size_t)offset * 3, *dl = deltas + (size_t)offset * 2;
+        float *gs = grad_sigmas + offset, *gc = grad_rgbs + (size_t)offset * 3;
+        uint32_t step = 0;
+        float T = 1.0f;
+        const float r_final = image[(size_t)index * 3], g_final = image[(size_t)index * 3 + 1], b_final = image[(size_t)index * 3 + 2];
+        const float ws_final = weights_sum[index];
+        float r = 0, g = 0, b = 0, ws = 0;
+        while (step < num_steps) {
+            const float alpha = 1.0f - exp_cr(-s[0] * dl[0]);
+            const float weight = alpha * T;
+            r += weight * c[0]; g += weight * c[1]; b += weight * c[2];
+            ws += weight;
+            T *= 1.0f - alpha;
+            gc[0] = gi[0] * weight; gc[1] = gi[1] * weight; gc[2] = gi[2] * weight;
+            gs[0] = dl[0] * (gi[0] * (T * c[0] - (r_final - r)) + gi[1] * (T * c[1] - (g_final - g)) +
+                             gi[2] * (T * c[2] - (b_final - b)) + gws[0] * (1 - ws_final));
+            if (T < T_thresh) break;
+            s++; c += 3; dl += 2; gs++; gc += 3; step++;
+        }
+        (void)ws;
+    }
+}
+
+/* march_rays (raymarching.cu:701-805) */
+void orc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t,
+                    const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                    uint32_t C, uint32_t H, const uint8_t *grid, const float *nears, const float *fars,
+                    float *xyzs, float *dirs, float *deltas, const float *noises) {
+    (void)nears;
+    for (uint32_t n = 0; n < n_alive; n++) {
+        const int index = rays_alive[n];
+        const float noise = noises[n];
+        march_ctx c;
+        march_ctx_init(&c, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid, fars[index]);
+        float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3, *pl = deltas + (size_t)n * n_step * 2;
+        float t = rays_t[index];
+        const float far = fars[index];
+        uint32_t step = 0;
+        t += clampf_(t * dt_gamma, c.dt_min, c.dt_max) * noise;
+        float last_t = t, x, y, z, dt;
+        while (t < far && step < n_step) {
+            if (march_probe(&c, &t, &x, &y, &z, &dt)) {
+                px[0] = x; px[1] = y; px[2] = z;
+                pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
+                t += dt;
+                pl[0] = dt;
+                pl[1] = t - last_t;
+                last_t = t;
+                px += 3; pd += 3; pl += 2;
+                step++;
+            }
+        }
+    }
+}
+
+/* composite_rays (raymarching.cu:819-905) */
+void orc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
+                        const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum,
+                        float *depth, float *image) {
+    for (uint32_t n = 0; n < n_alive; n++) {
+        const int index = rays_alive[n];
+        const float *s = sigmas + (size_t)n * n_step, *c = rgbs + (size_t)n * n_step * 3, *dl = deltas + (size_t)n * n_step * 2;
+        float t = rays_t[index];
+        float weight_sum = weights_sum[index], d = depth[index];
+        float r = image[(size_t)index * 3], g = image[(size_t)index * 3 + 1], b = image[(size_t)index * 3 + 2];
+        uint32_t step = 0;
+        while (step < n_step) {
+            if (dl[0] == 0) break;
+            const float alpha = 1.0f - exp_cr(-s[0] * dl[0]);
+            const float T = 1 - weight_sum;
+            const float weight = alpha * T;
+            weight_sum += weight;
+            t += dl[1];
+            d += weight * t;
+            r += weight * c[0]; g += weight * c[1]; b += weight * c[2];
+            if (T < T_thresh) break;
+            s++; c += 3; dl += 2; step++;
+        }
+        if (step < n_step) rays_alive[n] = -1;
+        else rays_t[index] = t;
+        weights_sum[index] = weight_sum; depth[index] = d;
+        image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* grid encoder (gridencoder/src/gridencoder.cu)                             */
+/* ------------------------------------------------------------------------- */
+#define ORC_MAXD 5
+#define ORC_MAXC 8
+
+/* gridencoder.cu:50-63 */
+static inline uint32_t fast_hash(uint32_t D, const uint32_t *pos_grid) {
+    static const uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+    uint32_t result = 0;
+    for (uint32_t i = 0; i < D; ++i) result ^= pos_grid[i] * primes[i];
+    return result;
+}
+
+/* gridencoder.cu:66-84 */
+static inline uint32_t get_grid_index(uint32_t D, uint32_t C, uint32_t gridtype, int align_corners, uint32_t ch,
+                                      uint32_t hashmap_size, uint32_t resolution, const uint32_t *pos_grid) {
+    uint32_t stride = 1, index = 0;
+    for (uint32_t d = 0; d < D && stride <= hashmap_size; d++) {
+        index += pos_grid[d] * stride;
+        stride *= align_corners ? resolution : (resolution + 1);
+    }
+    if (gridtype == 0 && stride > hashmap_size) index = fast_hash(D, pos_grid);
+    return (index % hashmap_size) * C + ch;
+}
+
+static inline float smoothstep_(float v) { return v * v * (3.0f - 2.0f * v); }
+static inline float smoothstep_derivative_(float v) { return 6 * v * (1.0f - v); }
+
+/* per-level scale/resolution (gridencoder.cu:138-139) */
+void orc_grid_level_params(uint32_t level, float S, uint32_t H, float *scale, uint32_t *resolution) {
+    *scale = exp2f((float)level * S) * (float)H - 1.0f;
+    *resolution = (uint32_t)ceil((double)*scale) + 1;
+}
+
+/* element access abstracting float vs emulated half storage */
+static inline float ld(const void *p, size_t i, int is_half) {
+    return is_half ? orc_h2f(((const uint16_t *)p)[i]) : ((const float *)p)[i];
+}
+static inline void st(void *p, size_t i, float v, int is_half) {
+    if (is_half) ((uint16_t *)p)[i] = orc_f2h(v);
+    else ((float *)p)[i] = v;
+}
+
+/* kernel_grid (gridencoder.cu:87-245).  outputs: [L,B,C]; dy_dx: [B,L,D,C] or NULL.
+ * is_half: embeddings/outputs/dy_dx are IEEE half (uint16 storage); every
+ * at::Half compound assignment of the reference rounds to half, emulated here. */
+void orc_grid_encode_forward(const float *inputs, const void *grid_all, const int32_t *offsets, void *outputs_all,
+                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx_all,
+                             uint32_t gridtype, int align_corners, uint32_t interp, int is_half) {
+    for (uint32_t level = 0; level < L; level++) {
+        const size_t goff = (size_t)(uint32_t)offsets[level] * C;
+        const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+        float scale; uint32_t resolution;
+        orc_grid_level_params(level, S, H, &scale, &resolution);
+        for (uint32_t b = 0; b < B; b++) {
+            const float *in = inputs + (size_t)b * D;
+            const size_t ooff = (size_t)level * B * C + (size_t)b * C;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; d++) if (in[d] < 0 || in[d] > 1) oob = 1;
+            if (oob) {
+                for (uint32_t ch = 0; ch < C; ch++) st(outputs_all, ooff + ch, 0.0f, is_half);
+                if (dy_dx_all) {
+                    const size_t doff = (size_t)b * D * L * C + (size_t)level * D * C;
+                    for (uint32_t i = 0; i < D * C; i++) st(dy_dx_all, doff + i, 0.0f, is_half);
+                }
+                continue;
+            }
+            float pos[ORC_MAXD], pos_deriv[ORC_MAXD];
+            uint32_t pos_grid[ORC_MAXD];
+            for (uint32_t d = 0; d < D; d++) {
+                pos[d] = in[d] * scale + (align_corners ? 0.0f : 0.5f);
+                pos_grid[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pos_grid[d];
+                if (interp == 1) {
+                    pos_deriv[d] = smoothstep_derivative_(pos[d]);
+                    pos[d] = smoothstep_(pos[d]);
+                } else {
+                    pos_deriv[d] = 1.0f;
+                }
+            }
+            float results[ORC_MAXC];
+            for (uint32_t ch = 0; ch < C; ch++) results[ch] = 0;
+            for (uint32_t idx = 0; idx < (1u << D); idx++) {
+                float w = 1;
+                uint32_t pgl[ORC_MAXD];
+                for (uint32_t d = 0; d < D; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+                    else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+                }
+                const uint32_t index = get_grid_index(D, C, gridtype, align_corners, 0, hashmap_size, resolution, pgl);
+                for (uint32_t ch = 0; ch < C; ch++) {
+                    /* scalar_t += float*scalar_t : float math, rounded back to scalar_t */
+                    const float v = results[ch] + w * ld(grid_all, goff + index + ch, is_half);
+                    results[ch] = is_half ? rh(v) : v;
+                }
+            }
+            for (uint32_t ch = 0; ch < C; ch++) st(outputs_all, ooff + ch, results[ch], is_half);
+            if (dy_dx_all) {
+                const size_t doff = (size_t)b * D * L * C + (size_t)level * D * C;
+                for (uint32_t gd = 0; gd < D; gd++) {
+                    float rg[ORC_MAXC];
+                    for (uint32_t ch = 0; ch < C; ch++) rg[ch] = 0;
+                    for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+                        float w = scale;
+                        uint32_t pgl[ORC_MAXD];
+                        for (uint32_t nd = 0; nd < D - 1; nd++) {
+                            const uint32_t d = (nd >= gd) ? (nd + 1) : nd;
+                            if ((idx & (1u << nd)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+                            else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+                        }
+                        pgl[gd] = pos_grid[gd];
+                        const uint32_t il = get_grid_index(D, C, gridtype, align_corners, 0, hashmap_size, resolution, pgl);
+                        pgl[gd] = pos_grid[gd] + 1;
+                        const uint32_t ir = get_grid_index(D, C, gridtype, align_corners, 0, hashmap_size, resolution, pgl);
+                        for (uint32_t ch = 0; ch < C; ch++) {
+                            float diff = ld(grid_all, goff + ir + ch, is_half) - ld(grid_all, goff + il + ch, is_half);
+                            if (is_half) diff = rh(diff); /* Half - Half -> Half */
+                            const float v = rg[ch] + w * diff * pos_deriv[gd];
+                            rg[ch] = is_half ? rh(v) : v;
+                        }
+                    }
+                    for (uint32_t ch = 0; ch < C; ch++) st(dy_dx_all, doff + gd * C + ch, rg[ch], is_half);
+                }
+            }
+        }
+    }
+}
+
+/* kernel_grid_backward (gridencoder.cu:248-340) + kernel_input_backward (343-369).
+ * grad: [L,B,C]; grad_grid: same layout as embeddings, caller zero-fills.
+ * Atomics serialised in (level, b, channel-pair, corner) order.  In half mode each
+ * atomic add rounds the running sum to half (as the __half2 atomicAdd does). */
+void orc_grid_encode_backward(const void *grad_all, const float *inputs, const int32_t *offsets, void *grad_grid_all,
+                              uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                              const void *dy_dx_all, void *grad_inputs, uint32_t gridtype, int align_corners,
+                              uint32_t interp, int is_half) {
+    const uint32_t N_C = C < 2 ? C : 2;
+    for (uint32_t level = 0; level < L; level++) {
+        const size_t goff = (size_t)(uint32_t)offsets[level] * C;
+        const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+        float scale; uint32_t resolution;
+        orc_grid_level_params(level, S, H, &scale, &resolution);
+        for (uint32_t b = 0; b < B; b++) {
+            const float *in = inputs + (size_t)b * D;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; d++) if (in[d] < 0 || in[d] > 1) oob = 1;
+            if (oob) continue;
+            float pos[ORC_MAXD];
+            uint32_t pos_grid[ORC_MAXD];
+            for (uint32_t d = 0; d < D; d++) {
+                pos[d] = in[d] * scale + (align_corners ? 0.0f : 0.5f);
+                pos_grid[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pos_grid[d];
+                if (interp == 1) pos[d] = smoothstep_(pos[d]);
+            }
+            for (uint32_t ch = 0; ch < C; ch += N_C) {
+                float grad_cur[2] = {0, 0};
+                for (uint32_t c = 0; c < N_C; c++) grad_cur[c] = ld(grad_all, (size_t)level * B * C + (size_t)b * C + ch + c, is_half);
+                for (uint32_t idx = 0; idx < (1u << D); idx++) {
+                    float w = 1;
+                    uint32_t pgl[ORC_MAXD];
+                    for (uint32_t d = 0; d < D; d++) {
+                        if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+                        else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+                    }
+                    const uint32_t index = get_grid_index(D, C, gridtype, align_corners, ch, hashmap_size, resolution, pgl);
+                    for (uint32_t c = 0; c < N_C; c++) {
+                        float v = w * grad_cur[c];
+                        if (is_half) v = rh(v);
+                        const float cur = ld(grad_grid_all, goff + index + c, is_half);
+                        st(grad_grid_all, goff + index + c, cur + v, is_half);
+                    }
+                }
+            }
+        }
+    }
+    if (dy_dx_all && grad_inputs) {
+        for (uint32_t b = 0; b < B; b++) {
+            for (uint32_t d = 0; d < D; d++) {
+                float result = 0;
+                for (uint32_t l = 0; l < L; l++) {
+                    for (uint32_t ch = 0; ch < C; ch++) {
+                        const float g = ld(grad_all, (size_t)l * B * C + (size_t)b * C + ch, is_half);
+                        const float dd = ld(dy_dx_all, (size_t)b * L * D * C + (size_t)l * D * C + (size_t)d * C + ch, is_half);
+                        if (is_half) result = rh(result + rh(g * dd)); /* Half*Half -> Half; Half += Half */
+                        else result += g * dd;
+                    }
+                }
+                st(grad_inputs, (size_t)b * D + d, result, is_half);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* frequency encoder (freqencoder/src/freqencoder.cu:30-94)                  */
+/* ------------------------------------------------------------------------- */
+void orc_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float *outputs) {
+    (void)deg;
+    const float half_pi = 3.141592653589793f / 2;
+    for (size_t t = 0; t < (size_t)B * C; t++) {
+        const uint32_t b = (uint32_t)(t / C), c = (uint32_t)(t - (size_t)b * C);
+        const float *in = inputs + (size_t)b * D;
+        if (c < D) outputs[t] = in[c];
+        else {
+            const uint32_t col = c / D - 1, d = c % D, freq = col / 2;
+            const float phase_shift = (float)(col % 2) * half_pi;
+            const float arg = scalbnf(in[d], (int)freq) + phase_shift;
+            outputs[t] = (float)sin((double)arg); /* correctly rounded stand-in for __sinf */
+        }
+    }
+}
+
+void orc_freq_encode_backward(const float *grad, const float *outputs, uint32_t B, uint32_t D, uint32_t deg,
+                              uint32_t C, float *grad_inputs) {
+    for (size_t t = 0; t < (size_t)B * D; t++) {
+        const uint32_t b = (uint32_t)(t / D), d = (uint32_t)(t - (size_t)b * D);
+        const float *g = grad + (size_t)b * C, *o = outputs + (size_t)b * C;
+        float result = g[d];
+        g += D; o += D;
+        for (uint32_t f = 0; f < deg; f++) {
+            result += scalbnf(1.0f, (int)f) * (g[d] * o[D + d] - g[D + d] * o[d]);
+            g += 2 * D; o += 2 * D;
+        }
+        grad_inputs[t] = result;
+    }
+}
+
+/* sh backward reduction (shencoder/src/shencoder.cu:358-382): grad_inputs += sum_ch grad*dy_dx */
+void orc_sh_encode_backward(const float *grad, uint32_t B, uint32_t D, uint32_t C, const float *dy_dx, float *grad_inputs) {
+    const uint32_t C2 = C * C;
+    for (size_t t = 0; t < (size_t)B * D; t++) {
+        const uint32_t b = (uint32_t)(t / D), d = (uint32_t)(t - (size_t)b * D);
+        const float *g = grad + (size_t)b * C2, *dd = dy_dx + (size_t)b * D * C2 + (size_t)d * C2;
+        for (uint32_t ch = 0; ch < C2; ch++) grad_inputs[t] += g[ch] * dd[ch];
+    }
+}

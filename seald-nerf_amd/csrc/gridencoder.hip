@@ -1,0 +1,411 @@
+// Multiresolution hash / tiled grid encoder for gfx950 (MI355X).
+//
+// Behavioural contract: gridencoder/src/gridencoder.cu of the reference
+// (kernel_grid :87-245, kernel_grid_backward :248-340, kernel_input_backward :343-369).
+// Built with -ffp-contract=off: position / index / weight arithmetic rounds exactly
+// as written in the reference source, so grid indices are bit-exact against
+// oracle/sdn_oracle.c and fp32 outputs are bit-identical (same corner order);
+// the fp16 path rounds to half wherever the reference's at::Half operators do.
+//
+// MI355X mapping:
+//   * launch = (point tiles) x (levels), level is the SLOW grid dimension: the
+//     dispatcher walks x first, so at any instant the whole chip works on one or two
+//     levels and the live table slice (<= 2 MiB fp16 / 4 MiB fp32 per level) stays in
+//     every XCD's 4 MiB L2; the whole 23/47 MiB table stays in the 256 MiB Infinity
+//     Cache between frames.
+//   * per-level constants (row offset, row count, scale, resolution) are computed
+//     on the host and passed by value -> SGPRs, no dependent offsets[] loads.
+//   * 256-thread blocks; one lane = one (point, level); inputs are re-read per
+//     level from L2 (12 B/point), outputs are written [L,B,C] so a wave's stores
+//     are contiguous.
+//   * backward: no-return float / packed-half atomics (global_atomic_add_f32 /
+//     global_atomic_pk_add_f16), order-free like the reference.
+#include <math.h>
+
+#include "sdn_common.h"
+
+namespace {
+
+constexpr uint32_t kMaxLevels = 32;
+
+struct LevelParams {
+    uint32_t offset[kMaxLevels];        // row offset of the level (rows, not elements)
+    uint32_t hashmap_size[kMaxLevels];  // rows in the level
+    float scale[kMaxLevels];            // exp2f(level*S)*H - 1
+    uint32_t resolution[kMaxLevels];    // ceil(scale) + 1
+};
+
+__device__ __forceinline__ float smoothstep_(float v) { return v * v * (3.0f - 2.0f * v); }
+__device__ __forceinline__ float smoothstep_derivative_(float v) { return 6 * v * (1.0f - v); }
+
+// gridencoder.cu:50-63
+template <uint32_t D>
+__device__ __forceinline__ uint32_t fast_hash(const uint32_t (&pos_grid)[D]) {
+    constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+    uint32_t result = 0;
+    #pragma unroll
+    for (uint32_t i = 0; i < D; ++i) result ^= pos_grid[i] * primes[i];
+    return result;
+}
+
+// gridencoder.cu:66-84 (returns the element index of channel 0 of the row)
+template <uint32_t D, uint32_t C>
+__device__ __forceinline__ uint32_t grid_index(uint32_t gridtype, bool align_corners, uint32_t hashmap_size, uint32_t resolution,
+                                               const uint32_t (&pos_grid)[D]) {
+    uint32_t stride = 1, index = 0;
+    #pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        if (stride <= hashmap_size) {
+            index += pos_grid[d] * stride;
+            stride *= align_corners ? resolution : (resolution + 1);
+        }
+    }
+    if (gridtype == 0 && stride > hashmap_size) index = fast_hash<D>(pos_grid);
+    return (index % hashmap_size) * C;
+}
+
+template <typename T> struct Num;
+template <> struct Num<float> {
+    static __device__ __forceinline__ float ld(const float *p) { return *p; }
+    static __device__ __forceinline__ float rnd(float v) { return v; }
+    static __device__ __forceinline__ void st(float *p, float v) { *p = v; }
+};
+template <> struct Num<__half> {
+    static __device__ __forceinline__ float ld(const __half *p) { return __half2float(*p); }
+    static __device__ __forceinline__ float rnd(float v) { return __half2float(__float2half_rn(v)); }
+    static __device__ __forceinline__ void st(__half *p, float v) { *p = __float2half_rn(v); }
+};
+
+// ---------------------------------------------------------------------------
+// forward (+ optional dy_dx)            gridencoder.cu:87-245
+// ---------------------------------------------------------------------------
+template <typename T, uint32_t D, uint32_t C, bool WITH_DYDX>
+__global__ void __launch_bounds__(256) k_grid_fwd(const float *__restrict__ inputs, const T *__restrict__ grid_all, T *__restrict__ outputs,
+                                                  uint32_t B, uint32_t L, LevelParams lp, T *__restrict__ dy_dx, uint32_t gridtype,
+                                                  bool align_corners, uint32_t interp) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+    const T *__restrict__ grid = grid_all + (size_t)lp.offset[level] * C;
+    const uint32_t hashmap_size = lp.hashmap_size[level];
+    const float scale = lp.scale[level];
+    const uint32_t resolution = lp.resolution[level];
+    T *out = outputs + ((size_t)level * B + b) * C;
+
+    float in[D];
+    bool oob = false;
+    #pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        in[d] = inputs[(size_t)b * D + d];
+        if (in[d] < 0 || in[d] > 1) oob = true;
+    }
+    if (oob) {
+        #pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) Num<T>::st(out + ch, 0.0f);
+        if (WITH_DYDX) {
+            T *dd = dy_dx + (size_t)b * D * L * C + (size_t)level * D * C;
+            #pragma unroll
+            for (uint32_t i = 0; i < D * C; i++) Num<T>::st(dd + i, 0.0f);
+        }
+        return;
+    }
+
+    float pos[D], pos_deriv[D];
+    uint32_t pos_grid[D];
+    #pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        pos[d] = in[d] * scale + (align_corners ? 0.0f : 0.5f);
+        pos_grid[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pos_grid[d];
+        if (interp == 1) {
+            pos_deriv[d] = smoothstep_derivative_(pos[d]);
+            pos[d] = smoothstep_(pos[d]);
+        } else {
+            pos_deriv[d] = 1.0f;
+        }
+    }
+
+    // issue all 2^D row gathers first (independent loads), then blend in the reference's corner order
+    float vals[1u << D][C];
+    float ws[1u << D];
+    #pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float w = 1;
+        uint32_t pgl[D];
+        #pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+            else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+        }
+        ws[idx] = w;
+        const uint32_t index = grid_index<D, C>(gridtype, align_corners, hashmap_size, resolution, pgl);
+        #pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) vals[idx][ch] = Num<T>::ld(grid + index + ch);
+    }
+    float results[C];
+    #pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) results[ch] = 0;
+    #pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        #pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) results[ch] = Num<T>::rnd(results[ch] + ws[idx] * vals[idx][ch]);
+    }
+    #pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) Num<T>::st(out + ch, results[ch]);
+
+    if (WITH_DYDX) {
+        T *dd = dy_dx + (size_t)b * D * L * C + (size_t)level * D * C;
+        #pragma unroll
+        for (uint32_t gd = 0; gd < D; gd++) {
+            float rg[C];
+            #pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) rg[ch] = 0;
+            #pragma unroll
+            for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+                float w = scale;
+                uint32_t corner = 0;  // bit d set <=> +1 along d, gd excluded
+                #pragma unroll
+                for (uint32_t nd = 0; nd < D - 1; nd++) {
+                    const uint32_t d = (nd >= gd) ? (nd + 1) : nd;
+                    if ((idx & (1u << nd)) == 0) { w *= 1 - pos[d]; }
+                    else { w *= pos[d]; corner |= (1u << d); }
+                }
+                // the left/right rows are two of the 2^D corners gathered above: reuse the registers
+                #pragma unroll
+                for (uint32_t ch = 0; ch < C; ch++) {
+                    const float diff = Num<T>::rnd(vals[corner | (1u << gd)][ch] - vals[corner][ch]);
+                    rg[ch] = Num<T>::rnd(rg[ch] + w * diff * pos_deriv[gd]);
+                }
+            }
+            #pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) Num<T>::st(dd + gd * C + ch, rg[ch]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward: scatter-add into the table gradient     gridencoder.cu:248-340
+// one lane = (point, level, channel pair)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_add_f32(float *p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add_h2(__half *p, float a, float b) {
+    unsafeAtomicAdd(reinterpret_cast<__half2 *>(p), __halves2half2(__float2half_rn(a), __float2half_rn(b)));
+}
+// scalar half add without a native instruction: CAS on the enclosing 32-bit word (C == 1 only; the
+// reference's own comment calls this path "very slow ... never use it").
+__device__ __forceinline__ void atomic_add_h1(__half *p, float a) {
+    const uintptr_t addr = (uintptr_t)p;
+    unsigned int *word = (unsigned int *)(addr & ~(uintptr_t)3);
+    const bool hi = addr & 2;
+    unsigned int old = *word, assumed;
+    const __half add = __float2half_rn(a);
+    do {
+        assumed = old;
+        const unsigned short cur = hi ? (unsigned short)(assumed >> 16) : (unsigned short)(assumed & 0xFFFFu);
+        const __half nv = __hadd(__ushort_as_half(cur), add);
+        const unsigned int nb = __half_as_ushort(nv);
+        const unsigned int repl = hi ? ((assumed & 0x0000FFFFu) | (nb << 16)) : ((assumed & 0xFFFF0000u) | nb);
+        old = atomicCAS(word, assumed, repl);
+    } while (old != assumed);
+}
+
+template <typename T, uint32_t D, uint32_t C, uint32_t N_C>
+__global__ void __launch_bounds__(256) k_grid_bwd(const T *__restrict__ grad, const float *__restrict__ inputs, T *__restrict__ grad_grid_all,
+                                                  uint32_t B, uint32_t L, LevelParams lp, uint32_t gridtype, bool align_corners,
+                                                  uint32_t interp) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = tid * N_C / C;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+    const uint32_t ch = tid * N_C - b * C;
+    T *__restrict__ grad_grid = grad_grid_all + (size_t)lp.offset[level] * C;
+    const uint32_t hashmap_size = lp.hashmap_size[level];
+    const float scale = lp.scale[level];
+    const uint32_t resolution = lp.resolution[level];
+
+    float pos[D];
+    uint32_t pos_grid[D];
+    #pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const float v = inputs[(size_t)b * D + d];
+        if (v < 0 || v > 1) return;
+        pos[d] = v * scale + (align_corners ? 0.0f : 0.5f);
+        pos_grid[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pos_grid[d];
+        if (interp == 1) pos[d] = smoothstep_(pos[d]);
+    }
+    float grad_cur[N_C];
+    #pragma unroll
+    for (uint32_t c = 0; c < N_C; c++) grad_cur[c] = Num<T>::ld(grad + ((size_t)level * B + b) * C + ch + c);
+
+    #pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float w = 1;
+        uint32_t pgl[D];
+        #pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+            else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+        }
+        const uint32_t index = grid_index<D, C>(gridtype, align_corners, hashmap_size, resolution, pgl) + ch;
+        if constexpr (sizeof(T) == 2) {
+            if constexpr (N_C == 2) atomic_add_h2((__half *)grad_grid + index, w * grad_cur[0], w * grad_cur[1]);
+            else atomic_add_h1((__half *)grad_grid + index, w * grad_cur[0]);
+        } else {
+            #pragma unroll
+            for (uint32_t c = 0; c < N_C; c++) atomic_add_f32((float *)grad_grid + index + c, w * grad_cur[c]);
+        }
+    }
+}
+
+// gridencoder.cu:343-369    grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(256) k_grid_input_bwd(const T *__restrict__ grad, const T *__restrict__ dy_dx, T *__restrict__ grad_inputs,
+                                                        uint32_t B, uint32_t L) {
+    const uint32_t t = threadIdx.x + blockIdx.x * blockDim.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    const T *dd = dy_dx + (size_t)b * L * D * C;
+    float result = 0;
+    for (uint32_t l = 0; l < L; l++) {
+        #pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) {
+            const float g = Num<T>::ld(grad + ((size_t)l * B + b) * C + ch);
+            const float x = Num<T>::ld(dd + (size_t)l * D * C + d * C + ch);
+            // at::Half: (Half*Half -> Half) then (Half += Half); float: plain fma-free mul, add
+            result = Num<T>::rnd(result + Num<T>::rnd(g * x));
+        }
+    }
+    Num<T>::st(grad_inputs + t, result);
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+int fill_levels(LevelParams &lp, const int32_t *offsets_host, uint32_t L, float S, uint32_t H) {
+    if (L == 0 || L > kMaxLevels) return SDN_E_UNSUPPORTED;
+    for (uint32_t l = 0; l < L; l++) {
+        lp.offset[l] = (uint32_t)offsets_host[l];
+        lp.hashmap_size[l] = (uint32_t)(offsets_host[l + 1] - offsets_host[l]);
+        if (lp.hashmap_size[l] == 0) return SDN_E_BADARG;
+        // gridencoder.cu:138-139, evaluated once on the host instead of per thread
+        const float scale = exp2f((float)l * S) * (float)H - 1.0f;
+        lp.scale[l] = scale;
+        lp.resolution[l] = (uint32_t)ceil((double)scale) + 1;
+    }
+    return 0;
+}
+
+template <typename T, uint32_t D, uint32_t C>
+void launch_fwd(const float *inputs, const T *emb, T *out, uint32_t B, uint32_t L, const LevelParams &lp, T *dy_dx, uint32_t gridtype,
+                bool ac, uint32_t interp, hipStream_t st) {
+    const dim3 grid(sdn_div_up(B, 256u), L, 1);
+    if (dy_dx) hipLaunchKernelGGL((k_grid_fwd<T, D, C, true>), grid, dim3(256), 0, st, inputs, emb, out, B, L, lp, dy_dx, gridtype, ac, interp);
+    else hipLaunchKernelGGL((k_grid_fwd<T, D, C, false>), grid, dim3(256), 0, st, inputs, emb, out, B, L, lp, dy_dx, gridtype, ac, interp);
+}
+
+template <typename T, uint32_t D>
+int dispatch_fwd_c(uint32_t C, const float *inputs, const T *emb, T *out, uint32_t B, uint32_t L, const LevelParams &lp, T *dy_dx,
+                   uint32_t gridtype, bool ac, uint32_t interp, hipStream_t st) {
+    switch (C) {
+        case 1: launch_fwd<T, D, 1>(inputs, emb, out, B, L, lp, dy_dx, gridtype, ac, interp, st); break;
+        case 2: launch_fwd<T, D, 2>(inputs, emb, out, B, L, lp, dy_dx, gridtype, ac, interp, st); break;
+        case 4: launch_fwd<T, D, 4>(inputs, emb, out, B, L, lp, dy_dx, gridtype, ac, interp, st); break;
+        case 8: launch_fwd<T, D, 8>(inputs, emb, out, B, L, lp, dy_dx, gridtype, ac, interp, st); break;
+        default: return SDN_E_UNSUPPORTED;  // "GridEncoding: C must be 1, 2, 4, or 8." gridencoder.cu:381
+    }
+    return 0;
+}
+
+template <typename T>
+int dispatch_fwd(uint32_t D, uint32_t C, const float *inputs, const T *emb, T *out, uint32_t B, uint32_t L, const LevelParams &lp, T *dy_dx,
+                 uint32_t gridtype, bool ac, uint32_t interp, hipStream_t st) {
+    switch (D) {
+        case 2: return dispatch_fwd_c<T, 2>(C, inputs, emb, out, B, L, lp, dy_dx, gridtype, ac, interp, st);
+        case 3: return dispatch_fwd_c<T, 3>(C, inputs, emb, out, B, L, lp, dy_dx, gridtype, ac, interp, st);
+        case 4: return dispatch_fwd_c<T, 4>(C, inputs, emb, out, B, L, lp, dy_dx, gridtype, ac, interp, st);
+        case 5: return dispatch_fwd_c<T, 5>(C, inputs, emb, out, B, L, lp, dy_dx, gridtype, ac, interp, st);
+        default: return SDN_E_UNSUPPORTED;
+    }
+}
+
+template <typename T, uint32_t D, uint32_t C, uint32_t N_C>
+void launch_bwd(const T *grad, const float *inputs, T *gg, uint32_t B, uint32_t L, const LevelParams &lp, const T *dy_dx, T *gi,
+                uint32_t gridtype, bool ac, uint32_t interp, hipStream_t st) {
+    const dim3 grid(sdn_div_up(B * C / N_C, 256u), L, 1);
+    hipLaunchKernelGGL((k_grid_bwd<T, D, C, N_C>), grid, dim3(256), 0, st, grad, inputs, gg, B, L, lp, gridtype, ac, interp);
+    if (dy_dx && gi) hipLaunchKernelGGL((k_grid_input_bwd<T, D, C>), dim3(sdn_div_up(B * D, 256u)), dim3(256), 0, st, grad, dy_dx, gi, B, L);
+}
+
+template <typename T, uint32_t D>
+int dispatch_bwd_c(uint32_t C, const T *grad, const float *inputs, T *gg, uint32_t B, uint32_t L, const LevelParams &lp, const T *dy_dx, T *gi,
+                   uint32_t gridtype, bool ac, uint32_t interp, hipStream_t st) {
+    switch (C) {
+        case 1: launch_bwd<T, D, 1, 1>(grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st); break;
+        case 2: launch_bwd<T, D, 2, 2>(grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st); break;
+        case 4: launch_bwd<T, D, 4, 2>(grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st); break;
+        case 8: launch_bwd<T, D, 8, 2>(grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st); break;
+        default: return SDN_E_UNSUPPORTED;
+    }
+    return 0;
+}
+
+template <typename T>
+int dispatch_bwd(uint32_t D, uint32_t C, const T *grad, const float *inputs, T *gg, uint32_t B, uint32_t L, const LevelParams &lp,
+                 const T *dy_dx, T *gi, uint32_t gridtype, bool ac, uint32_t interp, hipStream_t st) {
+    switch (D) {
+        case 2: return dispatch_bwd_c<T, 2>(C, grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st);
+        case 3: return dispatch_bwd_c<T, 3>(C, grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st);
+        case 4: return dispatch_bwd_c<T, 4>(C, grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st);
+        case 5: return dispatch_bwd_c<T, 5>(C, grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st);
+        default: return SDN_E_UNSUPPORTED;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sdn_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets_host, void *outputs, uint32_t B,
+                            uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx, uint32_t gridtype,
+                            int align_corners, uint32_t interp, int dtype, void *stream) {
+    if (B == 0) return 0;
+    if (!inputs || !embeddings || !offsets_host || !outputs) return SDN_E_BADARG;
+    if (gridtype > 1 || interp > 1) return SDN_E_UNSUPPORTED;
+    LevelParams lp;
+    int rc = fill_levels(lp, offsets_host, L, S, H);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SDN_F32)
+        rc = dispatch_fwd<float>(D, C, inputs, (const float *)embeddings, (float *)outputs, B, L, lp, (float *)dy_dx, gridtype,
+                                 align_corners != 0, interp, st);
+    else if (dtype == SDN_F16)
+        rc = dispatch_fwd<__half>(D, C, inputs, (const __half *)embeddings, (__half *)outputs, B, L, lp, (__half *)dy_dx, gridtype,
+                                  align_corners != 0, interp, st);
+    else
+        return SDN_E_UNSUPPORTED;
+    return rc ? rc : sdn_launch_status();
+}
+
+int sdn_grid_encode_backward(const void *grad, const float *inputs, const int32_t *offsets_host, void *grad_embeddings, uint32_t B,
+                             uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const void *dy_dx, void *grad_inputs,
+                             uint32_t gridtype, int align_corners, uint32_t interp, int dtype, void *stream) {
+    if (B == 0) return 0;
+    if (!grad || !inputs || !offsets_host || !grad_embeddings) return SDN_E_BADARG;
+    if (gridtype > 1 || interp > 1) return SDN_E_UNSUPPORTED;
+    LevelParams lp;
+    int rc = fill_levels(lp, offsets_host, L, S, H);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SDN_F32)
+        rc = dispatch_bwd<float>(D, C, (const float *)grad, inputs, (float *)grad_embeddings, B, L, lp, (const float *)dy_dx,
+                                 (float *)grad_inputs, gridtype, align_corners != 0, interp, st);
+    else if (dtype == SDN_F16)
+        rc = dispatch_bwd<__half>(D, C, (const __half *)grad, inputs, (__half *)grad_embeddings, B, L, lp, (const __half *)dy_dx,
+                                  (__half *)grad_inputs, gridtype, align_corners != 0, interp, st);
+    else
+        return SDN_E_UNSUPPORTED;
+    return rc ? rc : sdn_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,644 @@
+// Occupancy-grid ray marching + alpha compositing for gfx950 (MI355X).
+//
+// Behavioural contract: raymarching/src/raymarching.cu of the reference
+// (line ranges cited per kernel).  Arithmetic contract: this file is built with
+// -ffp-contract=off so that every float operation rounds on its own, in the
+// order the reference source writes it -- which is what oracle/sdn_oracle.c
+// evaluates on the CPU; ray/sample indices and counts are therefore bit-exact
+// against the oracle, not merely close.
+//
+// Layout notes (MI355X): one lane per ray, 256-thread workgroups (4 waves, one
+// per SIMD).  The density bitfield of one time slice is 256 KiB and lives in the
+// XCD's L2 after first touch; the marcher is bound by dependent L2 byte gathers
+// and by wave divergence, not by HBM.  Rays keep image order in rays_alive
+// (stable compaction), so a wave's 64 rays are neighbouring pixels and take
+// similar trip counts.
+#include "sdn_common.h"
+
+namespace {
+
+constexpr float kSqrt3 = 1.7320508075688772f;
+constexpr float kRPi = 0.3183098861837907f;
+
+__device__ __forceinline__ float signf_(float x) { return copysignf(1.0f, x); }
+__device__ __forceinline__ float clampf_(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+
+// raymarching.cu:42-47
+__device__ __forceinline__ int mip_from_pos(float x, float y, float z, float max_cascade) {
+    const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    int exponent;
+    frexpf(mx, &exponent);
+    return (int)fminf(max_cascade - 1, fmaxf(0.0f, (float)exponent));
+}
+// raymarching.cu:49-54
+__device__ __forceinline__ int mip_from_dt(float dt, float H, float max_cascade) {
+    const float mx = (float)((double)(dt * H) * 0.5);
+    int exponent;
+    frexpf(mx, &exponent);
+    return (int)fminf(max_cascade - 1, fmaxf(0.0f, (float)exponent));
+}
+// raymarching.cu:56-81
+__host__ __device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__host__ __device__ __forceinline__ uint32_t morton3D_(uint32_t x, uint32_t y, uint32_t z) {
+    return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
+}
+__host__ __device__ __forceinline__ uint32_t morton3D_invert_(uint32_t x) {
+    x = x & 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    x = (x | (x >> 16)) & 0x0000ffffu;
+    return x;
+}
+
+// ---------------------------------------------------------------------------
+// The DDA stepper shared by the three marching kernels
+// (raymarching.cu:359-400 == 427-479 == 750-804).
+// ---------------------------------------------------------------------------
+struct Marcher {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
+    float rH, H3, Hf, Cf, Hm1;
+    float bound, dt_gamma, dt_min, dt_max;
+    double Hd;
+    const uint8_t *__restrict__ grid;
+
+    __device__ __forceinline__ void init(const float *o, const float *d, float bound_, float dt_gamma_,
+                                         uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid_) {
+        ox = o[0]; oy = o[1]; oz = o[2];
+        dx = d[0]; dy = d[1]; dz = d[2];
+        rdx = 1 / dx; rdy = 1 / dy; rdz = 1 / dz;
+        rH = 1 / (float)H;
+        H3 = (float)(H * H * H);
+        Hf = (float)H; Hd = (double)H; Cf = (float)C; Hm1 = (float)(H - 1);
+        bound = bound_; dt_gamma = dt_gamma_;
+        dt_min = 2 * kSqrt3 / (float)max_steps;
+        dt_max = 2 * kSqrt3 * (float)(1 << (C - 1)) / (float)H;
+        grid = grid_;
+    }
+
+    __device__ __forceinline__ float step_size(float t) const { return clampf_(t * dt_gamma, dt_min, dt_max); }
+
+    // One loop-body evaluation at parameter t.  Occupied: returns true with the sample in
+    // (x,y,z,dt), t untouched.  Empty: returns false with t advanced past the voxel.
+    __device__ __forceinline__ bool probe(float &t, float &x, float &y, float &z, float &dt) const {
+        x = clampf_(ox + t * dx, -bound, bound);
+        y = clampf_(oy + t * dy, -bound, bound);
+        z = clampf_(oz + t * dz, -bound, bound);
+        dt = step_size(t);
+        const int l0 = mip_from_pos(x, y, z, Cf), l1 = mip_from_dt(dt, Hf, Cf);
+        const int level = l0 > l1 ? l0 : l1;
+        const float mip_bound = fminf(scalbnf(1.0f, level), bound);
+        const float mip_rbound = 1 / mip_bound;
+        // `0.5 * (...) * H` is a double expression in the reference (0.5 is a double literal)
+        const int nx = (int)clampf_((float)(0.5 * (double)(x * mip_rbound + 1) * Hd), 0.0f, Hm1);
+        const int ny = (int)clampf_((float)(0.5 * (double)(y * mip_rbound + 1) * Hd), 0.0f, Hm1);
+        const int nz = (int)clampf_((float)(0.5 * (double)(z * mip_rbound + 1) * Hd), 0.0f, Hm1);
+        const uint32_t index = (uint32_t)((float)level * H3 + (float)morton3D_((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+        const bool occ = grid[index >> 3] & (1u << (index & 7u));
+        if (occ) return true;
+        const float tx = (((nx + 0.5f + 0.5f * signf_(dx)) * rH * 2 - 1) * mip_bound - x) * rdx;
+        const float ty = (((ny + 0.5f + 0.5f * signf_(dy)) * rH * 2 - 1) * mip_bound - y) * rdy;
+        const float tz = (((nz + 0.5f + 0.5f * signf_(dz)) * rH * 2 - 1) * mip_bound - z) * rdz;
+        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        do {
+            t += step_size(t);
+        } while (t < tt);
+        return false;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// utils
+// ---------------------------------------------------------------------------
+// raymarching.cu:92-145
+__global__ void __launch_bounds__(256) k_near_far_from_aabb(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                            const float *__restrict__ aabb, uint32_t N, float min_near,
+                                                            float *__restrict__ nears, float *__restrict__ fars) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float rdx = 1 / rays_d[n * 3], rdy = 1 / rays_d[n * 3 + 1], rdz = 1 / rays_d[n * 3 + 2];
+    const float mx = __FLT_MAX__;
+    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx;
+    if (near > far) { float c = near; near = far; far = c; }
+    float near_y = (aabb[1] - oy) * rdy, far_y = (aabb[4] - oy) * rdy;
+    if (near_y > far_y) { float c = near_y; near_y = far_y; far_y = c; }
+    if (near > far_y || near_y > far) { nears[n] = mx; fars[n] = mx; return; }
+    if (near_y > near) near = near_y;
+    if (far_y < far) far = far_y;
+    float near_z = (aabb[2] - oz) * rdz, far_z = (aabb[5] - oz) * rdz;
+    if (near_z > far_z) { float c = near_z; near_z = far_z; far_z = c; }
+    if (near > far_z || near_z > far) { nears[n] = mx; fars[n] = mx; return; }
+    if (near_z > near) near = near_z;
+    if (far_z < far) far = far_z;
+    if (near < min_near) near = min_near;
+    nears[n] = near;
+    fars[n] = far;
+}
+
+// raymarching.cu:163-198
+__global__ void __launch_bounds__(256) k_sph_from_ray(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                      float radius, uint32_t N, float *__restrict__ coords) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    const float A = dx * dx + dy * dy + dz * dz;
+    const float B = ox * dx + oy * dy + oz * dz;
+    const float C = ox * ox + oy * oy + oz * oz - radius * radius;
+    const float t = (-B + sqrtf(B * B - A * C)) / A;
+    const float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+    const float theta = atan2f(sqrtf(x * x + z * z), y);
+    const float phi = atan2f(z, x);
+    coords[n * 2] = 2 * theta * kRPi - 1;
+    coords[n * 2 + 1] = phi * kRPi;
+}
+
+// raymarching.cu:214-254
+__global__ void __launch_bounds__(256) k_morton3D(const int32_t *__restrict__ coords, uint32_t N, int32_t *__restrict__ indices) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    indices[n] = (int32_t)morton3D_((uint32_t)coords[n * 3], (uint32_t)coords[n * 3 + 1], (uint32_t)coords[n * 3 + 2]);
+}
+__global__ void __launch_bounds__(256) k_morton3D_invert(const int32_t *__restrict__ indices, uint32_t N, int32_t *__restrict__ coords) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const int ind = indices[n];
+    coords[n * 3] = (int32_t)morton3D_invert_((uint32_t)(ind >> 0));
+    coords[n * 3 + 1] = (int32_t)morton3D_invert_((uint32_t)(ind >> 1));
+    coords[n * 3 + 2] = (int32_t)morton3D_invert_((uint32_t)(ind >> 2));
+}
+
+// raymarching.cu:268-289.  One lane per output byte; the 8 floats are fetched as two float4
+// (32 B per lane, 2 KiB per wave-instruction pair: fully coalesced).
+__global__ void __launch_bounds__(256) k_packbits(const float4 *__restrict__ grid, uint32_t N, float thresh, uint8_t *__restrict__ bitfield) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const float4 a = grid[(size_t)n * 2], b = grid[(size_t)n * 2 + 1];
+    uint32_t bits = 0;
+    bits |= (a.x > thresh) ? 1u : 0u;
+    bits |= (a.y > thresh) ? 2u : 0u;
+    bits |= (a.z > thresh) ? 4u : 0u;
+    bits |= (a.w > thresh) ? 8u : 0u;
+    bits |= (b.x > thresh) ? 16u : 0u;
+    bits |= (b.y > thresh) ? 32u : 0u;
+    bits |= (b.z > thresh) ? 64u : 0u;
+    bits |= (b.w > thresh) ? 128u : 0u;
+    bitfield[n] = (uint8_t)bits;
+}
+
+// ---------------------------------------------------------------------------
+// training march: count pass -> deterministic exclusive scan -> write pass
+// (raymarching.cu:312-480; the reference allocates slots with two racing atomicAdds)
+// ---------------------------------------------------------------------------
+constexpr uint32_t kScanBlock = 1024;
+
+__global__ void __launch_bounds__(256) k_march_train_count(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                           const uint8_t *__restrict__ grid, float bound, float dt_gamma,
+                                                           uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                                           const float *__restrict__ nears, const float *__restrict__ fars,
+                                                           const float *__restrict__ noises, uint32_t *__restrict__ num_steps_out) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    Marcher m;
+    m.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid);
+    const float far = fars[n];
+    float t = nears[n];
+    t += m.step_size(t) * noises[n];
+    uint32_t num_steps = 0;
+    float x, y, z, dt;
+    while (t < far && num_steps < max_steps) {
+        if (m.probe(t, x, y, z, dt)) { num_steps++; t += dt; }
+    }
+    num_steps_out[n] = num_steps;
+}
+
+// Block-level inclusive scan of one uint32 per thread (1024 threads = 16 waves): DPP-free,
+// __shfl_up based wave scan + LDS carry.
+__device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t *lds /*[16]*/, uint32_t &block_total) {
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    #pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(v, off, 64);
+        if (lane >= (uint32_t)off) v += u;
+    }
+    if (lane == 63) lds[wid] = v;
+    __syncthreads();
+    uint32_t carry = 0, total = 0;
+    const uint32_t nw = blockDim.x >> 6;
+    for (uint32_t w = 0; w < nw; w++) {
+        const uint32_t s = lds[w];
+        if (w < wid) carry += s;
+        total += s;
+    }
+    block_total = total;
+    __syncthreads();
+    return v + carry;
+}
+
+// pass A: per-block totals
+__global__ void __launch_bounds__(kScanBlock) k_scan_block_totals(const uint32_t *__restrict__ vals, uint32_t N, uint32_t *__restrict__ block_totals) {
+    __shared__ uint32_t lds[16];
+    const uint32_t i = blockIdx.x * kScanBlock + threadIdx.x;
+    uint32_t total;
+    block_inclusive_scan(i < N ? vals[i] : 0u, lds, total);
+    if (threadIdx.x == 0) block_totals[blockIdx.x] = total;
+}
+
+// pass B: offsets[i] = exclusive scan (every block re-sums the totals of the blocks before it:
+// <= 625 L2-resident words for a full 800x800 frame); writes rays[] and bumps counter[] like
+// the reference's atomics would, but in ray order.
+__global__ void __launch_bounds__(kScanBlock) k_march_train_offsets(const uint32_t *__restrict__ num_steps, uint32_t N,
+                                                                    const uint32_t *__restrict__ block_totals,
+                                                                    int32_t *__restrict__ rays, int32_t *__restrict__ counter,
+                                                                    uint32_t *__restrict__ base_out) {
+    __shared__ uint32_t lds[16];
+    __shared__ uint32_t s_prev;
+    // sum of previous blocks' totals, cooperatively
+    uint32_t part = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kScanBlock) part += block_totals[b];
+    uint32_t prev_total;
+    block_inclusive_scan(part, lds, prev_total);
+    if (threadIdx.x == 0) s_prev = prev_total;
+    __syncthreads();
+    const uint32_t base = (uint32_t)counter[0];  // reference semantics: slots start at the counter's current value
+    const uint32_t ray_base = (uint32_t)counter[1];
+    const uint32_t i = blockIdx.x * kScanBlock + threadIdx.x;
+    const uint32_t v = i < N ? num_steps[i] : 0u;
+    uint32_t total;
+    const uint32_t incl = block_inclusive_scan(v, lds, total);
+    if (i < N) {
+        const uint32_t ri = ray_base + i;
+        rays[ri * 3] = (int32_t)i;
+        rays[ri * 3 + 1] = (int32_t)(base + s_prev + incl - v);
+        rays[ri * 3 + 2] = (int32_t)v;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        base_out[0] = base;  // consumed by the write pass; counter itself is bumped by k_march_train_finish
+        base_out[1] = s_prev + total;
+    }
+}
+
+__global__ void k_march_train_finish(int32_t *__restrict__ counter, const uint32_t *__restrict__ base_out, uint32_t N) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        counter[0] += (int32_t)base_out[1];
+        counter[1] += (int32_t)N;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_march_train_write(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                           const uint8_t *__restrict__ grid, float bound, float dt_gamma,
+                                                           uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                                           const float *__restrict__ nears, const float *__restrict__ fars,
+                                                           const float *__restrict__ noises, const int32_t *__restrict__ rays,
+                                                           const int32_t *__restrict__ counter, float *__restrict__ xyzs,
+                                                           float *__restrict__ dirs, float *__restrict__ deltas) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const uint32_t ray_base = (uint32_t)counter[1];  // not yet bumped: k_march_train_finish runs after this kernel
+    const uint32_t point_index = (uint32_t)rays[(size_t)(ray_base + n) * 3 + 1];
+    const uint32_t num_steps = (uint32_t)rays[(size_t)(ray_base + n) * 3 + 2];
+    if (num_steps == 0) return;
+    if (point_index + num_steps > M) return;
+    Marcher m;
+    m.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid);
+    const float far = fars[n];
+    float t = nears[n];
+    t += m.step_size(t) * noises[n];
+    float *px = xyzs + (size_t)point_index * 3, *pd = dirs + (size_t)point_index * 3, *pl = deltas + (size_t)point_index * 2;
+    uint32_t step = 0;
+    float last_t = t, x, y, z, dt;
+    while (t < far && step < num_steps) {
+        if (m.probe(t, x, y, z, dt)) {
+            px[0] = x; px[1] = y; px[2] = z;
+            pd[0] = m.dx; pd[1] = m.dy; pd[2] = m.dz;
+            t += dt;
+            pl[0] = dt;
+            pl[1] = t - last_t;
+            last_t = t;
+            px += 3; pd += 3; pl += 2;
+            step++;
+        }
+    }
+}
+
+// raymarching.cu:501-577
+__global__ void __launch_bounds__(256) k_composite_train_fwd(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                                             const float *__restrict__ deltas, const int32_t *__restrict__ rays,
+                                                             uint32_t M, uint32_t N, float T_thresh, float *__restrict__ weights_sum,
+                                                             float *__restrict__ depth, float *__restrict__ image) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    if (num_steps == 0 || offset + num_steps > M) {
+        weights_sum[index] = 0; depth[index] = 0;
+        image[(size_t)index * 3] = 0; image[(size_t)index * 3 + 1] = 0; image[(size_t)index * 3 + 2] = 0;
+        return;
+    }
+    const float *s = sigmas + offset, *c = rgbs + (size_t)offset * 3, *dl = deltas + (size_t)offset * 2;
+    uint32_t step = 0;
+    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0;
+    while (step < num_steps) {
+        const float alpha = 1.0f - sdn_exp_cr(-s[0] * dl[0]);
+        const float weight = alpha * T;
+        r += weight * c[0]; g += weight * c[1]; b += weight * c[2];
+        t += dl[1];
+        d += weight * t;
+        ws += weight;
+        T *= 1.0f - alpha;
+        if (T < T_thresh) break;
+        s++; c += 3; dl += 2; step++;
+    }
+    weights_sum[index] = ws; depth[index] = d;
+    image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
+}
+
+// raymarching.cu:602-682
+__global__ void __launch_bounds__(256) k_composite_train_bwd(const float *__restrict__ grad_weights_sum, const float *__restrict__ grad_image,
+                                                             const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                                             const float *__restrict__ deltas, const int32_t *__restrict__ rays,
+                                                             const float *__restrict__ weights_sum, const float *__restrict__ image,
+                                                             uint32_t M, uint32_t N, float T_thresh, float *__restrict__ grad_sigmas,
+                                                             float *__restrict__ grad_rgbs) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    if (num_steps == 0 || offset + num_steps > M) return;
+    const float gws = grad_weights_sum[index];
+    const float gi0 = grad_image[(size_t)index * 3], gi1 = grad_image[(size_t)index * 3 + 1], gi2 = grad_image[(size_t)index * 3 + 2];
+    const float r_final = image[(size_t)index * 3], g_final = image[(size_t)index * 3 + 1], b_final = image[(size_t)index * 3 + 2];
+    const float ws_final = weights_sum[index];
+    const float *s = sigmas + offset, *c = rgbs + (size_t)offset * 3, *dl = deltas + (size_t)offset * 2;
+    float *gs = grad_sigmas + offset, *gc = grad_rgbs + (size_t)offset * 3;
+    uint32_t step = 0;
+    float T = 1.0f, r = 0, g = 0, b = 0;
+    while (step < num_steps) {
+        const float alpha = 1.0f - sdn_exp_cr(-s[0] * dl[0]);
+        const float weight = alpha * T;
+        r += weight * c[0]; g += weight * c[1]; b += weight * c[2];
+        T *= 1.0f - alpha;
+        gc[0] = gi0 * weight; gc[1] = gi1 * weight; gc[2] = gi2 * weight;
+        gs[0] = dl[0] * (gi0 * (T * c[0] - (r_final - r)) + gi1 * (T * c[1] - (g_final - g)) +
+                         gi2 * (T * c[2] - (b_final - b)) + gws * (1 - ws_final));
+        if (T < T_thresh) break;
+        s++; c += 3; dl += 2; gs++; gc += 3; step++;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// inference
+// ---------------------------------------------------------------------------
+// raymarching.cu:701-805.  Slots [step, n_step) of each alive ray are written as zeros here, so
+// the caller only has to clear the alignment tail, not the whole buffer.
+__global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
+                                                    const float *__restrict__ rays_t, const float *__restrict__ rays_o,
+                                                    const float *__restrict__ rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                                                    uint32_t C, uint32_t H, const uint8_t *__restrict__ grid,
+                                                    const float *__restrict__ fars, float *__restrict__ xyzs, float *__restrict__ dirs,
+                                                    float *__restrict__ deltas, const float *__restrict__ noises) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    Marcher m;
+    m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid);
+    float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3, *pl = deltas + (size_t)n * n_step * 2;
+    float t = rays_t[index];
+    const float far = fars[index];
+    uint32_t step = 0;
+    t += m.step_size(t) * (noises ? noises[n] : 0.0f);
+    float last_t = t, x, y, z, dt;
+    while (t < far && step < n_step) {
+        if (m.probe(t, x, y, z, dt)) {
+            px[0] = x; px[1] = y; px[2] = z;
+            pd[0] = m.dx; pd[1] = m.dy; pd[2] = m.dz;
+            t += dt;
+            pl[0] = dt;
+            pl[1] = t - last_t;
+            last_t = t;
+            px += 3; pd += 3; pl += 2;
+            step++;
+        }
+    }
+    for (; step < n_step; step++) {
+        px[0] = 0; px[1] = 0; px[2] = 0;
+        pd[0] = 0; pd[1] = 0; pd[2] = 0;
+        pl[0] = 0; pl[1] = 0;
+        px += 3; pd += 3; pl += 2;
+    }
+}
+
+// raymarching.cu:819-905
+__global__ void __launch_bounds__(256) k_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *__restrict__ rays_alive,
+                                                        float *__restrict__ rays_t, const float *__restrict__ sigmas,
+                                                        const float *__restrict__ rgbs, const float *__restrict__ deltas,
+                                                        float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    const float *s = sigmas + (size_t)n * n_step, *c = rgbs + (size_t)n * n_step * 3, *dl = deltas + (size_t)n * n_step * 2;
+    float t = rays_t[index];
+    float weight_sum = weights_sum[index], d = depth[index];
+    float r = image[(size_t)index * 3], g = image[(size_t)index * 3 + 1], b = image[(size_t)index * 3 + 2];
+    uint32_t step = 0;
+    while (step < n_step) {
+        if (dl[0] == 0) break;
+        const float alpha = 1.0f - sdn_exp_cr(-s[0] * dl[0]);
+        const float T = 1 - weight_sum;
+        const float weight = alpha * T;
+        weight_sum += weight;
+        t += dl[1];
+        d += weight * t;
+        r += weight * c[0]; g += weight * c[1]; b += weight * c[2];
+        if (T < T_thresh) break;
+        s++; c += 3; dl += 2; step++;
+    }
+    if (step < n_step) rays_alive[n] = -1;
+    else rays_t[index] = t;
+    weights_sum[index] = weight_sum; depth[index] = d;
+    image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
+}
+
+// ---------------------------------------------------------------------------
+// stable compaction of rays_alive >= 0 (replaces the torch mask-select of dnerf/renderer.py:372)
+// two launches: per-block survivor counts (wave ballot + popcount), then scatter.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kScanBlock) k_compact_count(const int32_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ block_totals) {
+    __shared__ uint32_t lds[16];
+    const uint32_t i = blockIdx.x * kScanBlock + threadIdx.x;
+    const bool keep = i < n && in[i] >= 0;
+    const unsigned long long mask = __ballot(keep);
+    if ((threadIdx.x & 63u) == 0) lds[threadIdx.x >> 6] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (uint32_t w = 0; w < (kScanBlock >> 6); w++) t += lds[w];
+        block_totals[blockIdx.x] = t;
+    }
+}
+
+__global__ void __launch_bounds__(kScanBlock) k_compact_scatter(const int32_t *__restrict__ in, uint32_t n, const uint32_t *__restrict__ block_totals,
+                                                                int32_t *__restrict__ out, int32_t *__restrict__ n_out) {
+    __shared__ uint32_t lds[16];
+    __shared__ uint32_t s_prev;
+    uint32_t part = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kScanBlock) part += block_totals[b];
+    uint32_t prev_total;
+    block_inclusive_scan(part, lds, prev_total);
+    if (threadIdx.x == 0) s_prev = prev_total;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * kScanBlock + threadIdx.x;
+    const int32_t v = i < n ? in[i] : -1;
+    const bool keep = v >= 0;
+    const unsigned long long mask = __ballot(keep);
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    const uint32_t below = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) lds[wid] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t carry = 0, total = 0;
+    for (uint32_t w = 0; w < (kScanBlock >> 6); w++) {
+        const uint32_t c = lds[w];
+        if (w < wid) carry += c;
+        total += c;
+    }
+    if (keep) out[s_prev + carry + below] = v;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) n_out[0] = (int32_t)(s_prev + total);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int sdn_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near,
+                           float *nears, float *fars, void *stream) {
+    if (N == 0) return 0;
+    if (!rays_o || !rays_d || !aabb || !nears || !fars) return SDN_E_BADARG;
+    hipLaunchKernelGGL(k_near_far_from_aabb, dim3(sdn_div_up(N, 256u)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, aabb, N,
+                       min_near, nears, fars);
+    return sdn_launch_status();
+}
+
+int sdn_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords, void *stream) {
+    if (N == 0) return 0;
+    if (!rays_o || !rays_d || !coords) return SDN_E_BADARG;
+    hipLaunchKernelGGL(k_sph_from_ray, dim3(sdn_div_up(N, 256u)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, radius, N, coords);
+    return sdn_launch_status();
+}
+
+int sdn_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, void *stream) {
+    if (N == 0) return 0;
+    if (!coords || !indices) return SDN_E_BADARG;
+    hipLaunchKernelGGL(k_morton3D, dim3(sdn_div_up(N, 256u)), dim3(256), 0, (hipStream_t)stream, coords, N, indices);
+    return sdn_launch_status();
+}
+
+int sdn_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, void *stream) {
+    if (N == 0) return 0;
+    if (!coords || !indices) return SDN_E_BADARG;
+    hipLaunchKernelGGL(k_morton3D_invert, dim3(sdn_div_up(N, 256u)), dim3(256), 0, (hipStream_t)stream, indices, N, coords);
+    return sdn_launch_status();
+}
+
+int sdn_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield, void *stream) {
+    if (N == 0) return 0;
+    if (!grid || !bitfield) return SDN_E_BADARG;
+    if (((uintptr_t)grid & 15u) != 0) return SDN_E_BADARG;  // float4 loads
+    hipLaunchKernelGGL(k_packbits, dim3(sdn_div_up(N, 256u)), dim3(256), 0, (hipStream_t)stream, (const float4 *)grid, N, density_thresh,
+                       bitfield);
+    return sdn_launch_status();
+}
+
+uint64_t sdn_march_rays_train_scratch_bytes(uint32_t N) {
+    // num_steps[N] + block_totals[ceil(N/1024)] + base_out[2]
+    return ((uint64_t)N + sdn_div_up(N, kScanBlock) + 2u) * sizeof(uint32_t);
+}
+
+int sdn_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                         uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears,
+                         const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
+                         const float *noises, void *scratch, void *stream) {
+    if (N == 0) return 0;
+    if (!rays_o || !rays_d || !grid || !nears || !fars || !xyzs || !dirs || !deltas || !rays || !counter || !noises || !scratch)
+        return SDN_E_BADARG;
+    if (C == 0 || C > 16 || H == 0 || max_steps == 0) return SDN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t *num_steps = (uint32_t *)scratch;
+    const uint32_t nb = sdn_div_up(N, kScanBlock);
+    uint32_t *block_totals = num_steps + N;
+    uint32_t *base_out = block_totals + nb;
+    hipLaunchKernelGGL(k_march_train_count, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N,
+                       C, H, nears, fars, noises, num_steps);
+    hipLaunchKernelGGL(k_scan_block_totals, dim3(nb), dim3(kScanBlock), 0, st, num_steps, N, block_totals);
+    // The reference writes ray records at rays[atomicAdd(counter+1, 1)] and points at atomicAdd(counter, n):
+    // both bases are read on the device from the counter the caller hands in (zeroed by dnerf/renderer.py:291-292).
+    hipLaunchKernelGGL(k_march_train_offsets, dim3(nb), dim3(kScanBlock), 0, st, num_steps, N, block_totals, rays, counter, base_out);
+    hipLaunchKernelGGL(k_march_train_write, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N,
+                       C, H, M, nears, fars, noises, rays, counter, xyzs, dirs, deltas);
+    hipLaunchKernelGGL(k_march_train_finish, dim3(1), dim3(64), 0, st, counter, base_out, N);
+    return sdn_launch_status();
+}
+
+int sdn_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, uint32_t M,
+                                     uint32_t N, float T_thresh, float *weights_sum, float *depth, float *image, void *stream) {
+    if (N == 0) return 0;
+    if (!sigmas || !rgbs || !deltas || !rays || !weights_sum || !depth || !image) return SDN_E_BADARG;
+    hipLaunchKernelGGL(k_composite_train_fwd, dim3(sdn_div_up(N, 256u)), dim3(256), 0, (hipStream_t)stream, sigmas, rgbs, deltas, rays, M, N,
+                       T_thresh, weights_sum, depth, image);
+    return sdn_launch_status();
+}
+
+int sdn_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_image, const float *sigmas, const float *rgbs,
+                                      const float *deltas, const int32_t *rays, const float *weights_sum, const float *image,
+                                      uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas, float *grad_rgbs, void *stream) {
+    if (N == 0) return 0;
+    if (!grad_weights_sum || !grad_image || !sigmas || !rgbs || !deltas || !rays || !weights_sum || !image || !grad_sigmas || !grad_rgbs)
+        return SDN_E_BADARG;
+    hipLaunchKernelGGL(k_composite_train_bwd, dim3(sdn_div_up(N, 256u)), dim3(256), 0, (hipStream_t)stream, grad_weights_sum, grad_image,
+                       sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs);
+    return sdn_launch_status();
+}
+
+int sdn_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
+                   const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                   const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
+                   const float *noises, void *stream) {
+    (void)nears;  // unused by the reference kernel as well (raymarching.cu:737)
+    if (n_alive == 0 || n_step == 0) return 0;
+    if (!rays_alive || !rays_t || !rays_o || !rays_d || !grid || !fars || !xyzs || !dirs || !deltas) return SDN_E_BADARG;
+    if (C == 0 || C > 16 || H == 0 || max_steps == 0) return SDN_E_BADARG;
+    hipLaunchKernelGGL(k_march_rays, dim3(sdn_div_up(n_alive, 256u)), dim3(256), 0, (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t,
+                       rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises);
+    return sdn_launch_status();
+}
+
+int sdn_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t, const float *sigmas,
+                       const float *rgbs, const float *deltas, float *weights_sum, float *depth, float *image, void *stream) {
+    if (n_alive == 0 || n_step == 0) return 0;
+    if (!rays_alive || !rays_t || !sigmas || !rgbs || !deltas || !weights_sum || !depth || !image) return SDN_E_BADARG;
+    hipLaunchKernelGGL(k_composite_rays, dim3(sdn_div_up(n_alive, 256u)), dim3(256), 0, (hipStream_t)stream, n_alive, n_step, T_thresh,
+                       rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+    return sdn_launch_status();
+}
+
+uint64_t sdn_compact_alive_scratch_bytes(uint32_t n) { return (uint64_t)sdn_div_up(n, kScanBlock) * sizeof(uint32_t); }
+
+int sdn_compact_alive(const int32_t *in, uint32_t n, int32_t *out, int32_t *n_out, void *scratch, void *stream) {
+    if (!n_out) return SDN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return (int)hipMemsetAsync(n_out, 0, sizeof(int32_t), st);
+    if (!in || !out || !scratch) return SDN_E_BADARG;
+    const uint32_t nb = sdn_div_up(n, kScanBlock);
+    hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(kScanBlock), 0, st, in, n, (uint32_t *)scratch);
+    hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(kScanBlock), 0, st, in, n, (const uint32_t *)scratch, out, n_out);
+    return sdn_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,145 @@
+"""Multiresolution hash / tiled grid encoder on libsdn_hip (MI355X).
+
+Same API as /root/reference/gridencoder/grid.py: `grid_encode` (autograd Function,
+:24-93) and `GridEncoder` (nn.Module, :96-161) with identical constructor arguments,
+parameter / buffer names (`embeddings`, `offsets`) and initialisation, so reference
+checkpoints load unchanged.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
+
+from sdn_backend import lib as _lib, check as _check, ptr as _ptr, stream as _stream, dtype_id as _dtype_id, require_device
+
+_gridtype_to_id = {"hash": 0, "tiled": 1}
+_interp_to_id = {"linear": 0, "smoothstep": 1}
+
+def _host_offsets(offsets):
+    """The kernels take the level offsets by value (SGPRs).  `offsets` is a small registered buffer that
+    never changes after construction; its host copy is cached ON the tensor object (one D2H copy per
+    tensor, none per call) together with the version counter that invalidates it on in-place writes."""
+    hit = getattr(offsets, "_sdn_host", None)
+    if hit is None or hit[2] != offsets._version:
+        arr = np.ascontiguousarray(offsets.detach().cpu().numpy().astype(np.int32))
+        hit = (arr, arr.ctypes.data, offsets._version)
+        offsets._sdn_host = hit
+    return hit[0], hit[1]
+
+
+class _grid_encode(Function):
+    @staticmethod
+    @custom_fwd(device_type="cuda")
+    def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
+                align_corners=False, interpolation=0):
+        """grid.py:27-63.  inputs [B,D] f32 in [0,1]; embeddings [rows,C]; offsets [L+1] int32 -> [B, L*C]."""
+        require_device()
+        inputs = inputs.contiguous()
+        if inputs.dtype != torch.float32:
+            inputs = inputs.float()
+        B, D = inputs.shape
+        L = offsets.shape[0] - 1
+        C = embeddings.shape[1]
+        S = float(np.log2(per_level_scale))
+        H = int(base_resolution)
+        # autocast handling of the reference (grid.py:41-44): half table iff autocast is on and C is even
+        if torch.is_autocast_enabled() and C % 2 == 0:
+            embeddings = embeddings.to(torch.half)
+        embeddings = embeddings.contiguous()
+        dt = _dtype_id(embeddings.dtype)
+        outputs = torch.empty(L, B, C, device=inputs.device, dtype=embeddings.dtype)
+        dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=embeddings.dtype) if calc_grad_inputs else None
+        _, off_ptr = _host_offsets(offsets)
+        _check(_lib.sdn_grid_encode_forward(_ptr(inputs, torch.float32, "inputs"), _ptr(embeddings, None, "embeddings"), off_ptr,
+                                            _ptr(outputs), B, D, C, L, S, H, _ptr(dy_dx), int(gridtype), int(bool(align_corners)),
+                                            int(interpolation), dt, _stream()), "grid_encode_forward")
+        outputs = outputs.permute(1, 0, 2).reshape(B, L * C)
+        ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
+        ctx.dims = [B, D, C, L, S, H, gridtype, interpolation]
+        ctx.align_corners = align_corners
+        return outputs
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad):
+        """grid.py:68-89: scatter-add into a zeroed table gradient (+ input gradient through dy_dx)."""
+        inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H, gridtype, interpolation = ctx.dims
+        grad = grad.view(B, L, C).permute(1, 0, 2).contiguous()
+        if grad.dtype != embeddings.dtype:
+            grad = grad.to(embeddings.dtype)
+        grad_embeddings = torch.zeros_like(embeddings)
+        grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
+        _, off_ptr = _host_offsets(offsets)
+        _check(_lib.sdn_grid_encode_backward(_ptr(grad), _ptr(inputs), off_ptr, _ptr(grad_embeddings), B, D, C, L, S, H, _ptr(dy_dx),
+                                             _ptr(grad_inputs), int(gridtype), int(bool(ctx.align_corners)), int(interpolation),
+                                             _dtype_id(embeddings.dtype), _stream()), "grid_encode_backward")
+        if dy_dx is not None:
+            grad_inputs = grad_inputs.to(inputs.dtype)
+        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None
+
+
+grid_encode = _grid_encode.apply
+
+
+class GridEncoder(nn.Module):
+    """grid.py:96-161.  Level table sizes follow :118-127 exactly (rows rounded up to a multiple of 8,
+    capped at 2**log2_hashmap_size); `embeddings` ~ U(-1e-4, 1e-4) (:138-140)."""
+
+    def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16, log2_hashmap_size=19,
+                 desired_resolution=None, gridtype="hash", align_corners=False, interpolation="linear"):
+        super().__init__()
+        if desired_resolution is not None:
+            per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
+        self.input_dim = input_dim
+        self.num_levels = num_levels
+        self.level_dim = level_dim
+        self.per_level_scale = per_level_scale
+        self.log2_hashmap_size = log2_hashmap_size
+        self.base_resolution = base_resolution
+        self.output_dim = num_levels * level_dim
+        self.gridtype = gridtype
+        self.gridtype_id = _gridtype_to_id[gridtype]
+        self.interpolation = interpolation
+        self.interp_id = _interp_to_id[interpolation]
+        self.align_corners = align_corners
+
+        offsets = []
+        offset = 0
+        self.max_params = 2 ** log2_hashmap_size
+        for i in range(num_levels):
+            resolution = int(np.ceil(base_resolution * per_level_scale ** i))
+            params_in_level = min(self.max_params, (resolution if align_corners else resolution + 1) ** input_dim)
+            params_in_level = int(np.ceil(params_in_level / 8) * 8)
+            offsets.append(offset)
+            offset += params_in_level
+        offsets.append(offset)
+        self.register_buffer("offsets", torch.from_numpy(np.array(offsets, dtype=np.int32)))
+        self.n_params = offsets[-1] * level_dim
+        self.embeddings = nn.Parameter(torch.empty(offset, level_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        std = 1e-4
+        self.embeddings.data.uniform_(-std, std)
+
+    def __repr__(self):
+        return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
+                f"resolution={self.base_resolution} -> {int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))} "
+                f"per_level_scale={self.per_level_scale:.4f} params={tuple(self.embeddings.shape)} gridtype={self.gridtype} "
+                f"align_corners={self.align_corners} interpolation={self.interpolation}")
+
+    def forward(self, inputs, bound=1):
+        """inputs [..., input_dim] in [-bound, bound] -> [..., num_levels*level_dim]  (grid.py:145-161)."""
+        inputs = (inputs + bound) / (2 * bound)
+        prefix_shape = list(inputs.shape[:-1])
+        inputs = inputs.view(-1, self.input_dim)
+        outputs = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution, inputs.requires_grad,
+                              self.gridtype_id, self.align_corners, self.interp_id)
+        return outputs.view(prefix_shape + [self.output_dim])
+
+    def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000):
+        """grid.py:164-185 (kernel_grad_tv).  Not on the dnerf / SealD-NeRF path (no caller outside grid.py);
+        out of scope for this build -- fails loudly rather than silently doing nothing."""
+        raise NotImplementedError("grad_total_variation (TV regulariser) is outside the dynamic-NeRF rendering path")

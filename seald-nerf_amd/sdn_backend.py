@@ -1,0 +1,107 @@
+"""ctypes binding of libsdn_hip.so (the C ABI declared in include/sdn_hip.h).
+
+This is the only place the Python layer touches native code.  There is no CPU
+fallback: if the library is missing the import fails, and if an operator is
+called without a HIP device (or with a tensor that is not on one) it raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsdn_hip.so")
+
+SDN_F32 = 0
+SDN_F16 = 1
+
+_c = ctypes
+_vp, _u32, _f32, _i32, _u64 = _c.c_void_p, _c.c_uint32, _c.c_float, _c.c_int, _c.c_uint64
+
+# name -> argtypes, exactly the prototypes of include/sdn_hip.h (restype int unless noted)
+PROTOTYPES = {
+    "sdn_near_far_from_aabb": [_vp, _vp, _vp, _u32, _f32, _vp, _vp, _vp],
+    "sdn_sph_from_ray": [_vp, _vp, _f32, _u32, _vp, _vp],
+    "sdn_morton3D": [_vp, _u32, _vp, _vp],
+    "sdn_morton3D_invert": [_vp, _u32, _vp, _vp],
+    "sdn_packbits": [_vp, _u32, _f32, _vp, _vp],
+    "sdn_march_rays_train": [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sdn_composite_rays_train_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp, _vp],
+    "sdn_composite_rays_train_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp],
+    "sdn_march_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sdn_composite_rays": [_u32, _u32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sdn_compact_alive": [_vp, _u32, _vp, _vp, _vp, _vp],
+    "sdn_grid_encode_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _i32, _u32, _i32, _vp],
+    "sdn_grid_encode_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _vp],
+    "sdn_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp],
+    "sdn_sh_encode_backward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp],
+    "sdn_freq_encode_forward": [_vp, _u32, _u32, _u32, _u32, _vp, _vp],
+    "sdn_freq_encode_backward": [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp],
+}
+PROTOTYPES_U64 = {
+    "sdn_march_rays_train_scratch_bytes": [_u32],
+    "sdn_compact_alive_scratch_bytes": [_u32],
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C seald-nerf_amd/csrc` (or __graft_entry__.build()). "
+        "There is no CPU fallback for the SealD-NeRF operators.")
+
+lib = ctypes.CDLL(LIB_PATH)
+lib.sdn_version.restype = ctypes.c_char_p
+for _name, _args in PROTOTYPES.items():
+    _fn = getattr(lib, _name)
+    _fn.argtypes = _args
+    _fn.restype = ctypes.c_int
+for _name, _args in PROTOTYPES_U64.items():
+    _fn = getattr(lib, _name)
+    _fn.argtypes = _args
+    _fn.restype = ctypes.c_uint64
+
+
+class SdnError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "bad argument", -2: "unsupported configuration"}.get(rc, f"hipError_t {rc}")
+        raise SdnError(f"{what} failed: {kind}")
+
+
+def require_device():
+    if not torch.cuda.is_available():
+        raise SdnError("SealD-NeRF HIP operators need a ROCm device (torch.cuda.is_available() is False); "
+                       "there is no CPU fallback")
+
+
+def to_device(t):
+    """The reference silently moves CPU inputs with .cuda() (raymarching.py:34-35); same here."""
+    require_device()
+    return t if t.is_cuda else t.cuda()
+
+
+def ptr(t, dtype=None, name="tensor"):
+    """data_ptr of a contiguous device tensor, validated (the reference checks nothing in raymarching)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SdnError(f"{name} must be a device tensor")
+    if not t.is_contiguous():
+        raise SdnError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise SdnError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_id(dt):
+    if dt == torch.float32:
+        return SDN_F32
+    if dt == torch.float16:
+        return SDN_F16
+    raise SdnError(f"unsupported table dtype {dt} (the reference dispatches float/half; double is not built)")

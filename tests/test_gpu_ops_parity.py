@@ -1,0 +1,395 @@
+"""GPU parity: every HIP operator, called through the reference-shaped Python API (which goes through
+the C ABI of libsdn_hip.so via ctypes), against the CPU oracle on the same seeded inputs.
+
+Bars (north_star): bit-exact for integer / index / count outputs and -- because both sides evaluate the
+same float operations in the same order without contraction -- bit-exact for the marching floats too;
+1e-4 relative (fp32) where a transcendental or an atomic summation order is involved, with the
+tolerance written at each assert.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle as O  # noqa: E402  (tests are one of the three places allowed to use the oracle)
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def cam():
+    from dnerf_amd import scene
+    H = W = 96
+    pose = scene.look_at_pose()
+    ro, rd = scene.get_rays(pose, scene.intrinsics(H, W), H, W)
+    bf = scene.jumpingjacks_occupancy(0.5)
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = O.near_far_from_aabb(ro, rd, aabb, 0.2)
+    return dict(ro=ro, rd=rd, bf=bf, aabb=aabb, nears=nears, fars=fars, N=ro.shape[0])
+
+
+def test_library_is_the_hip_build():
+    import sdn_backend
+    assert b"gfx950" in sdn_backend.lib.sdn_version()
+
+
+def test_near_far_from_aabb_bit_exact(cam):
+    import raymarching
+    rng = np.random.default_rng(0)
+    # image rays + random rays that miss / graze / start inside the box
+    ro = np.concatenate([cam["ro"], rng.uniform(-2, 2, (4096, 3)).astype(np.float32)])
+    rd = rng.standard_normal((4096, 3)).astype(np.float32)
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    rd = np.concatenate([cam["rd"], rd])
+    n_ref, f_ref = O.near_far_from_aabb(ro, rd, cam["aabb"], 0.2)
+    n, f = raymarching.near_far_from_aabb(_dev(ro), _dev(rd), _dev(cam["aabb"]), 0.2)
+    assert np.array_equal(n.cpu().numpy().view(np.uint32), n_ref.view(np.uint32))
+    assert np.array_equal(f.cpu().numpy().view(np.uint32), f_ref.view(np.uint32))
+    assert (n_ref > 1e30).any() and (n_ref < 1e30).any()  # both branches covered
+
+
+def test_sph_from_ray(cam):
+    import raymarching
+    ref = O.sph_from_ray(cam["ro"], cam["rd"], 4.0)
+    out = raymarching.sph_from_ray(_dev(cam["ro"]), _dev(cam["rd"]), 4.0).cpu().numpy()
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-5)  # atan2f/sqrtf: libm vs OCML
+
+
+def test_morton_roundtrip_and_packbits_bit_exact():
+    import raymarching
+    rng = np.random.default_rng(1)
+    coords = rng.integers(0, 128, (100000, 3)).astype(np.int32)
+    idx = raymarching.morton3D(_dev(coords))
+    assert idx.dtype == torch.int32
+    assert np.array_equal(idx.cpu().numpy(), O.morton3D(coords))
+    back = raymarching.morton3D_invert(idx)
+    assert np.array_equal(back.cpu().numpy(), coords)
+    assert np.array_equal(back.cpu().numpy(), O.morton3D_invert(idx.cpu().numpy()))
+    grid = rng.standard_normal((2, 64 ** 3)).astype(np.float32)
+    grid[0, :16] = 0.01  # exactly at threshold: '>' must be strict
+    bits = raymarching.packbits(_dev(grid), 0.01)
+    assert np.array_equal(bits.cpu().numpy(), O.packbits(grid, 0.01))
+    # in-place form
+    pre = torch.zeros(2 * 64 ** 3 // 8, dtype=torch.uint8, device="cuda")
+    out = raymarching.packbits(_dev(grid), 0.5, pre)
+    assert out.data_ptr() == pre.data_ptr()
+    assert np.array_equal(pre.cpu().numpy(), O.packbits(grid, 0.5))
+
+
+@pytest.mark.parametrize("n_step,dt_gamma", [(1, 0.0), (4, 0.0), (8, 0.0), (3, 1.0 / 128)])
+def test_march_rays_bit_exact(cam, n_step, dt_gamma):
+    import raymarching
+    N = cam["N"]
+    alive = np.arange(N, dtype=np.int32)[::-1].copy()[: N - 7]  # not the identity, ragged count
+    n_alive = alive.shape[0]
+    rays_t = cam["nears"].copy()
+    ref = O.march_rays(n_alive, n_step, alive, rays_t, cam["ro"], cam["rd"], 1.0, cam["bf"], 1, 128, cam["nears"], cam["fars"],
+                       align=128, dt_gamma=dt_gamma)
+    out = raymarching.march_rays(n_alive, n_step, _dev(alive), _dev(rays_t), _dev(cam["ro"]), _dev(cam["rd"]), 1.0, _dev(cam["bf"]), 1, 128,
+                                 _dev(cam["nears"]), _dev(cam["fars"]), 128, False, dt_gamma, 1024)
+    for o, r, name in zip(out, ref, ("xyzs", "dirs", "deltas")):
+        assert o.shape == r.shape, name  # includes the "+128 when already aligned" padding rule
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), r.view(np.uint32)), name
+    assert (ref[2][:, 0] > 0).sum() > 100  # the test actually sampled something
+
+
+def test_march_rays_perturb_uses_noise(cam):
+    import raymarching
+    N = cam["N"]
+    alive = np.arange(N, dtype=np.int32)
+    torch.manual_seed(3)
+    a = raymarching.march_rays(N, 2, _dev(alive), _dev(cam["nears"]), _dev(cam["ro"]), _dev(cam["rd"]), 1.0, _dev(cam["bf"]), 1, 128,
+                               _dev(cam["nears"]), _dev(cam["fars"]), 128, True, 0.0, 1024)
+    torch.manual_seed(3)
+    noises = torch.rand(N, dtype=torch.float32, device="cuda").cpu().numpy()
+    ref = O.march_rays(N, 2, alive, cam["nears"], cam["ro"], cam["rd"], 1.0, cam["bf"], 1, 128, cam["nears"], cam["fars"], align=128,
+                       perturb=True, noises=noises)
+    assert np.array_equal(a[0].cpu().numpy().view(np.uint32), ref[0].view(np.uint32))
+
+
+def _fake_field(xyzs, seed=0):
+    """Deterministic stand-in for the network so that compositing sees dense-ish media."""
+    rng = np.random.default_rng(seed)
+    M = xyzs.shape[0]
+    sigmas = (rng.random(M, dtype=np.float32) * 60).astype(np.float32)
+    rgbs = rng.random((M, 3), dtype=np.float32)
+    return sigmas, rgbs
+
+
+def test_inference_loop_bit_exact_counts(cam):
+    """march -> composite -> compact, the whole reference loop (dnerf/renderer.py:350-376) on both sides:
+    alive counts, alive ids and the n_step schedule must agree exactly at every iteration; image / depth /
+    weights to 1e-6 (only exp() differs: OCML double exp vs glibc, both rounded to float)."""
+    import raymarching
+    N = cam["N"]
+    d = {k: _dev(cam[k]) for k in ("ro", "rd", "bf", "nears", "fars")}
+    ws_r, dp_r, im_r = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32)
+    ws, dp, im = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, 3, device="cuda")
+    alive_r = np.arange(N, dtype=np.int32)
+    alive = torch.arange(N, dtype=torch.int32, device="cuda")
+    t_r = cam["nears"].copy()
+    t = d["nears"].clone()
+    step, it = 0, 0
+    total_samples = 0
+    while step < 1024:
+        n_alive = alive_r.shape[0]
+        assert alive.shape[0] == n_alive
+        if n_alive <= 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        xr, dr, lr = O.march_rays(n_alive, n_step, alive_r, t_r, cam["ro"], cam["rd"], 1.0, cam["bf"], 1, 128, cam["nears"], cam["fars"], align=128)
+        x, dd, l = raymarching.march_rays(n_alive, n_step, alive, t, d["ro"], d["rd"], 1.0, d["bf"], 1, 128, d["nears"], d["fars"], 128, False, 0, 1024)
+        assert np.array_equal(l.cpu().numpy().view(np.uint32), lr.view(np.uint32))
+        total_samples += int((lr[:, 0] > 0).sum())
+        sig, rgb = _fake_field(xr, seed=it)
+        O.composite_rays(n_alive, n_step, alive_r, t_r, sig, rgb, lr, ws_r, dp_r, im_r, 1e-2)
+        raymarching.composite_rays(n_alive, n_step, alive, t, _dev(sig), _dev(rgb), l, ws, dp, im, 1e-2)
+        assert np.array_equal(alive.cpu().numpy(), alive_r), f"termination flags differ at iteration {it}"
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), t_r.view(np.uint32))
+        # device-side stable compaction == the caller's boolean mask select
+        comp, cnt = raymarching.compact_alive(alive)
+        alive_r = alive_r[alive_r >= 0]
+        assert int(cnt.item()) == alive_r.shape[0]
+        alive = comp[: alive_r.shape[0]].clone()
+        assert np.array_equal(alive.cpu().numpy(), alive_r)
+        step += n_step
+        it += 1
+    assert it > 3 and total_samples > 1000
+    np.testing.assert_allclose(ws.cpu().numpy(), ws_r, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(dp.cpu().numpy(), dp_r, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(im.cpu().numpy(), im_r, rtol=1e-6, atol=1e-7)
+
+
+def test_compact_alive_edge_cases():
+    import raymarching
+    for n, frac in ((1, 1.0), (1, 0.0), (63, 0.5), (64, 0.5), (1024, 0.0), (1025, 1.0), (5000, 0.3), (300000, 0.9)):
+        rng = np.random.default_rng(n)
+        a = np.arange(n, dtype=np.int32)
+        a[rng.random(n) >= frac] = -1
+        out, cnt = raymarching.compact_alive(_dev(a))
+        ref = a[a >= 0]
+        assert int(cnt.item()) == ref.shape[0]
+        assert np.array_equal(out[: ref.shape[0]].cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("perturb,force_all,mean_count", [(False, False, -1), (True, False, -1), (False, True, 500), (False, False, 20000)])
+def test_march_rays_train_exact_per_ray(cam, perturb, force_all, mean_count):
+    import raymarching
+    N = 2048
+    rng = np.random.default_rng(7)
+    sel = rng.integers(0, cam["N"], N)
+    ro, rd, nears, fars = cam["ro"][sel], cam["rd"][sel], cam["nears"][sel], cam["fars"][sel]
+    torch.manual_seed(11)
+    counter = torch.zeros(2, dtype=torch.int32, device="cuda")
+    out = raymarching.march_rays_train(_dev(ro), _dev(rd), 1.0, _dev(cam["bf"]), 1, 128, _dev(nears), _dev(fars), counter, mean_count, perturb,
+                                       128, force_all, 0, 1024)
+    torch.manual_seed(11)
+    noises = torch.rand(N, dtype=torch.float32, device="cuda").cpu().numpy() if perturb else None
+    counter_r = np.zeros(2, np.int32)
+    ref = O.march_rays_train(ro, rd, 1.0, cam["bf"], 1, 128, nears, fars, counter_r, mean_count, perturb, 128, force_all, 0, 1024, noises=noises)
+    assert np.array_equal(counter.cpu().numpy(), counter_r)
+    for o, r, name in zip(out, ref, ("xyzs", "dirs", "deltas", "rays")):
+        assert o.shape == r.shape, name
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), r.view(np.uint32)), name
+    assert counter_r[0] > 1000
+
+
+def test_march_rays_train_overflow_drops_rays_deterministically(cam):
+    import raymarching
+    N = 1024
+    sel = np.arange(cam["N"])[cam["nears"] < 1e30][:N]
+    ro, rd, nears, fars = cam["ro"][sel], cam["rd"][sel], cam["nears"][sel], cam["fars"][sel]
+    counter = torch.zeros(2, dtype=torch.int32, device="cuda")
+    counter_r = np.zeros(2, np.int32)
+    # a budget far below what the rays need: later rays must be dropped (offset + n > M), raymarching.cu:416
+    out = raymarching.march_rays_train(_dev(ro), _dev(rd), 1.0, _dev(cam["bf"]), 1, 128, _dev(nears), _dev(fars), counter, 256, False, 128, False, 0, 1024)
+    ref = O.march_rays_train(ro, rd, 1.0, cam["bf"], 1, 128, nears, fars, counter_r, 256, False, 128, False, 0, 1024)
+    assert out[0].shape[0] == 384 == ref[0].shape[0]
+    for o, r in zip(out, ref):
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), r.view(np.uint32))
+
+
+def test_composite_rays_train_forward_backward(cam):
+    import raymarching
+    N = 2048
+    rng = np.random.default_rng(9)
+    sel = rng.integers(0, cam["N"], N)
+    ro, rd, nears, fars = cam["ro"][sel], cam["rd"][sel], cam["nears"][sel], cam["fars"][sel]
+    xyzs, dirs, deltas, rays = O.march_rays_train(ro, rd, 1.0, cam["bf"], 1, 128, nears, fars, np.zeros(2, np.int32), -1, False, 128)
+    M = xyzs.shape[0]
+    sig, rgb = _fake_field(xyzs, 5)
+    sig *= 0.3
+    ws_r, dp_r, im_r = O.composite_rays_train_forward(sig, rgb, deltas, rays, 1e-4)
+    s_t = _dev(sig).requires_grad_(True)
+    c_t = _dev(rgb).requires_grad_(True)
+    ws, dp, im = raymarching.composite_rays_train(s_t, c_t, _dev(deltas), _dev(rays), 1e-4)
+    # exp() is the only non-identical operation (OCML vs glibc double exp, rounded to float): 1e-6
+    np.testing.assert_allclose(ws.detach().cpu().numpy(), ws_r, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(dp.detach().cpu().numpy(), dp_r, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(im.detach().cpu().numpy(), im_r, rtol=1e-6, atol=1e-7)
+    g_ws = rng.standard_normal(N).astype(np.float32)
+    g_im = rng.standard_normal((N, 3)).astype(np.float32)
+    gs_r, gc_r = O.composite_rays_train_backward(g_ws, g_im, sig, rgb, deltas, rays, ws_r, im_r, 1e-4)
+    torch.autograd.backward([ws, dp, im], [_dev(g_ws), torch.zeros_like(dp), _dev(g_im)])
+    # north_star tolerance: 1e-4 relative (fp32); measured error is ~1e-6
+    np.testing.assert_allclose(s_t.grad.cpu().numpy(), gs_r, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(c_t.grad.cpu().numpy(), gc_r, rtol=1e-4, atol=1e-7)
+    assert M > 1000 and np.abs(gs_r).max() > 0
+
+
+# ------------------------------------------------------------------------------------------------
+# encoders
+# ------------------------------------------------------------------------------------------------
+GRID_CASES = [
+    # D, L, C, H, desired_res, log2T, gridtype, align, interp
+    (3, 16, 2, 16, 2048, 19, "tiled", False, "linear"),   # the dnerf configuration (dnerf/network.py:12,59)
+    (3, 16, 2, 16, 2048, 19, "hash", False, "linear"),
+    (3, 4, 2, 4, 64, 8, "hash", True, "smoothstep"),
+    (2, 4, 2, 16, 2048, 19, "hash", False, "linear"),     # the bg encoder shape (dnerf/network.py:102)
+    (3, 6, 4, 8, 256, 12, "tiled", False, "smoothstep"),
+    (3, 5, 1, 8, 128, 10, "hash", False, "linear"),
+    (3, 3, 8, 4, 32, 9, "tiled", True, "linear"),
+    (4, 3, 2, 4, 16, 10, "hash", False, "linear"),
+    (5, 2, 2, 3, 6, 10, "hash", False, "linear"),
+]
+
+
+def _grid_setup(D, L, C, H, res, log2T, align, seed, B):
+    offsets, pls = O.grid_offsets(D, L, C, 2, H, log2T, res, align)
+    rng = np.random.default_rng(seed)
+    emb = rng.uniform(-1, 1, (int(offsets[-1]), C)).astype(np.float32)
+    x = rng.random((B, D), dtype=np.float32)
+    x[0] = 0.0
+    x[1] = 1.0               # both ends of the closed range are in-bounds
+    x[2, 0] = -1e-3          # out of range -> zeros
+    x[3, D - 1] = 1.0 + 1e-3
+    return offsets, pls, emb, x
+
+
+@pytest.mark.parametrize("case", GRID_CASES)
+@pytest.mark.parametrize("half", [False, True])
+def test_grid_encode_forward_bit_exact(case, half):
+    from gridencoder.grid import grid_encode
+    D, L, C, H, res, log2T, gridtype, align, interp = case
+    gid, iid = {"hash": 0, "tiled": 1}[gridtype], {"linear": 0, "smoothstep": 1}[interp]
+    offsets, pls, emb, x = _grid_setup(D, L, C, H, res, log2T, align, 3, 3001)
+    if half:
+        emb = emb.astype(np.float16)
+    ref, ref_dd = O.grid_encode_forward(x, emb, offsets, pls, H, True, gid, align, iid)
+    xt = _dev(x).requires_grad_(True)
+    out = grid_encode(xt, _dev(emb), _dev(offsets), pls, H, True, gid, align, iid)
+    assert out.shape == (x.shape[0], L * C) and out.dtype == (torch.float16 if half else torch.float32)
+    o = out.detach().cpu().numpy()
+    bits = np.uint16 if half else np.uint32
+    assert np.array_equal(o.view(bits), ref.view(bits)), "forward must be bit-identical (same ops, same order)"
+    assert not o[2].any() and not o[3].any() and o[0].any() and o[1].any()
+
+
+@pytest.mark.parametrize("case", GRID_CASES[:5])
+@pytest.mark.parametrize("half", [False, True])
+def test_grid_encode_backward(case, half):
+    from gridencoder.grid import grid_encode
+    D, L, C, H, res, log2T, gridtype, align, interp = case
+    gid, iid = {"hash": 0, "tiled": 1}[gridtype], {"linear": 0, "smoothstep": 1}[interp]
+    offsets, pls, emb, x = _grid_setup(D, L, C, H, res, log2T, align, 4, 2000)
+    rng = np.random.default_rng(5)
+    g = rng.standard_normal((x.shape[0], L * C)).astype(np.float32)
+    if half:
+        emb = emb.astype(np.float16)
+        g = (g * 1e-2).astype(np.float16)
+    _, dd = O.grid_encode_forward(x, emb, offsets, pls, H, True, gid, align, iid)
+    ge_r, gi_r = O.grid_encode_backward(g, x, emb, offsets, pls, H, dd, gid, align, iid)
+    xt = _dev(x).requires_grad_(True)
+    et = _dev(emb).requires_grad_(True)
+    out = grid_encode(xt, et, _dev(offsets), pls, H, True, gid, align, iid)
+    out.backward(_dev(g))
+    ge, gi = et.grad.cpu().numpy().astype(np.float32), xt.grad.cpu().numpy()
+    ge_r = ge_r.astype(np.float32)
+    if half:
+        # half accumulation: each atomic rounds the running sum to fp16; order differs from the oracle's
+        # serial order, so agreement is to a few fp16 ulps of the largest partial sum
+        np.testing.assert_allclose(ge, ge_r, rtol=2e-2, atol=2e-3 * max(1.0, float(np.abs(ge_r).max())))
+        np.testing.assert_allclose(gi, gi_r, rtol=2e-2, atol=2e-2 * float(np.abs(gi_r).max()))
+    else:
+        # fp32 atomics: summation order only -> 1e-4 relative (north_star), measured ~1e-6
+        np.testing.assert_allclose(ge, ge_r, rtol=1e-4, atol=1e-5 * float(np.abs(ge_r).max()))
+        np.testing.assert_allclose(gi, gi_r, rtol=1e-4, atol=1e-5 * float(np.abs(gi_r).max()))
+    assert np.abs(ge_r).max() > 0 and np.abs(gi_r).max() > 0
+
+
+def test_grid_encoder_module_matches_reference_layout():
+    from gridencoder import GridEncoder
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048,
+                      gridtype="tiled").cuda()
+    assert tuple(enc.embeddings.shape) == (6119864, 2)
+    assert enc.offsets.dtype == torch.int32 and enc.offsets.shape[0] == 17
+    assert list(enc.state_dict().keys()) == ["embeddings", "offsets"]
+    assert float(enc.embeddings.abs().max()) <= 1e-4
+    x = torch.rand(1000, 3, device="cuda") * 2 - 1
+    y = enc(x, bound=1)
+    assert y.shape == (1000, 32) and y.dtype == torch.float32
+    with torch.autocast("cuda", dtype=torch.float16):
+        yh = enc(x, bound=1)
+    assert yh.dtype == torch.float16
+    ref, _ = O.grid_encode_forward(((x + 1) / 2).cpu().numpy(), enc.embeddings.detach().cpu().numpy(), enc.offsets.cpu().numpy(),
+                                   enc.per_level_scale, 16, False, 1, False, 0)
+    assert np.array_equal(y.detach().cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+def test_sh_encode_vs_oracle_and_reference_closed_forms(golden_dir):
+    from shencoder import SHEncoder, sh_encode
+    g = np.load(f"{golden_dir}/sh_reference_closed_form.npz")
+    x = g["inputs"]
+    for degree in range(1, 9):
+        xt = _dev(x).requires_grad_(True)
+        out = sh_encode(xt, degree, True)
+        ref, ref_dd = O.sh_encode_forward(x, degree, True)
+        C2 = degree * degree
+        # fp32 polynomial evaluation in a different (factored) order than the float64 references:
+        # 1e-4 relative with an absolute floor for values that cancel to ~0
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), g["outputs"][:, :C2], rtol=1e-4, atol=2e-5)
+        gy = np.random.default_rng(degree).standard_normal(ref.shape).astype(np.float32)
+        out.backward(_dev(gy))
+        gi_ref = O.sh_encode_backward(gy, ref_dd, degree)
+        gi_gold = np.stack([(gy * g[k][:, :C2]).sum(1) for k in ("dx", "dy", "dz")], 1)
+        scale = float(np.abs(gi_ref).max())
+        np.testing.assert_allclose(xt.grad.cpu().numpy(), gi_ref, rtol=1e-4, atol=1e-5 * scale)
+        np.testing.assert_allclose(xt.grad.cpu().numpy(), gi_gold, rtol=1e-4, atol=1e-5 * scale)
+    enc = SHEncoder(degree=4)
+    y = enc(_dev(x))
+    assert y.shape == (x.shape[0], 16) and not y.requires_grad
+
+
+def test_freq_encode_vs_oracle_and_reference_torch(golden_dir):
+    from freqencoder import FreqEncoder
+    g = np.load(f"{golden_dir}/freq_reference_torch.npz")
+    for name in ("xyz", "time"):
+        x, deg = g[f"{name}_inputs"], int(g[f"{name}_degree"])
+        enc = FreqEncoder(input_dim=x.shape[1], degree=deg)
+        xt = _dev(x).requires_grad_(True)
+        y = enc(xt)
+        ref = O.freq_encode_forward(x, deg)
+        # oracle: same float argument (incl. the reference's float pi/2 phase add), sin correctly rounded: 1e-6
+        np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=0, atol=1e-6)
+        # reference torch FreqEncoder computes cos(x*2^f) directly; the kernel's sin(x*2^f + fl(pi/2)) differs by
+        # the rounding of the phase add (<= ulp(2^9)/2 = 3e-5): inside the stated 1e-4 absolute bar
+        np.testing.assert_allclose(y.detach().cpu().numpy(), g[f"{name}_outputs"], rtol=0, atol=1e-4)
+        y.backward(_dev(g[f"{name}_grad_outputs"]))
+        gi_ref = O.freq_encode_backward(g[f"{name}_grad_outputs"], ref, x.shape[1], deg)
+        scale = float(np.abs(gi_ref).max())
+        np.testing.assert_allclose(xt.grad.cpu().numpy(), gi_ref, rtol=1e-4, atol=1e-5 * scale)
+        np.testing.assert_allclose(xt.grad.cpu().numpy(), g[f"{name}_grad_inputs"], rtol=1e-4, atol=1e-4 * scale)
+
+
+def test_ops_reject_bad_buffers():
+    import raymarching
+    from sdn_backend import SdnError
+    a = torch.zeros(10, 3, device="cuda")
+    with pytest.raises(SdnError):
+        raymarching.march_rays(10, 1, torch.zeros(10, dtype=torch.int64, device="cuda"), torch.zeros(10, device="cuda"), a, a, 1.0,
+                               torch.zeros(128 ** 3 // 8, dtype=torch.uint8, device="cuda"), 1, 128, torch.zeros(10, device="cuda"),
+                               torch.zeros(10, device="cuda"))
