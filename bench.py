@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rendered rays/s + sampled-points/s, 800x800 D-NeRF "jumpingjacks-like" frame
+(BASELINE.json config[1]: `-O`, i.e. fp16 field network, HIP gridencoder + raymarching + shencoder on one
+MI355X; with --gpus N the frame's rays are sharded N-way and the rendered tiles all-gathered over RCCL).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One "step" = one full pass of the hot path over one batch = one rendered frame (all rays of the frame,
+or this rank's shard of them).  Inputs (rays, weights, occupancy bitfield) are resident in HBM before the
+timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "seald-nerf_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+METRIC = "rendered rays/sec + sampled-points/sec, 800×800 D-NeRF jumpingjacks"
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA
+GRID_BYTES_PER_POINT = {"f16": 588.0, "f32": 1164.0}  # gathers + 12 B in + outputs
+FIELD_FLOP_PER_POINT = 235520.0                          # 117 760 MAC
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=800, help="image side (800 = BASELINE config)")
+    ap.add_argument("--fp32", action="store_true", help="fp32 field network instead of the -O (fp16) configuration")
+    ap.add_argument("--field", default="auto", choices=["auto", "ops", "fused"], help="field network implementation")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-side", type=int, default=96, help="side of the CPU-baseline sample image")
+    return ap.parse_args()
+
+
+def shard_rays(n_rays, W, rank, world, tile=16):
+    """Interleaved 16x16-pixel tiles dealt round-robin: the object-covering centre of the image is
+    balanced across ranks.  Returns the int64 ray indices of this rank, padded to equal length with repeats of its
+    last ray so that all_gather_into_tensor sees equal shards (padding is dropped after the gather)."""
+    H = n_rays // W
+    ty, tx = (H + tile - 1) // tile, (W + tile - 1) // tile
+    ys, xs = np.divmod(np.arange(n_rays), W)
+    tile_id = (ys // tile) * tx + (xs // tile)
+    owner = tile_id % world
+    mine = np.nonzero(owner == rank)[0]
+    per = max(int((owner == r).sum()) for r in range(world))
+    pad = per - mine.shape[0]
+    if pad:
+        mine = np.concatenate([mine, np.repeat(mine[-1:], pad)])
+    return mine, per
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from dnerf_amd.bench_scene import build_scene
+    from dnerf_amd.renderer import render_frame, FrameWorkspace
+    from dnerf_amd import fused
+
+    fp16 = not args.fp32
+    sc = build_scene(H=args.size, W=args.size, device=dev, seed=0)
+    n_total = sc.rays_o.shape[0]
+    if world > 1:
+        idx, per = shard_rays(n_total, args.size, rank, world)
+        idx_t = torch.from_numpy(idx).to(dev)
+        rays_o, rays_d = sc.rays_o[idx_t].contiguous(), sc.rays_d[idx_t].contiguous()
+        gathered = torch.empty(world * per, 4, dtype=torch.float32, device=dev)
+        all_idx = torch.from_numpy(np.concatenate([shard_rays(n_total, args.size, r, world)[0] for r in range(world)])).to(dev)
+        frame = torch.empty(n_total, 4, dtype=torch.float32, device=dev)
+    else:
+        rays_o, rays_d = sc.rays_o, sc.rays_d
+    n_local = rays_o.shape[0]
+    ws = FrameWorkspace(n_local, dev)
+    field_kind = args.field
+    if field_kind == "auto":
+        field_kind = "fused" if fused.available() else "ops"
+    field = fused.FusedField(sc.model, sc.time, fp16=fp16) if field_kind == "fused" else None
+    import sdn_backend
+    timers = sdn_backend.KernelTimers()
+
+    def step(count=False, timed=False):
+        sdn_backend.timers = timers if timed else None  # HIP events around the tracked launches, timed steps only
+        out = render_frame(sc.model, rays_o, rays_d, sc.time, fp16=fp16, workspace=ws, field=field, count_samples=count)
+        sdn_backend.timers = None
+        if world > 1:
+            local = torch.cat([out["image"], out["depth"].unsqueeze(-1)], dim=1)
+            dist.all_gather_into_tensor(gathered, local)
+            frame[all_idx] = gathered  # un-permute (padding rows rewrite a pixel with its own value)
+        return out
+
+    # untimed: sample count of this rank's shard (deterministic), then warm-up
+    n_samples_local = step(count=True)["n_samples"]
+    n_iters = len(step()["trace"])
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(timed=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        ns = torch.tensor([n_samples_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(ns)
+        n_samples = int(ns.item())
+    else:
+        n_samples = n_samples_local
+    ms_per_step = elapsed / args.steps * 1e3
+    points_per_s = n_samples * args.steps / elapsed
+    rays_per_s = n_total * args.steps / elapsed
+
+    result = {
+        "metric": METRIC, "value": points_per_s, "unit": "sampled-points/s", "rays_per_s": rays_per_s,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f16" if fp16 else "f32", "data": "synthetic",
+        "config": {"workload": f"dnerf jumpingjacks-like {args.size}x{args.size} full-frame inference render, "
+                               f"{'-O (fp16 field network, fp16 grid table)' if fp16 else 'fp32'}, 1 timestep (t=0.5), "
+                               f"T_thresh 1e-2, max_steps 1024, dt_gamma 0",
+                   "rays": n_total, "sampled_points_per_frame": n_samples, "loop_iterations": n_iters,
+                   "field": field_kind, "parallelism": f"ray-tiles x{world}" if world > 1 else "single GPU"},
+    }
+    if rank == 0:
+        result["roofline"], result["kernel_times"] = roofline(timers, fp16)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(sc, args.cpu_baseline_side)
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def roofline(timers, fp16):
+    """Roofline entry of the dominant TRACKED kernel: achieved = algorithmic bytes (or flops) per launch / average launch
+    duration, both from the HIP events recorded around the launches inside the timed region."""
+    summ = timers.summary()
+    if not summ:
+        return None, {}
+    name = max(summ, key=lambda k: summ[k]["total_ms"])
+    s = summ[name]
+    if name.startswith("grid_encode_fwd"):
+        per_unit = GRID_BYTES_PER_POINT["f16" if name.endswith("f16") else "f32"]
+        achieved = per_unit * s["avg_units"] / (s["avg_ms"] * 1e-3) / 1e9
+        roof = {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_point": per_unit,
+                "avg_launch_ms": s["avg_ms"], "avg_points_per_launch": s["avg_units"]}
+    else:
+        achieved = FIELD_FLOP_PER_POINT * s["avg_units"] / (s["avg_ms"] * 1e-3) / 1e12
+        roof = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": None, "flop_per_point": FIELD_FLOP_PER_POINT,
+                "avg_launch_ms": s["avg_ms"], "avg_points_per_launch": s["avg_units"]}
+    return roof, summ
+
+
+def cpu_baseline(sc, side):
+    """The reference's pure-PyTorch renderer (`NeRFRenderer.run`, 128 uniform samples per ray, no occupancy grid) on the
+    host cores, on a bounded sample of the same workload: a side x side image of the same camera / scene / weights."""
+    from dnerf_amd import scene
+    from oracle import render as orender
+    cores = os.cpu_count() or 1
+    cores = min(cores, 64)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    torch.set_num_threads(cores)
+    ro, rd = scene.get_rays(sc.pose, scene.intrinsics(side, side), side, side)
+    state = orender.state_of(sc.model)
+    orender.render_run_cpu(state, ro[:1024], rd[:1024], 0.5, threads=cores)  # warm-up (page-in, thread pools)
+    t0 = time.perf_counter()
+    orender.render_run_cpu(state, ro, rd, 0.5, threads=cores)
+    dt = time.perf_counter() - t0
+    n = ro.shape[0]
+    return {"value": n * 128 / dt, "unit": "sampled-points/s", "rays_per_s": n / dt, "cores": cores, "kind": "port",
+            "sample": f"{side}x{side} rays of the same camera and weights, 128 uniform samples/ray (the reference's non-cuda_ray "
+                      f"sampler, upsample_steps=0, max_ray_batch=4096), fp32, {dt:.1f} s; it samples empty space too, so rays/s is the "
+                      f"like-for-like figure"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,119 @@
+"""CPU oracle of the render loops (test infrastructure only).
+
+  * `render_frame_oracle`  -- the occupancy-grid inference loop of dnerf/renderer.py:261-386 (run_cuda,
+    inference branch) on the oracle operators; returns the same dict as dnerf_amd.renderer.render_frame
+    plus the per-iteration trace (n_alive, n_step, padded points) and the live sample count.
+  * `render_run_cpu`       -- the uniform sampler dnerf/renderer.py:129-258 (`run`, upsample_steps = 0 as
+    main_dnerf.py:31-32 sets it) staged in max_ray_batch chunks (:571-582): the reference's "pure-PyTorch"
+    renderer, which is what bench.py times as cpu_baseline (kind "port": the reference's encoders are
+    CUDA-only, so the oracle encoders stand in for them; the MLPs run as torch CPU fp32 GEMMs exactly like
+    the reference's nn.Linear would).
+"""
+import numpy as np
+
+from . import oracle as O
+from .field import FieldOracle
+
+
+def state_of(model):
+    return {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if not k.startswith("density_grid")}
+
+
+def render_frame_oracle(sc, mode="fp32", T_thresh=1e-2, max_steps=1024, dt_gamma=0.0, bg_color=1.0, field=None):
+    model = sc.model
+    field = field or FieldOracle(state_of(model), bound=model.bound, density_scale=model.density_scale, mode=mode)
+    ro = sc.rays_o.detach().cpu().numpy().reshape(-1, 3)
+    rd = sc.rays_d.detach().cpu().numpy().reshape(-1, 3)
+    t = float(sc.time.reshape(-1)[0])
+    bf = np.ascontiguousarray(sc.bitfield)
+    N = ro.shape[0]
+    aabb = np.array([-model.bound] * 3 + [model.bound] * 3, np.float32)
+    nears, fars = O.near_far_from_aabb(ro, rd, aabb, model.min_near)
+    ws, dp, im = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32)
+    alive = np.arange(N, dtype=np.int32)
+    rays_t = nears.copy()
+    step, n_samples, trace = 0, 0, []
+    while step < max_steps:
+        n_alive = alive.shape[0]
+        if n_alive <= 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        xyzs, dirs, deltas = O.march_rays(n_alive, n_step, alive, rays_t, ro, rd, float(model.bound), bf, model.cascade, model.grid_size,
+                                          nears, fars, align=128, dt_gamma=dt_gamma, max_steps=max_steps)
+        live = deltas[:, 0] > 0
+        n_samples += int(live.sum())
+        sig = np.zeros(xyzs.shape[0], np.float32)
+        rgb = np.zeros((xyzs.shape[0], 3), np.float32)
+        if live.any():  # dead slots never reach the compositor (delta == 0 terminates the ray first)
+            s, c, _ = field.forward(xyzs[live], dirs[live], t)
+            sig[live], rgb[live] = s, c
+        O.composite_rays(n_alive, n_step, alive, rays_t, sig, rgb, deltas, ws, dp, im, T_thresh)
+        trace.append((n_alive, n_step, xyzs.shape[0]))
+        alive = alive[alive >= 0]
+        step += n_step
+    image = im + (1 - ws)[:, None] * np.float32(bg_color)
+    depth = np.clip(dp - nears, 0, None) / (fars - nears)
+    return {"image": image.astype(np.float32), "depth": depth.astype(np.float32), "weights_sum": ws, "trace": trace, "n_samples": n_samples}
+
+
+def render_run_cpu(model_state, rays_o, rays_d, time, bound=1.0, min_near=0.2, density_scale=1.0, num_steps=128, max_ray_batch=4096,
+                   bg_color=1.0, threads=None):
+    """Uniform sampler on the host cores.  Encoders: oracle C (OpenMP); MLPs: torch CPU fp32 (as nn.Linear)."""
+    import torch
+    import torch.nn.functional as F
+    if threads:
+        torch.set_num_threads(threads)
+    W = lambda p: [torch.from_numpy(np.asarray(model_state[k], np.float32)) for k in  # noqa: E731
+                   sorted((k for k in model_state if k.startswith(p + ".") and k.endswith(".weight")), key=lambda k: int(k.split(".")[1]))]
+    deform_w, sigma_w, color_w = W("deform_net"), W("sigma_net"), W("color_net")
+    emb = np.asarray(model_state["encoder.embeddings"], np.float32)
+    offsets = np.asarray(model_state["encoder.offsets"], np.int32)
+    pls = np.exp2(np.log2(2048 * bound / 16) / (offsets.shape[0] - 2))
+
+    def mlp(h, ws_):
+        for i, w in enumerate(ws_):
+            h = F.linear(h, w)
+            if i != len(ws_) - 1:
+                h = F.relu(h, inplace=True)
+        return h
+
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    N = rays_o.shape[0]
+    image = np.empty((N, 3), np.float32)
+    depth = np.empty(N, np.float32)
+    t = float(np.asarray(time).reshape(-1)[0])
+    enc_t = torch.from_numpy(O.freq_encode_forward(np.array([[t]], np.float32), 6))
+    for head in range(0, N, max_ray_batch):
+        ro, rd = rays_o[head:head + max_ray_batch], rays_d[head:head + max_ray_batch]
+        n = ro.shape[0]
+        nears, fars = O.near_far_from_aabb(ro, rd, aabb, min_near)
+        nears, fars = nears[:, None], fars[:, None]
+        z = np.linspace(0.0, 1.0, num_steps, dtype=np.float32)[None, :]
+        z = nears + (fars - nears) * z
+        sample_dist = (fars - nears) / num_steps
+        xyzs = np.clip(ro[:, None, :] + rd[:, None, :] * z[:, :, None], aabb[:3], aabb[3:]).astype(np.float32).reshape(-1, 3)
+        # density
+        enc_x = torch.from_numpy(O.freq_encode_forward(xyzs, 10))
+        deform = mlp(torch.cat([enc_x, enc_t.repeat(xyzs.shape[0], 1)], 1), deform_w).numpy()
+        xd = xyzs if t == 0.0 else xyzs + deform
+        enc, _ = O.grid_encode_forward((xd + bound) / (2 * bound), emb, offsets, pls, 16, False, 1, False, 0)
+        h = mlp(torch.from_numpy(enc), sigma_w)
+        sigma = torch.exp(h[:, 0]).numpy().reshape(n, num_steps)
+        geo = h[:, 1:]
+        deltas = np.concatenate([z[:, 1:] - z[:, :-1], sample_dist], axis=1)
+        alphas = 1 - np.exp(-deltas * density_scale * sigma)
+        shifted = np.concatenate([np.ones_like(alphas[:, :1]), 1 - alphas + 1e-15], axis=1)
+        weights = alphas * np.cumprod(shifted, axis=1)[:, :-1]
+        mask = (weights > 1e-4).reshape(-1)
+        rgbs = np.zeros((n * num_steps, 3), np.float32)
+        if mask.any():
+            dirs = np.repeat(rd, num_steps, axis=0)[mask]
+            sh, _ = O.sh_encode_forward(dirs, 4)
+            hc = mlp(torch.cat([torch.from_numpy(sh), geo[torch.from_numpy(mask)]], 1), color_w)
+            rgbs[mask] = torch.sigmoid(hc).numpy()
+        rgbs = rgbs.reshape(n, num_steps, 3)
+        ws_ = weights.sum(1)
+        ori_z = np.clip((z - nears) / (fars - nears), 0, 1)
+        depth[head:head + n] = (weights * ori_z).sum(1)
+        image[head:head + n] = (weights[:, :, None] * rgbs).sum(1) + (1 - ws_)[:, None] * bg_color
+    return {"image": image, "depth": depth}

@@ -483,6 +483,8 @@ void orc_grid_encode_forward(const float *inputs, const void *grid_all, const in
         const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
         float scale; uint32_t resolution;
         orc_grid_level_params(level, S, H, &scale, &resolution);
+        /* points are independent: OpenMP only speeds up the cpu_baseline leg, results do not depend on it */
+        #pragma omp parallel for schedule(static)
         for (uint32_t b = 0; b < B; b++) {
             const float *in = inputs + (size_t)b * D;
             const size_t ooff = (size_t)level * B * C + (size_t)b * C;
@@ -629,6 +631,7 @@ void orc_grid_encode_backward(const void *grad_all, const float *inputs, const i
 void orc_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float *outputs) {
     (void)deg;
     const float half_pi = 3.141592653589793f / 2;
+    #pragma omp parallel for schedule(static)
     for (size_t t = 0; t < (size_t)B * C; t++) {
         const uint32_t b = (uint32_t)(t / C), c = (uint32_t)(t - (size_t)b * C);
         const float *in = inputs + (size_t)b * D;

@@ -1,0 +1,141 @@
+"""Dynamic-NeRF field network (deform + sigma + color MLPs over the HIP encoders).
+
+Host-side mirror of /root/reference/dnerf/network.py:10-275 (`NeRFNetwork`): the same sub-module and
+parameter names (`encoder_deform`, `encoder_time`, `deform_net.{l}.weight`, `encoder.embeddings`,
+`encoder.offsets`, `sigma_net`, `encoder_dir`, `color_net`), so a reference checkpoint's model state
+dict loads with `strict=False` exactly as the reference's own loader does (nerf/utils.py:1095-1154).
+
+Two evaluation paths produce the same numbers:
+  * `forward` / `density` / `color`  -- the reference's op sequence on the drop-in operators
+    (`freq_encode`, `grid_encode`, `sh_encode`) with the MLPs as `F.linear` calls; differentiable.
+  * `forward_fused` -- the MI355X-native inference path (fused encoders + MLPs on MFMA, see
+    csrc/field.hip) used by the native render loop when available.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from freqencoder import FreqEncoder
+from gridencoder import GridEncoder
+from shencoder import SHEncoder
+
+from .renderer import NeRFRenderer
+
+
+class _TruncExp(torch.autograd.Function):
+    """activation.py:5-17 of the reference: exp forward in fp32, backward clamps the argument to [-15, 15]."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * torch.exp(x.clamp(-15, 15))
+
+
+trunc_exp = _TruncExp.apply
+
+
+def _mlp(dims):
+    """bias-free Linear stack, `dims` = [in, hidden..., out] (dnerf/network.py:38-52,61-75,82-96)."""
+    return nn.ModuleList([nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(len(dims) - 1)])
+
+
+def _run_mlp(layers, h):
+    last = len(layers) - 1
+    for i, layer in enumerate(layers):
+        h = layer(h)
+        if i != last:
+            h = F.relu(h, inplace=True)
+    return h
+
+
+class NeRFNetwork(NeRFRenderer):
+    def __init__(self, num_layers=2, hidden_dim=64, geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64,
+                 num_layers_deform=8, hidden_dim_deform=128, bound=1, **kwargs):
+        super().__init__(bound, **kwargs)
+        if self.bg_radius > 0:
+            raise NotImplementedError("background sphere model (bg_radius > 0) is outside the dnerf jumpingjacks path")
+        self.num_layers, self.hidden_dim, self.geo_feat_dim = num_layers, hidden_dim, geo_feat_dim
+        self.num_layers_color, self.hidden_dim_color = num_layers_color, hidden_dim_color
+        self.num_layers_deform, self.hidden_dim_deform = num_layers_deform, hidden_dim_deform
+
+        # deformation field: freq(xyz, 10) ++ freq(t, 6) -> 8 x 128 -> 3          (network.py:31-52)
+        self.encoder_deform = FreqEncoder(input_dim=3, degree=10)
+        self.encoder_time = FreqEncoder(input_dim=1, degree=6)
+        self.in_dim_deform, self.in_dim_time = self.encoder_deform.output_dim, self.encoder_time.output_dim
+        self.deform_net = _mlp([self.in_dim_deform + self.in_dim_time] + [hidden_dim_deform] * (num_layers_deform - 1) + [3])
+
+        # density: tiled grid (16 levels x 2, 16 -> 2048*bound) -> 64 -> 1 + 15      (network.py:55-75)
+        self.encoder = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
+                                   desired_resolution=2048 * bound, gridtype="tiled", align_corners=False)
+        self.in_dim = self.encoder.output_dim
+        self.sigma_net = _mlp([self.in_dim] + [hidden_dim] * (num_layers - 1) + [1 + geo_feat_dim])
+
+        # colour: SH(dir, 4) ++ geo_feat -> 64 -> 64 -> 3                             (network.py:78-96)
+        self.encoder_dir = SHEncoder(input_dim=3, degree=4)
+        self.in_dim_dir = self.encoder_dir.output_dim
+        self.color_net = _mlp([self.in_dim_dir + geo_feat_dim] + [hidden_dim_color] * (num_layers_color - 1) + [3])
+        self.bg_net = None
+
+    # ------------------------------------------------------------------------------------------
+    def _deform(self, x, t):
+        enc_x = self.encoder_deform(x, bound=self.bound)
+        enc_t = self.encoder_time(t)
+        if enc_t.shape[0] == 1:
+            enc_t = enc_t.repeat(x.shape[0], 1)
+        return _run_mlp(self.deform_net, torch.cat([enc_x, enc_t], dim=1))
+
+    def _sigma(self, x):
+        h = _run_mlp(self.sigma_net, self.encoder(x, bound=self.bound))
+        return trunc_exp(h[..., 0]), h[..., 1:]
+
+    def _color(self, d, geo_feat):
+        h = torch.cat([self.encoder_dir(d), geo_feat], dim=-1)
+        return torch.sigmoid(_run_mlp(self.color_net, h))
+
+    def forward(self, x, d, t):
+        """x [M,3] in [-bound,bound], d [M,3] unit, t [1,1] -> sigma [M], rgb [M,3], deform [M,3]  (network.py:123-169)."""
+        deform = self._deform(x, t)
+        if t == 0:  # canonical frame: no deformation (device compare => host sync, as in the reference :140)
+            deform = torch.zeros_like(x)
+        sigma, geo_feat = self._sigma(x + deform)
+        return sigma, self._color(d, geo_feat), deform
+
+    def density(self, x, t):
+        """network.py:171-206."""
+        deform = self._deform(x, t)
+        if t != 0:
+            x = x + deform
+        sigma, geo_feat = self._sigma(x)
+        return {"deform": deform, "sigma": sigma, "geo_feat": geo_feat}
+
+    def color(self, x, d, mask=None, geo_feat=None, **kwargs):
+        """network.py:225-257 (masked colour query used by the non-cuda-ray sampler)."""
+        if mask is not None:
+            rgbs = torch.zeros(mask.shape[0], 3, dtype=x.dtype, device=x.device)
+            if not mask.any():
+                return rgbs
+            d, geo_feat = d[mask], geo_feat[mask]
+        h = self._color(d, geo_feat)
+        if mask is not None:
+            rgbs[mask] = h.to(rgbs.dtype)
+            return rgbs
+        return h
+
+    def get_params(self, lr, lr_net):
+        """network.py:260-275."""
+        return [
+            {"params": self.encoder.parameters(), "lr": lr},
+            {"params": self.sigma_net.parameters(), "lr": lr_net},
+            {"params": self.encoder_dir.parameters(), "lr": lr},
+            {"params": self.color_net.parameters(), "lr": lr_net},
+            {"params": self.encoder_deform.parameters(), "lr": lr},
+            {"params": self.encoder_time.parameters(), "lr": lr},
+            {"params": self.deform_net.parameters(), "lr": lr_net},
+        ]

@@ -1,0 +1,376 @@
+"""Volume renderer of the dynamic-NeRF path on the HIP operators.
+
+Host-side mirror of /root/reference/dnerf/renderer.py:61-590 (`NeRFRenderer`): same constructor
+arguments, registered buffers (`aabb_train`, `aabb_infer`, `density_grid`, `density_bitfield`, `times`,
+`step_counter`) and the same `render / run_cuda / run / update_extra_state` semantics, so checkpoints
+and callers carry over.  `render_frame` is the MI355X-native inference loop built on the same
+operators: it produces the same image / depth bit for bit (per-ray results do not depend on the
+compaction schedule) with one 4-byte read-back per iteration and no boolean-mask kernels.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import raymarching
+
+
+def _meshgrid(*args):
+    return torch.meshgrid(*args, indexing="ij")
+
+
+def sample_pdf(bins, weights, n_samples, det=False):
+    """Inverse-CDF resampling of the coarse samples (dnerf/renderer.py:12-46; the NeRF formulation)."""
+    weights = weights + 1e-5
+    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    if det:
+        u = torch.linspace(0.0 + 0.5 / n_samples, 1.0 - 0.5 / n_samples, steps=n_samples, device=weights.device)
+        u = u.expand(list(cdf.shape[:-1]) + [n_samples])
+    else:
+        u = torch.rand(list(cdf.shape[:-1]) + [n_samples], device=weights.device)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = (inds - 1).clamp(min=0)
+    above = inds.clamp(max=cdf.shape[-1] - 1)
+    inds_g = torch.stack([below, above], -1)
+    shape = [inds_g.shape[0], inds_g.shape[1], cdf.shape[-1]]
+    cdf_g = torch.gather(cdf.unsqueeze(1).expand(shape), 2, inds_g)
+    bins_g = torch.gather(bins.unsqueeze(1).expand(shape), 2, inds_g)
+    denom = cdf_g[..., 1] - cdf_g[..., 0]
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    t = (u - cdf_g[..., 0]) / denom
+    return bins_g[..., 0] + t * (bins_g[..., 1] - bins_g[..., 0])
+
+
+class NeRFRenderer(nn.Module):
+    def __init__(self, bound=1, cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1):
+        super().__init__()
+        self.bound = bound
+        self.cascade = 1 + math.ceil(math.log2(bound))
+        self.time_size = 64
+        self.grid_size = 128
+        self.density_scale = density_scale
+        self.min_near = min_near
+        self.density_thresh = density_thresh
+        self.bg_radius = bg_radius
+        aabb = torch.tensor([-bound, -bound, -bound, bound, bound, bound], dtype=torch.float32)
+        self.register_buffer("aabb_train", aabb)
+        self.register_buffer("aabb_infer", aabb.clone())
+        self.cuda_ray = cuda_ray
+        if cuda_ray:
+            self.register_buffer("density_grid", torch.zeros(self.time_size, self.cascade, self.grid_size ** 3))
+            self.register_buffer("density_bitfield", torch.zeros(self.time_size, self.cascade * self.grid_size ** 3 // 8, dtype=torch.uint8))
+            self.mean_density = 0
+            self.iter_density = 0
+            times = ((torch.arange(self.time_size, dtype=torch.float32) + 0.5) / self.time_size).view(-1, 1, 1)
+            self.register_buffer("times", times)
+            self.register_buffer("step_counter", torch.zeros(16, 2, dtype=torch.int32))
+            self.mean_count = 0
+            self.local_step = 0
+
+    def forward(self, x, d, t):
+        raise NotImplementedError()
+
+    def density(self, x, t):
+        raise NotImplementedError()
+
+    def color(self, x, d, t, mask=None, **kwargs):
+        raise NotImplementedError()
+
+    def reset_extra_state(self):
+        if not self.cuda_ray:
+            return
+        self.density_grid.zero_()
+        self.mean_density = 0
+        self.iter_density = 0
+        self.step_counter.zero_()
+        self.mean_count = 0
+        self.local_step = 0
+
+    def time_slice(self, time):
+        """Index of the density-grid time slice for `time` [B,1] (dnerf/renderer.py:285)."""
+        return torch.floor(time[0][0] * self.time_size).clamp(min=0, max=self.time_size - 1).long()
+
+    # ------------------------------------------------------------------------------------------
+    # occupancy-grid path (dnerf/renderer.py:261-386)
+    # ------------------------------------------------------------------------------------------
+    def run_cuda(self, rays_o, rays_d, time, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024,
+                 T_thresh=None, **kwargs):
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        N = rays_o.shape[0]
+        device = rays_o.device
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
+        if bg_color is None:
+            bg_color = 1
+        t = self.time_slice(time)
+        results = {}
+        if self.training:
+            counter = self.step_counter[self.local_step % 16]
+            counter.zero_()
+            self.local_step += 1
+            xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield[t], self.cascade,
+                                                                    self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
+                                                                    force_all_rays, dt_gamma, max_steps)
+            sigmas, rgbs, deform = self(xyzs, dirs, time)
+            sigmas = self.density_scale * sigmas
+            args = (sigmas, rgbs, deltas, rays) if T_thresh is None else (sigmas, rgbs, deltas, rays, T_thresh)
+            weights_sum, depth, image = raymarching.composite_rays_train(*args)
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+            results["deform"] = deform
+        else:
+            weights_sum = torch.zeros(N, dtype=torch.float32, device=device)
+            depth = torch.zeros(N, dtype=torch.float32, device=device)
+            image = torch.zeros(N, 3, dtype=torch.float32, device=device)
+            rays_alive = torch.arange(N, dtype=torch.int32, device=device)
+            rays_t = nears.clone()
+            bitfield = self.density_bitfield[t]
+            step = 0
+            while step < max_steps:
+                n_alive = rays_alive.shape[0]
+                if n_alive <= 0:
+                    break
+                n_step = max(min(N // n_alive, 8), 1)
+                xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, bitfield,
+                                                            self.cascade, self.grid_size, nears, fars, 128, perturb if step == 0 else False,
+                                                            dt_gamma, max_steps)
+                sigmas, rgbs, _ = self(xyzs, dirs, time)
+                sigmas = self.density_scale * sigmas
+                cargs = (n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image)
+                raymarching.composite_rays(*(cargs if T_thresh is None else cargs + (T_thresh,)))
+                rays_alive = rays_alive[rays_alive >= 0]
+                step += n_step
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+        results["depth"] = depth.view(*prefix)
+        results["image"] = image.view(*prefix, 3)
+        return results
+
+    # ------------------------------------------------------------------------------------------
+    # uniform sampler (dnerf/renderer.py:129-258): no occupancy grid, fixed num_steps (+ optional upsampling)
+    # ------------------------------------------------------------------------------------------
+    def run(self, rays_o, rays_d, time, num_steps=128, upsample_steps=128, bg_color=None, perturb=False, **kwargs):
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        N = rays_o.shape[0]
+        device = rays_o.device
+        aabb = self.aabb_train if self.training else self.aabb_infer
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
+        nears, fars = nears.unsqueeze(-1), fars.unsqueeze(-1)
+        z_vals = torch.linspace(0.0, 1.0, num_steps, device=device).unsqueeze(0).expand((N, num_steps))
+        z_vals = nears + (fars - nears) * z_vals
+        sample_dist = (fars - nears) / num_steps
+        if perturb:
+            z_vals = z_vals + (torch.rand(z_vals.shape, device=device) - 0.5) * sample_dist
+
+        def points(z):
+            p = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z.unsqueeze(-1)
+            return torch.min(torch.max(p, aabb[:3]), aabb[3:])
+
+        def weights_of(z, sigma):
+            deltas = torch.cat([z[..., 1:] - z[..., :-1], sample_dist * torch.ones_like(z[..., :1])], dim=-1)
+            alphas = 1 - torch.exp(-deltas * self.density_scale * sigma)
+            shifted = torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas + 1e-15], dim=-1)
+            return deltas, alphas * torch.cumprod(shifted, dim=-1)[..., :-1]
+
+        xyzs = points(z_vals)
+        dens = {k: v.view(N, num_steps, -1) for k, v in self.density(xyzs.reshape(-1, 3), time).items()}
+        if upsample_steps > 0:
+            with torch.no_grad():
+                deltas, weights = weights_of(z_vals, dens["sigma"].squeeze(-1))
+                z_mid = z_vals[..., :-1] + 0.5 * deltas[..., :-1]
+                new_z = sample_pdf(z_mid, weights[:, 1:-1], upsample_steps, det=not self.training).detach()
+                new_xyzs = points(new_z)
+            new_dens = {k: v.view(N, upsample_steps, -1) for k, v in self.density(new_xyzs.reshape(-1, 3), time).items()}
+            z_vals, z_index = torch.sort(torch.cat([z_vals, new_z], dim=1), dim=1)
+            xyzs = torch.cat([xyzs, new_xyzs], dim=1)
+            xyzs = torch.gather(xyzs, dim=1, index=z_index.unsqueeze(-1).expand_as(xyzs))
+            for k in dens:
+                tmp = torch.cat([dens[k], new_dens[k]], dim=1)
+                dens[k] = torch.gather(tmp, dim=1, index=z_index.unsqueeze(-1).expand_as(tmp))
+        _, weights = weights_of(z_vals, dens["sigma"].squeeze(-1))
+        dirs = rays_d.view(-1, 1, 3).expand_as(xyzs)
+        dens = {k: v.view(-1, v.shape[-1]) for k, v in dens.items()}
+        mask = weights > 1e-4
+        rgbs = self.color(xyzs.reshape(-1, 3), dirs.reshape(-1, 3), mask=mask.reshape(-1), **dens).view(N, -1, 3)
+        weights_sum = weights.sum(dim=-1)
+        ori_z = ((z_vals - nears) / (fars - nears)).clamp(0, 1)
+        depth = torch.sum(weights * ori_z, dim=-1)
+        image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2)
+        if bg_color is None:
+            bg_color = 1
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "deform": dens["deform"]}
+
+    # ------------------------------------------------------------------------------------------
+    # density-grid maintenance (dnerf/renderer.py:453-555)
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def update_extra_state(self, decay=0.95, S=128):
+        if not self.cuda_ray:
+            return
+        dev = self.density_bitfield.device
+        tmp_grid = -torch.ones_like(self.density_grid)
+        half_time = 0.5 / self.time_size
+
+        def query(coords, indices, t_idx, time, cas):
+            xyzs = 2 * coords.float() / (self.grid_size - 1) - 1
+            bound = min(2 ** cas, self.bound)
+            half_grid = bound / self.grid_size
+            cas_xyzs = xyzs * (bound - half_grid)
+            cas_xyzs += (torch.rand_like(cas_xyzs) * 2 - 1) * half_grid
+            time_perturb = time + (torch.rand_like(time) * 2 - 1) * half_time
+            sigmas = self.density(cas_xyzs, time_perturb)["sigma"].reshape(-1).detach().float()
+            tmp_grid[t_idx, cas, indices] = sigmas * self.density_scale
+
+        if self.iter_density < 16:
+            axes = [torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S) for _ in range(3)]
+            for t_idx, time in enumerate(self.times):
+                for xs in axes[0]:
+                    for ys in axes[1]:
+                        for zs in axes[2]:
+                            xx, yy, zz = _meshgrid(xs, ys, zs)
+                            coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
+                            indices = raymarching.morton3D(coords).long()
+                            for cas in range(self.cascade):
+                                query(coords, indices, t_idx, time, cas)
+        elif self.iter_density < 100:
+            N = self.grid_size ** 3 // 4
+            for t_idx, time in enumerate(self.times):
+                for cas in range(self.cascade):
+                    coords = torch.randint(0, self.grid_size, (N, 3), device=dev)
+                    indices = raymarching.morton3D(coords).long()
+                    occ = torch.nonzero(self.density_grid[t_idx, cas] > 0).squeeze(-1)
+                    if occ.shape[0] > 0:
+                        occ = occ[torch.randint(0, occ.shape[0], [N], dtype=torch.long, device=dev)]
+                        indices = torch.cat([indices, occ], dim=0)
+                        coords = torch.cat([coords, raymarching.morton3D_invert(occ)], dim=0)
+                    query(coords, indices, t_idx, time, cas)
+        valid = (self.density_grid >= 0) & (tmp_grid >= 0)
+        self.density_grid[valid] = torch.maximum(self.density_grid[valid] * decay, tmp_grid[valid])
+        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        self.iter_density += 1
+        density_thresh = min(self.mean_density, self.density_thresh)
+        for t_idx in range(self.time_size):
+            raymarching.packbits(self.density_grid[t_idx], density_thresh, self.density_bitfield[t_idx])
+        total_step = min(16, self.local_step)
+        if total_step > 0:
+            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+        self.local_step = 0
+
+    def render(self, rays_o, rays_d, time, staged=False, max_ray_batch=4096, **kwargs):
+        """dnerf/renderer.py:558-590: rays [B,N,3] -> {image [B,N,3], depth [B,N]}; staging only without the grid."""
+        _run = self.run_cuda if self.cuda_ray else self.run
+        B, N = rays_o.shape[:2]
+        device = rays_o.device
+        if staged and not self.cuda_ray:
+            depth = torch.empty((B, N), device=device)
+            image = torch.empty((B, N, 3), device=device)
+            for b in range(B):
+                for head in range(0, N, max_ray_batch):
+                    tail = min(head + max_ray_batch, N)
+                    r = _run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail], time[b:b + 1], **kwargs)
+                    depth[b:b + 1, head:tail] = r["depth"]
+                    image[b:b + 1, head:tail] = r["image"]
+            return {"depth": depth, "image": image}
+        return _run(rays_o, rays_d, time, **kwargs)
+
+
+# ==================================================================================================
+# MI355X-native inference loop
+# ==================================================================================================
+class FrameWorkspace:
+    """Per-(N) buffers of the native loop, allocated once and reused across frames: the reference
+    re-allocates and memsets three M-sized sample buffers every iteration."""
+
+    def __init__(self, N, device):
+        self.N = N
+        f32, i32 = torch.float32, torch.int32
+        M = N + 128 + 8 * 128  # >= n_alive * n_step + align for every schedule (n_alive*n_step <= N)
+        self.xyzs = torch.empty(M, 3, dtype=f32, device=device)
+        self.dirs = torch.empty(M, 3, dtype=f32, device=device)
+        self.deltas = torch.empty(M, 2, dtype=f32, device=device)
+        self.alive = [torch.empty(N, dtype=i32, device=device), torch.empty(N, dtype=i32, device=device)]
+        self.rays_t = torch.empty(N, dtype=f32, device=device)
+        self.weights_sum = torch.empty(N, dtype=f32, device=device)
+        self.depth = torch.empty(N, dtype=f32, device=device)
+        self.image = torch.empty(N, 3, dtype=f32, device=device)
+        self.count = torch.zeros(1, dtype=i32, device=device)
+        self.count_host = torch.zeros(1, dtype=i32).pin_memory()
+        from sdn_backend import lib
+        self.scratch = torch.empty(max(int(lib.sdn_compact_alive_scratch_bytes(N)), 4), dtype=torch.uint8, device=device)
+
+
+@torch.no_grad()
+def render_frame(model, rays_o, rays_d, time, fp16=False, dt_gamma=0.0, max_steps=1024, T_thresh=1e-2, bg_color=1.0,
+                 workspace=None, field=None, count_samples=True):
+    """One inference frame: rays [N,3] -> {'image' [N,3], 'depth' [N], 'weights_sum' [N], 'n_samples', 'trace'}.
+
+    Same schedule as dnerf/renderer.py:340-381 (n_step = clamp(N // n_alive, 1, 8), stop at max_steps),
+    same operators, but: buffers come from a reusable workspace, alive-ray compaction is the device-side
+    `compact_alive` (one 4-byte count read back per iteration instead of a boolean-mask select), and the
+    field network may be the fused MFMA kernel (`field`, see dnerf_amd/fused.py) instead of the op-by-op
+    network.  `trace` lists (n_alive, n_step, padded_points) per iteration.
+    """
+    from sdn_backend import lib, check, ptr, stream
+    device = rays_o.device
+    rays_o = rays_o.contiguous().view(-1, 3)
+    rays_d = rays_d.contiguous().view(-1, 3)
+    N = rays_o.shape[0]
+    ws = workspace if workspace is not None and workspace.N == N else FrameWorkspace(N, device)
+    nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, model.aabb_infer, model.min_near)
+    bitfield = model.density_bitfield[model.time_slice(time)]
+    ws.weights_sum.zero_(); ws.depth.zero_(); ws.image.zero_()
+    ws.rays_t.copy_(nears)
+    torch.arange(N, dtype=torch.int32, device=device, out=ws.alive[0])
+    cur = 0
+    n_alive = N
+    step = 0
+    trace = []
+    n_samples = torch.zeros((), dtype=torch.int64, device=device) if count_samples else None
+    st = stream()
+    evaluate = field if field is not None else _field_eval(model, time, fp16)
+    while step < max_steps and n_alive > 0:
+        n_step = max(min(N // n_alive, 8), 1)
+        M0 = n_alive * n_step
+        M = M0 + (128 - M0 % 128)
+        xyzs, dirs, deltas = ws.xyzs[:M], ws.dirs[:M], ws.deltas[:M]
+        xyzs[M0:].zero_(); dirs[M0:].zero_(); deltas[M0:].zero_()
+        alive = ws.alive[cur]
+        check(lib.sdn_march_rays(n_alive, n_step, ptr(alive), ptr(ws.rays_t), ptr(rays_o), ptr(rays_d), float(model.bound), float(dt_gamma),
+                                 int(max_steps), int(model.cascade), int(model.grid_size), ptr(bitfield), ptr(nears), ptr(fars), ptr(xyzs),
+                                 ptr(dirs), ptr(deltas), None, st), "march_rays")
+        if count_samples:  # live samples = slots with a non-zero step (untimed bookkeeping; off in the timed bench loop)
+            n_samples += (deltas[:M0, 0] > 0).sum()
+        sigmas, rgbs = evaluate(xyzs, dirs)
+        check(lib.sdn_composite_rays(n_alive, n_step, float(T_thresh), ptr(alive), ptr(ws.rays_t), ptr(sigmas), ptr(rgbs), ptr(deltas),
+                                     ptr(ws.weights_sum), ptr(ws.depth), ptr(ws.image), st), "composite_rays")
+        check(lib.sdn_compact_alive(ptr(alive), n_alive, ptr(ws.alive[1 - cur]), ptr(ws.count), ptr(ws.scratch), st), "compact_alive")
+        ws.count_host.copy_(ws.count, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        trace.append((n_alive, n_step, M))
+        n_alive = int(ws.count_host[0])
+        cur = 1 - cur
+        step += n_step
+    image = ws.image + (1 - ws.weights_sum).unsqueeze(-1) * bg_color
+    depth = torch.clamp(ws.depth - nears, min=0) / (fars - nears)
+    return {"image": image, "depth": depth, "weights_sum": ws.weights_sum.clone(), "trace": trace, "nears": nears, "fars": fars,
+            "n_samples": int(n_samples.item()) if count_samples else None}
+
+
+def _field_eval(model, time, fp16):
+    """Op-by-op field evaluation (the reference's network on the drop-in operators), fp32 outputs."""
+    def run(xyzs, dirs):
+        if fp16:
+            with torch.autocast("cuda", dtype=torch.float16):
+                sigmas, rgbs, _ = model(xyzs, dirs, time)
+        else:
+            sigmas, rgbs, _ = model(xyzs, dirs, time)
+        return (model.density_scale * sigmas).float().contiguous(), rgbs.float().contiguous()
+    return run

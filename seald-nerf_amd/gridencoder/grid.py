@@ -11,6 +11,7 @@ import torch.nn as nn
 from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
 
+import sdn_backend as _sdn
 from sdn_backend import lib as _lib, check as _check, ptr as _ptr, stream as _stream, dtype_id as _dtype_id, require_device
 
 _gridtype_to_id = {"hash": 0, "tiled": 1}
@@ -51,9 +52,10 @@ class _grid_encode(Function):
         outputs = torch.empty(L, B, C, device=inputs.device, dtype=embeddings.dtype)
         dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=embeddings.dtype) if calc_grad_inputs else None
         _, off_ptr = _host_offsets(offsets)
-        _check(_lib.sdn_grid_encode_forward(_ptr(inputs, torch.float32, "inputs"), _ptr(embeddings, None, "embeddings"), off_ptr,
-                                            _ptr(outputs), B, D, C, L, S, H, _ptr(dy_dx), int(gridtype), int(bool(align_corners)),
-                                            int(interpolation), dt, _stream()), "grid_encode_forward")
+        with _sdn.timed("grid_encode_fwd_f16" if dt == _sdn.SDN_F16 else "grid_encode_fwd_f32", B):
+            _check(_lib.sdn_grid_encode_forward(_ptr(inputs, torch.float32, "inputs"), _ptr(embeddings, None, "embeddings"), off_ptr,
+                                                _ptr(outputs), B, D, C, L, S, H, _ptr(dy_dx), int(gridtype), int(bool(align_corners)),
+                                                int(interpolation), dt, _stream()), "grid_encode_forward")
         outputs = outputs.permute(1, 0, 2).reshape(B, L * C)
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
         ctx.dims = [B, D, C, L, S, H, gridtype, interpolation]

@@ -105,3 +105,50 @@ def dtype_id(dt):
     if dt == torch.float16:
         return SDN_F16
     raise SdnError(f"unsupported table dtype {dt} (the reference dispatches float/half; double is not built)")
+
+
+# ---------------------------------------------------------------------------------------------------
+# optional per-kernel HIP-event timing (used by bench.py for the roofline object; off by default)
+# ---------------------------------------------------------------------------------------------------
+class KernelTimers:
+    """Collects (start, end) HIP events around native launches, keyed by kernel family, together with the
+    number of work units (points) each launch processed.  Events are recorded on torch's current stream,
+    which is the stream the launch goes to.  Nothing is synchronised until `summary()`."""
+
+    def __init__(self):
+        self.records = {}
+
+    def record(self, name, units):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        self.records.setdefault(name, []).append((s, e, units))
+        return s, e
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = [s.elapsed_time(e) for s, e, _ in recs]
+            units = [u for _, _, u in recs]
+            out[name] = {"launches": len(recs), "total_ms": float(sum(ms)), "avg_ms": float(sum(ms) / len(ms)),
+                         "units": int(sum(units)), "avg_units": float(sum(units) / len(units))}
+        return out
+
+
+timers = None  # set to a KernelTimers instance to enable
+
+
+class timed:
+    """`with timed("grid_encode_fwd", B): launch(...)` -- no-op unless `sdn_backend.timers` is set."""
+
+    def __init__(self, name, units):
+        self.ev = timers.record(name, units) if timers is not None else None
+
+    def __enter__(self):
+        if self.ev:
+            self.ev[0].record()
+
+    def __exit__(self, *exc):
+        if self.ev:
+            self.ev[1].record()
+        return False
