@@ -157,6 +157,22 @@ int sdn_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D, uint32_
 int sdn_freq_encode_backward(const float *grad, const float *outputs, uint32_t B, uint32_t D, uint32_t deg,
                              uint32_t C, float *grad_inputs, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * fused field network  (reference: the op sequence of dnerf/network.py:123-169 under `-O`; the fused-MLP operator
+ * shape of ffmlp/src/ffmlp.h:8-14 -- one launch, fp16 weights, activations on chip -- extended over the encoders)
+ * ------------------------------------------------------------------------- */
+/* Number of 1-KiB weight fragments sdn_field_forward_f16 expects (fragment order: seald-nerf_amd/dnerf_amd/fused.py). */
+uint32_t sdn_field_weight_blocks(void);
+
+/* sigma [M], rgb [M,3] of sample points xyzs/dirs [M,3] for the dnerf field network (freq(10) ++ time bias -> 8x128
+ * deform MLP -> tiled grid 16x2 (fp16 table) -> 64,16 sigma MLP; SH(4) ++ geo_feat -> 64,64,3 colour MLP), with the
+ * reference's autocast numerics.  live_idx/live_count (both or neither): evaluate only the listed slots; the count is read
+ * on the device.  bias0 [128] f32: W0[:,63:76] . freq(t, 6).  offsets_host [17]: level row offsets. */
+int sdn_field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count,
+                          uint32_t M, const void *weights, const float *bias0, const void *table,
+                          const int32_t *offsets_host, float S, uint32_t H, float bound, float density_scale,
+                          int zero_deform, float *sigmas, float *rgbs, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,10 @@ PROTOTYPES = {
     "sdn_sh_encode_backward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp],
     "sdn_freq_encode_forward": [_vp, _u32, _u32, _u32, _u32, _vp, _vp],
     "sdn_freq_encode_backward": [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp],
+    "sdn_field_forward_f16": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _f32, _u32, _f32, _f32, _i32, _vp, _vp, _vp],
+}
+PROTOTYPES_U32 = {
+    "sdn_field_weight_blocks": [],
 }
 PROTOTYPES_U64 = {
     "sdn_march_rays_train_scratch_bytes": [_u32],
@@ -54,6 +58,10 @@ for _name, _args in PROTOTYPES.items():
     _fn = getattr(lib, _name)
     _fn.argtypes = _args
     _fn.restype = ctypes.c_int
+for _name, _args in PROTOTYPES_U32.items():
+    _fn = getattr(lib, _name)
+    _fn.argtypes = _args
+    _fn.restype = ctypes.c_uint32
 for _name, _args in PROTOTYPES_U64.items():
     _fn = getattr(lib, _name)
     _fn.argtypes = _args

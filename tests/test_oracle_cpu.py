@@ -240,9 +240,8 @@ def test_c_abi_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     import sdn_backend
-    declared = set(sdn_backend.PROTOTYPES) | set(sdn_backend.PROTOTYPES_U64) | {"sdn_version"}
-    assert set(names) <= declared | {n for n in names if n.startswith("sdn_render") or n.startswith("sdn_field") or n.startswith("sdn_mlp")}, \
-        sorted(set(names) - declared)
+    declared = set(sdn_backend.PROTOTYPES) | set(sdn_backend.PROTOTYPES_U64) | set(sdn_backend.PROTOTYPES_U32) | {"sdn_version"}
+    assert set(names) == declared, sorted(set(names) ^ declared)
 
 
 def test_ops_fail_loudly_without_a_device():
