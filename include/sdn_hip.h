@@ -98,6 +98,22 @@ int sdn_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive,
                    uint32_t C, uint32_t H, const uint8_t *grid, const float *nears, const float *fars,
                    float *xyzs, float *dirs, float *deltas, const float *noises, void *stream);
 
+/* Extension of march_rays for the native render loop (same samples, bit for bit):
+ *   M_pad      rows of xyzs/dirs/deltas; the rows [n_alive*n_step, M_pad) are cleared by the same launch
+ *              (the reference wrapper memsets all three buffers before every call, raymarching.py:334-336);
+ *   cull_grid  sdn_cull_grid_bytes() bytes from sdn_build_cull_grid, or NULL: exact early-out for rays whose remaining
+ *              segment stays >= 2 voxels away from every occupied voxel (they produce no sample in the reference either);
+ *   live_idx / live_count (both or neither): slot indices that received a sample are appended at
+ *              live_idx[atomicAdd(live_count, n)] -- unordered; the caller zeroes *live_count. */
+int sdn_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t,
+                      const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                      uint32_t C, uint32_t H, const uint8_t *grid, const float *fars, float *xyzs, float *dirs,
+                      float *deltas, const float *noises, uint32_t M_pad, const uint8_t *cull_grid,
+                      uint32_t *live_idx, uint32_t *live_count, void *stream);
+uint32_t sdn_cull_grid_bytes(void);
+/* bitfield: one 128^3 Morton-ordered occupancy slice (cascade 0), 8-byte aligned.  H must be 128. */
+int sdn_build_cull_grid(const uint8_t *bitfield, uint32_t H, uint8_t *cull_grid, void *stream);
+
 /* raymarching.h:17  composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas,
  *                                  weights_sum, depth, image)   -- mutates the last three, rays_alive, rays_t */
 int sdn_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,

@@ -48,6 +48,16 @@ __host__ __device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
 __host__ __device__ __forceinline__ uint32_t morton3D_(uint32_t x, uint32_t y, uint32_t z) {
     return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
 }
+// coordinates < 256: the first spreading step of expand_bits is the identity
+__device__ __forceinline__ uint32_t expand_bits8(uint32_t v) {
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton3D_8bit(uint32_t x, uint32_t y, uint32_t z) {
+    return expand_bits8(x) | (expand_bits8(y) << 1) | (expand_bits8(z) << 2);
+}
 __host__ __device__ __forceinline__ uint32_t morton3D_invert_(uint32_t x) {
     x = x & 0x49249249u;
     x = (x | (x >> 2)) & 0xc30c30c3u;
@@ -61,10 +71,15 @@ __host__ __device__ __forceinline__ uint32_t morton3D_invert_(uint32_t x) {
 // The DDA stepper shared by the three marching kernels
 // (raymarching.cu:359-400 == 427-479 == 750-804).
 // ---------------------------------------------------------------------------
-struct Marcher {
+// FAST = (cascade == 1, bound == 1, H a power of two <= 256): the configuration dnerf runs (bound 1, grid 128).
+// Then the mip level is always 0 and every scaling in the index / voxel-edge arithmetic is by a power of two, i.e.
+// exact, so the float-only forms below produce the same bits as the reference's double / multi-step expressions.
+template <bool FAST>
+struct MarcherT {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
     float rH, H3, Hf, Cf, Hm1;
     float bound, dt_gamma, dt_min, dt_max;
+    float halfH, twoRH, ex, ey, ez;  // FAST only
     double Hd;
     const uint8_t *__restrict__ grid;
 
@@ -80,6 +95,9 @@ struct Marcher {
         dt_min = 2 * kSqrt3 / (float)max_steps;
         dt_max = 2 * kSqrt3 * (float)(1 << (C - 1)) / (float)H;
         grid = grid_;
+        halfH = 0.5f * Hf; twoRH = 2.0f * rH;
+        // nx + 0.5f + 0.5f * signf(d) == nx + (signbit(d) ? 0 : 1), exactly
+        ex = signbit(dx) ? 0.0f : 1.0f; ey = signbit(dy) ? 0.0f : 1.0f; ez = signbit(dz) ? 0.0f : 1.0f;
     }
 
     __device__ __forceinline__ float step_size(float t) const { return clampf_(t * dt_gamma, dt_min, dt_max); }
@@ -91,27 +109,91 @@ struct Marcher {
         y = clampf_(oy + t * dy, -bound, bound);
         z = clampf_(oz + t * dz, -bound, bound);
         dt = step_size(t);
-        const int l0 = mip_from_pos(x, y, z, Cf), l1 = mip_from_dt(dt, Hf, Cf);
-        const int level = l0 > l1 ? l0 : l1;
-        const float mip_bound = fminf(scalbnf(1.0f, level), bound);
-        const float mip_rbound = 1 / mip_bound;
-        // `0.5 * (...) * H` is a double expression in the reference (0.5 is a double literal)
-        const int nx = (int)clampf_((float)(0.5 * (double)(x * mip_rbound + 1) * Hd), 0.0f, Hm1);
-        const int ny = (int)clampf_((float)(0.5 * (double)(y * mip_rbound + 1) * Hd), 0.0f, Hm1);
-        const int nz = (int)clampf_((float)(0.5 * (double)(z * mip_rbound + 1) * Hd), 0.0f, Hm1);
-        const uint32_t index = (uint32_t)((float)level * H3 + (float)morton3D_((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
-        const bool occ = grid[index >> 3] & (1u << (index & 7u));
-        if (occ) return true;
-        const float tx = (((nx + 0.5f + 0.5f * signf_(dx)) * rH * 2 - 1) * mip_bound - x) * rdx;
-        const float ty = (((ny + 0.5f + 0.5f * signf_(dy)) * rH * 2 - 1) * mip_bound - y) * rdy;
-        const float tz = (((nz + 0.5f + 0.5f * signf_(dz)) * rH * 2 - 1) * mip_bound - z) * rdz;
-        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
-        do {
-            t += step_size(t);
-        } while (t < tt);
-        return false;
+        if constexpr (FAST) {
+            const int nx = (int)clampf_((x + 1) * halfH, 0.0f, Hm1);
+            const int ny = (int)clampf_((y + 1) * halfH, 0.0f, Hm1);
+            const int nz = (int)clampf_((z + 1) * halfH, 0.0f, Hm1);
+            const uint32_t index = morton3D_8bit((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+            const bool occ = grid[index >> 3] & (1u << (index & 7u));
+            if (occ) return true;
+            const float tx = ((((float)nx + ex) * twoRH - 1) - x) * rdx;
+            const float ty = ((((float)ny + ey) * twoRH - 1) - y) * rdy;
+            const float tz = ((((float)nz + ez) * twoRH - 1) - z) * rdz;
+            const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+            do {
+                t += step_size(t);
+            } while (t < tt);
+            return false;
+        } else {
+            const int l0 = mip_from_pos(x, y, z, Cf), l1 = mip_from_dt(dt, Hf, Cf);
+            const int level = l0 > l1 ? l0 : l1;
+            const float mip_bound = fminf(scalbnf(1.0f, level), bound);
+            const float mip_rbound = 1 / mip_bound;
+            // `0.5 * (...) * H` is a double expression in the reference (0.5 is a double literal)
+            const int nx = (int)clampf_((float)(0.5 * (double)(x * mip_rbound + 1) * Hd), 0.0f, Hm1);
+            const int ny = (int)clampf_((float)(0.5 * (double)(y * mip_rbound + 1) * Hd), 0.0f, Hm1);
+            const int nz = (int)clampf_((float)(0.5 * (double)(z * mip_rbound + 1) * Hd), 0.0f, Hm1);
+            const uint32_t index = (uint32_t)((float)level * H3 + (float)morton3D_((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+            const bool occ = grid[index >> 3] & (1u << (index & 7u));
+            if (occ) return true;
+            const float tx = (((nx + 0.5f + 0.5f * signf_(dx)) * rH * 2 - 1) * mip_bound - x) * rdx;
+            const float ty = (((ny + 0.5f + 0.5f * signf_(dy)) * rH * 2 - 1) * mip_bound - y) * rdy;
+            const float tz = (((nz + 0.5f + 0.5f * signf_(dz)) * rH * 2 - 1) * mip_bound - z) * rdz;
+            const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+            do {
+                t += step_size(t);
+            } while (t < tt);
+            return false;
+        }
     }
 };
+using Marcher = MarcherT<false>;
+
+static inline bool fast_config(float bound, uint32_t C, uint32_t H) {
+    return C == 1 && bound == 1.0f && H >= 2 && H <= 256 && (H & (H - 1)) == 0;
+}
+
+// ---------------------------------------------------------------------------
+// Exact early-out for rays that cannot produce a sample ("cull grid").
+// cull[32^3] (x fastest) marks coarse cells (4^3 fine voxels of the 128^3 grid) whose 3x3x3 coarse neighbourhood
+// holds any occupied voxel.  A ray whose remaining segment [t, far], tested every cell width, only sees unmarked
+// cells stays >= half a coarse cell (2 fine voxels) away from every occupied voxel, so the reference's marcher --
+// whose probe points lie on that segment up to float rounding -- emits nothing for it: returning "no samples"
+// is exact, not an approximation.  Rays that may hit take the full reference chain from their own t.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kCullRes = 32;
+
+__global__ void __launch_bounds__(256) k_build_cull_grid(const uint8_t *__restrict__ bitfield, uint8_t *__restrict__ cull) {
+    const uint32_t c = threadIdx.x + blockIdx.x * blockDim.x;
+    if (c >= kCullRes * kCullRes * kCullRes) return;
+    const int cx = c & 31, cy = (c >> 5) & 31, cz = c >> 10;
+    const unsigned long long *__restrict__ blocks = reinterpret_cast<const unsigned long long *>(bitfield);
+    bool any = false;
+    for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const int x = cx + dx, y = cy + dy, z = cz + dz;
+                if (x < 0 || y < 0 || z < 0 || x > 31 || y > 31 || z > 31) continue;
+                // a 4x4x4 block of the 128^3 grid is 64 consecutive Morton bits = one aligned 8-byte word
+                any |= blocks[morton3D_((uint32_t)x, (uint32_t)y, (uint32_t)z)] != 0ull;
+            }
+    cull[c] = any ? 1 : 0;
+}
+
+__device__ __forceinline__ bool ray_may_hit(const uint8_t *__restrict__ cull, float ox, float oy, float oz, float dx, float dy, float dz,
+                                            float t, float far) {
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float ds = (2.0f / kCullRes) / fmaxf(len, 1e-12f);  // parameter step = one cull cell along the ray
+    for (float s = t;; s += ds) {
+        const float ss = fminf(s, far);
+        const float x = clampf_(ox + ss * dx, -1.0f, 1.0f), y = clampf_(oy + ss * dy, -1.0f, 1.0f), z = clampf_(oz + ss * dz, -1.0f, 1.0f);
+        const int cx = (int)fminf((x + 1) * (0.5f * kCullRes), (float)(kCullRes - 1));
+        const int cy = (int)fminf((y + 1) * (0.5f * kCullRes), (float)(kCullRes - 1));
+        const int cz = (int)fminf((z + 1) * (0.5f * kCullRes), (float)(kCullRes - 1));
+        if (cull[(cz * (int)kCullRes + cy) * (int)kCullRes + cx]) return true;
+        if (s >= far) return false;
+    }
+}
 
 // ---------------------------------------------------------------------------
 // utils
@@ -199,6 +281,7 @@ __global__ void __launch_bounds__(256) k_packbits(const float4 *__restrict__ gri
 // ---------------------------------------------------------------------------
 constexpr uint32_t kScanBlock = 1024;
 
+template <bool FAST>
 __global__ void __launch_bounds__(256) k_march_train_count(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                            const uint8_t *__restrict__ grid, float bound, float dt_gamma,
                                                            uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
@@ -206,7 +289,7 @@ __global__ void __launch_bounds__(256) k_march_train_count(const float *__restri
                                                            const float *__restrict__ noises, uint32_t *__restrict__ num_steps_out) {
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
     if (n >= N) return;
-    Marcher m;
+    MarcherT<FAST> m;
     m.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid);
     const float far = fars[n];
     float t = nears[n];
@@ -292,6 +375,7 @@ __global__ void k_march_train_finish(int32_t *__restrict__ counter, const uint32
     }
 }
 
+template <bool FAST>
 __global__ void __launch_bounds__(256) k_march_train_write(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                            const uint8_t *__restrict__ grid, float bound, float dt_gamma,
                                                            uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
@@ -306,7 +390,7 @@ __global__ void __launch_bounds__(256) k_march_train_write(const float *__restri
     const uint32_t num_steps = (uint32_t)rays[(size_t)(ray_base + n) * 3 + 2];
     if (num_steps == 0) return;
     if (point_index + num_steps > M) return;
-    Marcher m;
+    MarcherT<FAST> m;
     m.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid);
     const float far = fars[n];
     float t = nears[n];
@@ -394,42 +478,76 @@ __global__ void __launch_bounds__(256) k_composite_train_bwd(const float *__rest
 // ---------------------------------------------------------------------------
 // inference
 // ---------------------------------------------------------------------------
-// raymarching.cu:701-805.  Slots [step, n_step) of each alive ray are written as zeros here, so
-// the caller only has to clear the alignment tail, not the whole buffer.
+// raymarching.cu:701-805.  Extras over the reference kernel (all optional, none changes a sample):
+//   * slots [step, n_step) of each alive ray are written as zeros here and the alignment tail [n_alive*n_step, M_pad)
+//     is cleared by the same launch, so the caller never memsets the sample buffers;
+//   * cull: exact early-out for rays that cannot produce a sample (see ray_may_hit);
+//   * live_idx / live_count: the slots that received a sample are appended (one atomicAdd per wave, ballot-free prefix
+//     via wave shuffles) to a compact list so that the field network is evaluated on samples, not on padded slots.
+template <bool FAST>
 __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
                                                     const float *__restrict__ rays_t, const float *__restrict__ rays_o,
                                                     const float *__restrict__ rays_d, float bound, float dt_gamma, uint32_t max_steps,
                                                     uint32_t C, uint32_t H, const uint8_t *__restrict__ grid,
                                                     const float *__restrict__ fars, float *__restrict__ xyzs, float *__restrict__ dirs,
-                                                    float *__restrict__ deltas, const float *__restrict__ noises) {
+                                                    float *__restrict__ deltas, const float *__restrict__ noises, uint32_t M_pad,
+                                                    const uint8_t *__restrict__ cull, uint32_t *__restrict__ live_idx,
+                                                    uint32_t *__restrict__ live_count) {
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
-    if (n >= n_alive) return;
-    const int index = rays_alive[n];
-    Marcher m;
-    m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid);
-    float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3, *pl = deltas + (size_t)n * n_step * 2;
-    float t = rays_t[index];
-    const float far = fars[index];
+    const uint32_t lane = threadIdx.x & 63u;
     uint32_t step = 0;
-    t += m.step_size(t) * (noises ? noises[n] : 0.0f);
-    float last_t = t, x, y, z, dt;
-    while (t < far && step < n_step) {
-        if (m.probe(t, x, y, z, dt)) {
-            px[0] = x; px[1] = y; px[2] = z;
-            pd[0] = m.dx; pd[1] = m.dy; pd[2] = m.dz;
-            t += dt;
-            pl[0] = dt;
-            pl[1] = t - last_t;
-            last_t = t;
+    if (n < n_alive) {
+        const int index = rays_alive[n];
+        MarcherT<FAST> m;
+        m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid);
+        float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3, *pl = deltas + (size_t)n * n_step * 2;
+        float t = rays_t[index];
+        const float far = fars[index];
+        t += m.step_size(t) * (noises ? noises[n] : 0.0f);
+        float last_t = t, x, y, z, dt;
+        bool go = t < far;
+        if (FAST && cull && go) go = ray_may_hit(cull, m.ox, m.oy, m.oz, m.dx, m.dy, m.dz, t, far);
+        if (go) {
+            while (t < far && step < n_step) {
+                if (m.probe(t, x, y, z, dt)) {
+                    px[0] = x; px[1] = y; px[2] = z;
+                    pd[0] = m.dx; pd[1] = m.dy; pd[2] = m.dz;
+                    t += dt;
+                    pl[0] = dt;
+                    pl[1] = t - last_t;
+                    last_t = t;
+                    px += 3; pd += 3; pl += 2;
+                    step++;
+                }
+            }
+        }
+        for (uint32_t k = step; k < n_step; k++) {
+            px[0] = 0; px[1] = 0; px[2] = 0;
+            pd[0] = 0; pd[1] = 0; pd[2] = 0;
+            pl[0] = 0; pl[1] = 0;
             px += 3; pd += 3; pl += 2;
-            step++;
+        }
+    } else {
+        const uint32_t slot = n_alive * n_step + (n - n_alive);  // spare lanes of the last blocks clear the alignment tail
+        if (slot < M_pad) {
+            xyzs[(size_t)slot * 3] = 0; xyzs[(size_t)slot * 3 + 1] = 0; xyzs[(size_t)slot * 3 + 2] = 0;
+            dirs[(size_t)slot * 3] = 0; dirs[(size_t)slot * 3 + 1] = 0; dirs[(size_t)slot * 3 + 2] = 0;
+            deltas[(size_t)slot * 2] = 0; deltas[(size_t)slot * 2 + 1] = 0;
         }
     }
-    for (; step < n_step; step++) {
-        px[0] = 0; px[1] = 0; px[2] = 0;
-        pd[0] = 0; pd[1] = 0; pd[2] = 0;
-        pl[0] = 0; pl[1] = 0;
-        px += 3; pd += 3; pl += 2;
+    if (live_idx) {  // kernel-uniform
+        uint32_t incl = step;
+        #pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t u = __shfl_up(incl, off, 64);
+            if (lane >= (uint32_t)off) incl += u;
+        }
+        const uint32_t total = __shfl(incl, 63, 64);
+        uint32_t base = 0;
+        if (lane == 63 && total) base = atomicAdd(live_count, total);
+        base = __shfl(base, 63, 64);
+        uint32_t dst = base + incl - step;
+        for (uint32_t k = 0; k < step; k++) live_idx[dst + k] = n * n_step + k;
     }
 }
 
@@ -574,14 +692,19 @@ int sdn_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
     const uint32_t nb = sdn_div_up(N, kScanBlock);
     uint32_t *block_totals = num_steps + N;
     uint32_t *base_out = block_totals + nb;
-    hipLaunchKernelGGL(k_march_train_count, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N,
-                       C, H, nears, fars, noises, num_steps);
+    const bool fast = fast_config(bound, C, H);
+    if (fast) hipLaunchKernelGGL(k_march_train_count<true>, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
+                                 max_steps, N, C, H, nears, fars, noises, num_steps);
+    else hipLaunchKernelGGL(k_march_train_count<false>, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
+                            max_steps, N, C, H, nears, fars, noises, num_steps);
     hipLaunchKernelGGL(k_scan_block_totals, dim3(nb), dim3(kScanBlock), 0, st, num_steps, N, block_totals);
     // The reference writes ray records at rays[atomicAdd(counter+1, 1)] and points at atomicAdd(counter, n):
     // both bases are read on the device from the counter the caller hands in (zeroed by dnerf/renderer.py:291-292).
     hipLaunchKernelGGL(k_march_train_offsets, dim3(nb), dim3(kScanBlock), 0, st, num_steps, N, block_totals, rays, counter, base_out);
-    hipLaunchKernelGGL(k_march_train_write, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N,
-                       C, H, M, nears, fars, noises, rays, counter, xyzs, dirs, deltas);
+    if (fast) hipLaunchKernelGGL(k_march_train_write<true>, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
+                                 max_steps, N, C, H, M, nears, fars, noises, rays, counter, xyzs, dirs, deltas);
+    else hipLaunchKernelGGL(k_march_train_write<false>, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
+                            max_steps, N, C, H, M, nears, fars, noises, rays, counter, xyzs, dirs, deltas);
     hipLaunchKernelGGL(k_march_train_finish, dim3(1), dim3(64), 0, st, counter, base_out, N);
     return sdn_launch_status();
 }
@@ -606,16 +729,53 @@ int sdn_composite_rays_train_backward(const float *grad_weights_sum, const float
     return sdn_launch_status();
 }
 
+static int launch_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
+                             const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                             const uint8_t *grid, const float *fars, float *xyzs, float *dirs, float *deltas, const float *noises,
+                             uint32_t M_pad, const uint8_t *cull, uint32_t *live_idx, uint32_t *live_count, hipStream_t st) {
+    if (n_alive == 0 || n_step == 0) return 0;
+    if (!rays_alive || !rays_t || !rays_o || !rays_d || !grid || !fars || !xyzs || !dirs || !deltas) return SDN_E_BADARG;
+    if (C == 0 || C > 16 || H == 0 || max_steps == 0) return SDN_E_BADARG;
+    if ((live_idx == nullptr) != (live_count == nullptr)) return SDN_E_BADARG;
+    const uint32_t base = n_alive * n_step;
+    if (M_pad < base) M_pad = base;
+    const uint32_t threads = n_alive + (M_pad - base);  // one lane per alive ray + one per tail slot
+    const dim3 g(sdn_div_up(threads, 256u)), b(256);
+    if (fast_config(bound, C, H)) {
+        if (cull && H != 128) cull = nullptr;  // the cull grid is built for the 128^3 grid only
+        hipLaunchKernelGGL(k_march_rays<true>, g, b, 0, st, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
+                           grid, fars, xyzs, dirs, deltas, noises, M_pad, cull, live_idx, live_count);
+    } else {
+        hipLaunchKernelGGL(k_march_rays<false>, g, b, 0, st, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
+                           grid, fars, xyzs, dirs, deltas, noises, M_pad, (const uint8_t *)nullptr, live_idx, live_count);
+    }
+    return sdn_launch_status();
+}
+
 int sdn_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
                    const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
                    const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
                    const float *noises, void *stream) {
     (void)nears;  // unused by the reference kernel as well (raymarching.cu:737)
-    if (n_alive == 0 || n_step == 0) return 0;
-    if (!rays_alive || !rays_t || !rays_o || !rays_d || !grid || !fars || !xyzs || !dirs || !deltas) return SDN_E_BADARG;
-    if (C == 0 || C > 16 || H == 0 || max_steps == 0) return SDN_E_BADARG;
-    hipLaunchKernelGGL(k_march_rays, dim3(sdn_div_up(n_alive, 256u)), dim3(256), 0, (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t,
-                       rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises);
+    return launch_march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs,
+                             deltas, noises, 0, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int sdn_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
+                      const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                      const uint8_t *grid, const float *fars, float *xyzs, float *dirs, float *deltas, const float *noises,
+                      uint32_t M_pad, const uint8_t *cull_grid, uint32_t *live_idx, uint32_t *live_count, void *stream) {
+    return launch_march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs,
+                             deltas, noises, M_pad, cull_grid, live_idx, live_count, (hipStream_t)stream);
+}
+
+uint32_t sdn_cull_grid_bytes(void) { return kCullRes * kCullRes * kCullRes; }
+
+int sdn_build_cull_grid(const uint8_t *bitfield, uint32_t H, uint8_t *cull_grid, void *stream) {
+    if (!bitfield || !cull_grid) return SDN_E_BADARG;
+    if (H != 128) return SDN_E_UNSUPPORTED;
+    if (((uintptr_t)bitfield & 7u) != 0) return SDN_E_BADARG;
+    hipLaunchKernelGGL(k_build_cull_grid, dim3(kCullRes * kCullRes * kCullRes / 256), dim3(256), 0, (hipStream_t)stream, bitfield, cull_grid);
     return sdn_launch_status();
 }
 

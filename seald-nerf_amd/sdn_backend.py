@@ -29,6 +29,8 @@ PROTOTYPES = {
     "sdn_composite_rays_train_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp, _vp],
     "sdn_composite_rays_train_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp],
     "sdn_march_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sdn_march_rays_ex": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp],
+    "sdn_build_cull_grid": [_vp, _u32, _vp, _vp],
     "sdn_composite_rays": [_u32, _u32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sdn_compact_alive": [_vp, _u32, _vp, _vp, _vp, _vp],
     "sdn_grid_encode_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _i32, _u32, _i32, _vp],
@@ -41,6 +43,7 @@ PROTOTYPES = {
 }
 PROTOTYPES_U32 = {
     "sdn_field_weight_blocks": [],
+    "sdn_cull_grid_bytes": [],
 }
 PROTOTYPES_U64 = {
     "sdn_march_rays_train_scratch_bytes": [_u32],
