@@ -184,7 +184,10 @@ __device__ __forceinline__ bool ray_may_hit(const uint8_t *__restrict__ cull, fl
                                             float t, float far) {
     const float len = sqrtf(dx * dx + dy * dy + dz * dz);
     const float ds = (2.0f / kCullRes) / fmaxf(len, 1e-12f);  // parameter step = one cull cell along the ray
-    for (float s = t;; s += ds) {
+    float s = t;
+    // bounded: a unit-cube diagonal is 2*sqrt(3)/ (2/32) = 56 cells; anything longer (degenerate direction, huge far)
+    // falls through to "may hit" and takes the ordinary marcher
+    for (int it = 0; it < 96; it++, s += ds) {
         const float ss = fminf(s, far);
         const float x = clampf_(ox + ss * dx, -1.0f, 1.0f), y = clampf_(oy + ss * dy, -1.0f, 1.0f), z = clampf_(oz + ss * dz, -1.0f, 1.0f);
         const int cx = (int)fminf((x + 1) * (0.5f * kCullRes), (float)(kCullRes - 1));
@@ -193,6 +196,7 @@ __device__ __forceinline__ bool ray_may_hit(const uint8_t *__restrict__ cull, fl
         if (cull[(cz * (int)kCullRes + cy) * (int)kCullRes + cx]) return true;
         if (s >= far) return false;
     }
+    return true;
 }
 
 // ---------------------------------------------------------------------------

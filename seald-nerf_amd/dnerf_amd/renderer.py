@@ -305,11 +305,14 @@ class FrameWorkspace:
         self.count_host = torch.zeros(1, dtype=i32).pin_memory()
         from sdn_backend import lib
         self.scratch = torch.empty(max(int(lib.sdn_compact_alive_scratch_bytes(N)), 4), dtype=torch.uint8, device=device)
+        self.cull = torch.empty(int(lib.sdn_cull_grid_bytes()), dtype=torch.uint8, device=device)
+        self.live_idx = torch.empty(M, dtype=i32, device=device)          # slots that received a sample, per iteration
+        self.live_counts = torch.zeros(1024 + 8, dtype=i32, device=device)  # one counter per loop iteration (<= max_steps)
 
 
 @torch.no_grad()
 def render_frame(model, rays_o, rays_d, time, fp16=False, dt_gamma=0.0, max_steps=1024, T_thresh=1e-2, bg_color=1.0,
-                 workspace=None, field=None, count_samples=True):
+                 workspace=None, field=None, count_samples=True, use_cull=True):
     """One inference frame: rays [N,3] -> {'image' [N,3], 'depth' [N], 'weights_sum' [N], 'n_samples', 'trace'}.
 
     Same schedule as dnerf/renderer.py:340-381 (n_step = clamp(N // n_alive, 1, 8), stop at max_steps),
@@ -317,6 +320,11 @@ def render_frame(model, rays_o, rays_d, time, fp16=False, dt_gamma=0.0, max_step
     `compact_alive` (one 4-byte count read back per iteration instead of a boolean-mask select), and the
     field network may be the fused MFMA kernel (`field`, see dnerf_amd/fused.py) instead of the op-by-op
     network.  `trace` lists (n_alive, n_step, padded_points) per iteration.
+
+    With the fused field the marcher also appends the slots that received a sample to a compact list and the network is
+    evaluated on those only (the reference evaluates every padded slot, including the ~94 % empty ones of the first
+    iteration); rays whose remaining segment provably cannot produce a sample are retired by the marcher's exact
+    cull-grid test instead of stepping through the empty volume voxel by voxel.
     """
     from sdn_backend import lib, check, ptr, stream
     device = rays_o.device
@@ -333,22 +341,34 @@ def render_frame(model, rays_o, rays_d, time, fp16=False, dt_gamma=0.0, max_step
     n_alive = N
     step = 0
     trace = []
-    n_samples = torch.zeros((), dtype=torch.int64, device=device) if count_samples else None
+    use_list = field is not None
+    n_samples = torch.zeros((), dtype=torch.int64, device=device) if (count_samples and not use_list) else None
     st = stream()
     evaluate = field if field is not None else _field_eval(model, time, fp16)
+    cull = None
+    if use_cull and model.grid_size == 128 and model.cascade == 1:
+        check(lib.sdn_build_cull_grid(ptr(bitfield), 128, ptr(ws.cull), st), "build_cull_grid")
+        cull = ptr(ws.cull)
+    if use_list:
+        ws.live_counts.zero_()
+    it = 0
     while step < max_steps and n_alive > 0:
         n_step = max(min(N // n_alive, 8), 1)
         M0 = n_alive * n_step
         M = M0 + (128 - M0 % 128)
         xyzs, dirs, deltas = ws.xyzs[:M], ws.dirs[:M], ws.deltas[:M]
-        xyzs[M0:].zero_(); dirs[M0:].zero_(); deltas[M0:].zero_()
         alive = ws.alive[cur]
-        check(lib.sdn_march_rays(n_alive, n_step, ptr(alive), ptr(ws.rays_t), ptr(rays_o), ptr(rays_d), float(model.bound), float(dt_gamma),
-                                 int(max_steps), int(model.cascade), int(model.grid_size), ptr(bitfield), ptr(nears), ptr(fars), ptr(xyzs),
-                                 ptr(dirs), ptr(deltas), None, st), "march_rays")
-        if count_samples:  # live samples = slots with a non-zero step (untimed bookkeeping; off in the timed bench loop)
+        live_count = ws.live_counts[it:it + 1] if use_list else None
+        check(lib.sdn_march_rays_ex(n_alive, n_step, ptr(alive), ptr(ws.rays_t), ptr(rays_o), ptr(rays_d), float(model.bound),
+                                    float(dt_gamma), int(max_steps), int(model.cascade), int(model.grid_size), ptr(bitfield), ptr(fars),
+                                    ptr(xyzs), ptr(dirs), ptr(deltas), None, M, cull, ptr(ws.live_idx) if use_list else None,
+                                    ptr(live_count), st), "march_rays_ex")
+        if n_samples is not None:  # ops path: live samples = slots with a non-zero step (bookkeeping, off in the timed loop)
             n_samples += (deltas[:M0, 0] > 0).sum()
-        sigmas, rgbs = evaluate(xyzs, dirs)
+        if use_list:
+            sigmas, rgbs = evaluate(xyzs, dirs, ws.live_idx, live_count)
+        else:
+            sigmas, rgbs = evaluate(xyzs, dirs)
         check(lib.sdn_composite_rays(n_alive, n_step, float(T_thresh), ptr(alive), ptr(ws.rays_t), ptr(sigmas), ptr(rgbs), ptr(deltas),
                                      ptr(ws.weights_sum), ptr(ws.depth), ptr(ws.image), st), "composite_rays")
         check(lib.sdn_compact_alive(ptr(alive), n_alive, ptr(ws.alive[1 - cur]), ptr(ws.count), ptr(ws.scratch), st), "compact_alive")
@@ -358,10 +378,15 @@ def render_frame(model, rays_o, rays_d, time, fp16=False, dt_gamma=0.0, max_step
         n_alive = int(ws.count_host[0])
         cur = 1 - cur
         step += n_step
+        it += 1
     image = ws.image + (1 - ws.weights_sum).unsqueeze(-1) * bg_color
     depth = torch.clamp(ws.depth - nears, min=0) / (fars - nears)
+    if count_samples:
+        total = int(ws.live_counts[:it].sum().item()) if use_list else int(n_samples.item())
+    else:
+        total = None
     return {"image": image, "depth": depth, "weights_sum": ws.weights_sum.clone(), "trace": trace, "nears": nears, "fars": fars,
-            "n_samples": int(n_samples.item()) if count_samples else None}
+            "n_samples": total}
 
 
 def _field_eval(model, time, fp16):

@@ -19,7 +19,7 @@ import sdn_backend as _sdn
 from sdn_backend import lib as _lib, check as _check, ptr as _ptr, stream as _stream, to_device as _dev
 
 __all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "march_rays_train",
-           "composite_rays_train", "march_rays", "composite_rays", "compact_alive"]
+           "composite_rays_train", "march_rays", "composite_rays", "compact_alive", "build_cull_grid", "march_rays_ex"]
 
 _f32 = torch.float32
 _i32 = torch.int32
@@ -263,3 +263,31 @@ def compact_alive(rays_alive, out=None, count=None, scratch=None):
     _check(_lib.sdn_compact_alive(_ptr(rays_alive, _i32, "rays_alive"), n, _ptr(out, _i32, "out"), _ptr(count, _i32, "count"),
                                   _ptr(scratch), _stream()), "compact_alive")
     return out, count
+
+
+def build_cull_grid(density_bitfield, H=128):
+    """Extension: 32^3 byte grid marking coarse cells within one cell of an occupied voxel (exact ray early-out)."""
+    cull = torch.empty(int(_lib.sdn_cull_grid_bytes()), dtype=torch.uint8, device=density_bitfield.device)
+    _check(_lib.sdn_build_cull_grid(_ptr(density_bitfield, torch.uint8, "density_bitfield"), int(H), _ptr(cull), _stream()), "build_cull_grid")
+    return cull
+
+
+def march_rays_ex(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, far, align=128, dt_gamma=0,
+                  max_steps=1024, cull_grid=None, want_live_list=False):
+    """Extension of march_rays used by the native loop: same samples bit for bit; optionally culls dead-end rays exactly and
+    returns the (unordered) list of slots that received a sample.  -> xyzs, dirs, deltas[, live_idx, live_count]."""
+    dev = rays_o.device
+    M0 = n_alive * n_step
+    M = M0 + (align - M0 % align) if align > 0 else M0
+    xyzs = torch.empty(M, 3, dtype=_f32, device=dev)
+    dirs = torch.empty(M, 3, dtype=_f32, device=dev)
+    deltas = torch.empty(M, 2, dtype=_f32, device=dev)
+    live_idx = torch.empty(max(M0, 1), dtype=_i32, device=dev) if want_live_list else None
+    live_count = torch.zeros(1, dtype=_i32, device=dev) if want_live_list else None
+    _check(_lib.sdn_march_rays_ex(int(n_alive), int(n_step), _ptr(rays_alive, _i32), _ptr(rays_t, _f32), _ptr(rays_o, _f32), _ptr(rays_d, _f32),
+                                  float(bound), float(dt_gamma), int(max_steps), int(C), int(H), _ptr(density_bitfield, torch.uint8),
+                                  _ptr(far, _f32), _ptr(xyzs), _ptr(dirs), _ptr(deltas), None, M, _ptr(cull_grid), _ptr(live_idx),
+                                  _ptr(live_count), _stream()), "march_rays_ex")
+    if want_live_list:
+        return xyzs, dirs, deltas, live_idx, live_count
+    return xyzs, dirs, deltas

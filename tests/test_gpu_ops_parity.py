@@ -96,6 +96,42 @@ def test_march_rays_bit_exact(cam, n_step, dt_gamma):
     assert (ref[2][:, 0] > 0).sum() > 100  # the test actually sampled something
 
 
+@pytest.mark.parametrize("n_step", [1, 8])
+def test_march_rays_ex_cull_and_live_list_are_exact(cam, n_step):
+    """The cull-grid early-out and the live list must not change a single bit of the samples, at any stage of a render:
+    checked on fresh rays and on rays advanced part-way through / past the figure."""
+    import raymarching
+    N = cam["N"]
+    cull = raymarching.build_cull_grid(_dev(cam["bf"]))
+    # reference semantics of the cull grid itself: cell marked <=> an occupied voxel within its 3x3x3 coarse neighbourhood
+    bits = np.unpackbits(cam["bf"], bitorder="little")
+    from dnerf_amd import scene
+    g = np.arange(128)
+    ix, iy, iz = np.meshgrid(g, g, g, indexing="ij")
+    occ = np.zeros((128, 128, 128), bool)
+    occ[ix.reshape(-1), iy.reshape(-1), iz.reshape(-1)] = bits[scene.morton3d(ix.reshape(-1), iy.reshape(-1), iz.reshape(-1))] > 0
+    coarse = occ.reshape(32, 4, 32, 4, 32, 4).any(axis=(1, 3, 5))
+    pad = np.pad(coarse, 1)
+    dil = np.zeros_like(coarse)
+    for a in range(3):
+        for b in range(3):
+            for c in range(3):
+                dil |= pad[a:a + 32, b:b + 32, c:c + 32]
+    assert np.array_equal(cull.cpu().numpy().reshape(32, 32, 32).astype(bool), dil.transpose(2, 1, 0))  # stored x fastest
+    alive = np.arange(N, dtype=np.int32)
+    for advance in (0.0, 0.15, 0.6, 1.5):
+        rays_t = (cam["nears"] + np.float32(advance)).astype(np.float32)
+        ref = O.march_rays(N, n_step, alive, rays_t, cam["ro"], cam["rd"], 1.0, cam["bf"], 1, 128, cam["nears"], cam["fars"], align=128)
+        out = raymarching.march_rays_ex(N, n_step, _dev(alive), _dev(rays_t), _dev(cam["ro"]), _dev(cam["rd"]), 1.0, _dev(cam["bf"]), 1, 128,
+                                        _dev(cam["fars"]), 128, 0.0, 1024, cull, True)
+        for o, r, name in zip(out[:3], ref, ("xyzs", "dirs", "deltas")):
+            assert np.array_equal(o.cpu().numpy().view(np.uint32), r.view(np.uint32)), (name, advance)
+        live = np.nonzero(ref[2][: N * n_step, 0] > 0)[0]
+        cnt = int(out[4].item())
+        assert cnt == live.shape[0]
+        assert np.array_equal(np.sort(out[3][:cnt].cpu().numpy()), live)   # unordered, complete, no duplicates
+
+
 def test_march_rays_perturb_uses_noise(cam):
     import raymarching
     N = cam["N"]
