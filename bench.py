@@ -43,23 +43,6 @@ def parse():
     return ap.parse_args()
 
 
-def shard_rays(n_rays, W, rank, world, tile=16):
-    """Interleaved 16x16-pixel tiles dealt round-robin: the object-covering centre of the image is
-    balanced across ranks.  Returns the int64 ray indices of this rank, padded to equal length with repeats of its
-    last ray so that all_gather_into_tensor sees equal shards (padding is dropped after the gather)."""
-    H = n_rays // W
-    ty, tx = (H + tile - 1) // tile, (W + tile - 1) // tile
-    ys, xs = np.divmod(np.arange(n_rays), W)
-    tile_id = (ys // tile) * tx + (xs // tile)
-    owner = tile_id % world
-    mine = np.nonzero(owner == rank)[0]
-    per = max(int((owner == r).sum()) for r in range(world))
-    pad = per - mine.shape[0]
-    if pad:
-        mine = np.concatenate([mine, np.repeat(mine[-1:], pad)])
-    return mine, per
-
-
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -85,12 +68,11 @@ def main():
     sc = build_scene(H=args.size, W=args.size, device=dev, seed=0)
     n_total = sc.rays_o.shape[0]
     if world > 1:
+        from dnerf_amd.dist import shard_rays, FrameGather
         idx, per = shard_rays(n_total, args.size, rank, world)
         idx_t = torch.from_numpy(idx).to(dev)
         rays_o, rays_d = sc.rays_o[idx_t].contiguous(), sc.rays_d[idx_t].contiguous()
-        gathered = torch.empty(world * per, 4, dtype=torch.float32, device=dev)
-        all_idx = torch.from_numpy(np.concatenate([shard_rays(n_total, args.size, r, world)[0] for r in range(world)])).to(dev)
-        frame = torch.empty(n_total, 4, dtype=torch.float32, device=dev)
+        gather = FrameGather(n_total, args.size, world, dev)
     else:
         rays_o, rays_d = sc.rays_o, sc.rays_d
     n_local = rays_o.shape[0]
@@ -107,9 +89,7 @@ def main():
         out = render_frame(sc.model, rays_o, rays_d, sc.time, fp16=fp16, workspace=ws, field=field, count_samples=count)
         sdn_backend.timers = None
         if world > 1:
-            local = torch.cat([out["image"], out["depth"].unsqueeze(-1)], dim=1)
-            dist.all_gather_into_tensor(gathered, local)
-            frame[all_idx] = gathered  # un-permute (padding rows rewrite a pixel with its own value)
+            gather(out["image"], out["depth"])  # one RCCL all-gather per frame + local un-permute
         return out
 
     # untimed: sample count of this rank's shard (deterministic), then warm-up
@@ -154,7 +134,7 @@ def main():
                    "field": field_kind, "parallelism": f"ray-tiles x{world}" if world > 1 else "single GPU"},
     }
     if rank == 0:
-        result["roofline"], result["kernel_times"] = roofline(timers, fp16)
+        result["roofline"], result["kernel_times"] = roofline(timers, fp16, n_samples_local, n_iters)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sc, args.cpu_baseline_side)
         print(json.dumps(result))
@@ -162,12 +142,17 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline(timers, fp16):
+def roofline(timers, fp16, n_samples, n_iters):
     """Roofline entry of the dominant TRACKED kernel: achieved = algorithmic bytes (or flops) per launch / average launch
-    duration, both from the HIP events recorded around the launches inside the timed region."""
+    duration, both from the HIP events recorded around the launches inside the timed region.  The fused field kernel
+    evaluates only the live samples of each iteration (device-side list), so its units per launch are the frame's sampled
+    points / loop iterations, not the padded slot count the launch is sized for."""
     summ = timers.summary()
     if not summ:
         return None, {}
+    if "field_forward_f16" in summ:
+        summ["field_forward_f16"]["avg_units"] = n_samples / max(n_iters, 1)
+        summ["field_forward_f16"]["units"] = int(summ["field_forward_f16"]["avg_units"] * summ["field_forward_f16"]["launches"])
     name = max(summ, key=lambda k: summ[k]["total_ms"])
     s = summ[name]
     if name.startswith("grid_encode_fwd"):

@@ -111,7 +111,8 @@ int sdn_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_t *rays_ali
                       float *deltas, const float *noises, uint32_t M_pad, const uint8_t *cull_grid,
                       uint32_t *live_idx, uint32_t *live_count, void *stream);
 uint32_t sdn_cull_grid_bytes(void);
-/* bitfield: one 128^3 Morton-ordered occupancy slice (cascade 0), 8-byte aligned.  H must be 128. */
+/* bitfield: one 128^3 Morton-ordered occupancy slice (cascade 0), 8-byte aligned.  H must be 128.
+ * cull_grid: 32^3 bits (bit (z*32+y)*32+x, 16-byte aligned): cell marked iff an occupied voxel lies in its 3x3x3 neighbourhood. */
 int sdn_build_cull_grid(const uint8_t *bitfield, uint32_t H, uint8_t *cull_grid, void *stream);
 
 /* raymarching.h:17  composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas,

@@ -71,6 +71,12 @@ __host__ __device__ __forceinline__ uint32_t morton3D_invert_(uint32_t x) {
 // The DDA stepper shared by the three marching kernels
 // (raymarching.cu:359-400 == 427-479 == 750-804).
 // ---------------------------------------------------------------------------
+constexpr uint32_t kCullRes = 32;  // cull grid resolution (see "Exact early-out" below)
+__device__ __forceinline__ bool cull_marked(const uint32_t *cull_bits, int cx, int cy, int cz) {
+    const uint32_t c = ((uint32_t)cz * kCullRes + (uint32_t)cy) * kCullRes + (uint32_t)cx;
+    return (cull_bits[c >> 5] >> (c & 31u)) & 1u;
+}
+
 // FAST = (cascade == 1, bound == 1, H a power of two <= 256): the configuration dnerf runs (bound 1, grid 128).
 // Then the mip level is always 0 and every scaling in the index / voxel-edge arithmetic is by a power of two, i.e.
 // exact, so the float-only forms below produce the same bits as the reference's double / multi-step expressions.
@@ -104,7 +110,7 @@ struct MarcherT {
 
     // One loop-body evaluation at parameter t.  Occupied: returns true with the sample in
     // (x,y,z,dt), t untouched.  Empty: returns false with t advanced past the voxel.
-    __device__ __forceinline__ bool probe(float &t, float &x, float &y, float &z, float &dt) const {
+    __device__ __forceinline__ bool probe(float &t, float &x, float &y, float &z, float &dt, const uint32_t *cull_bits = nullptr) const {
         x = clampf_(ox + t * dx, -bound, bound);
         y = clampf_(oy + t * dy, -bound, bound);
         z = clampf_(oz + t * dz, -bound, bound);
@@ -113,8 +119,12 @@ struct MarcherT {
             const int nx = (int)clampf_((x + 1) * halfH, 0.0f, Hm1);
             const int ny = (int)clampf_((y + 1) * halfH, 0.0f, Hm1);
             const int nz = (int)clampf_((z + 1) * halfH, 0.0f, Hm1);
-            const uint32_t index = morton3D_8bit((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
-            const bool occ = grid[index >> 3] & (1u << (index & 7u));
+            bool occ = false;
+            // an unmarked cull cell holds no occupied voxel: the fine bit (a dependent L2 load) is only fetched near the object
+            if (!cull_bits || cull_marked(cull_bits, nx >> 2, ny >> 2, nz >> 2)) {
+                const uint32_t index = morton3D_8bit((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+                occ = grid[index >> 3] & (1u << (index & 7u));
+            }
             if (occ) return true;
             const float tx = ((((float)nx + ex) * twoRH - 1) - x) * rdx;
             const float ty = ((((float)ny + ey) * twoRH - 1) - y) * rdy;
@@ -161,11 +171,9 @@ static inline bool fast_config(float bound, uint32_t C, uint32_t H) {
 // whose probe points lie on that segment up to float rounding -- emits nothing for it: returning "no samples"
 // is exact, not an approximation.  Rays that may hit take the full reference chain from their own t.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kCullRes = 32;
 
-__global__ void __launch_bounds__(256) k_build_cull_grid(const uint8_t *__restrict__ bitfield, uint8_t *__restrict__ cull) {
-    const uint32_t c = threadIdx.x + blockIdx.x * blockDim.x;
-    if (c >= kCullRes * kCullRes * kCullRes) return;
+__global__ void __launch_bounds__(256) k_build_cull_grid(const uint8_t *__restrict__ bitfield, uint32_t *__restrict__ cull_bits) {
+    const uint32_t c = threadIdx.x + blockIdx.x * blockDim.x;  // grid is exactly 32^3 threads
     const int cx = c & 31, cy = (c >> 5) & 31, cz = c >> 10;
     const unsigned long long *__restrict__ blocks = reinterpret_cast<const unsigned long long *>(bitfield);
     bool any = false;
@@ -177,25 +185,35 @@ __global__ void __launch_bounds__(256) k_build_cull_grid(const uint8_t *__restri
                 // a 4x4x4 block of the 128^3 grid is 64 consecutive Morton bits = one aligned 8-byte word
                 any |= blocks[morton3D_((uint32_t)x, (uint32_t)y, (uint32_t)z)] != 0ull;
             }
-    cull[c] = any ? 1 : 0;
+    const unsigned long long m = __ballot(any);  // lane i <-> cell c0 + i
+    if ((threadIdx.x & 63u) == 0) {
+        cull_bits[c >> 5] = (uint32_t)m;
+        cull_bits[(c >> 5) + 1] = (uint32_t)(m >> 32);
+    }
 }
 
-__device__ __forceinline__ bool ray_may_hit(const uint8_t *__restrict__ cull, float ox, float oy, float oz, float dx, float dy, float dz,
-                                            float t, float far) {
+// Scans the remaining segment [t, far] once per cull-cell width.  Returns false if no marked cell is met (the ray
+// cannot produce a sample).  Otherwise t_end receives a parameter beyond which no marked cell is met any more: the
+// marcher may stop there -- the reference would only step through empty voxels from there to `far`.
+__device__ __forceinline__ bool ray_may_hit(const uint32_t *cull_bits, float ox, float oy, float oz, float dx, float dy, float dz,
+                                            float t, float far, float &t_end) {
     const float len = sqrtf(dx * dx + dy * dy + dz * dz);
     const float ds = (2.0f / kCullRes) / fmaxf(len, 1e-12f);  // parameter step = one cull cell along the ray
     float s = t;
-    // bounded: a unit-cube diagonal is 2*sqrt(3)/ (2/32) = 56 cells; anything longer (degenerate direction, huge far)
-    // falls through to "may hit" and takes the ordinary marcher
+    bool hit = false;
+    t_end = far;
+    // bounded: a unit-cube diagonal is 2*sqrt(3) / (2/32) = 56 cells; anything longer (degenerate direction, huge far)
+    // falls through to "may hit, no early end" and takes the ordinary marcher
     for (int it = 0; it < 96; it++, s += ds) {
         const float ss = fminf(s, far);
         const float x = clampf_(ox + ss * dx, -1.0f, 1.0f), y = clampf_(oy + ss * dy, -1.0f, 1.0f), z = clampf_(oz + ss * dz, -1.0f, 1.0f);
         const int cx = (int)fminf((x + 1) * (0.5f * kCullRes), (float)(kCullRes - 1));
         const int cy = (int)fminf((y + 1) * (0.5f * kCullRes), (float)(kCullRes - 1));
         const int cz = (int)fminf((z + 1) * (0.5f * kCullRes), (float)(kCullRes - 1));
-        if (cull[(cz * (int)kCullRes + cy) * (int)kCullRes + cx]) return true;
-        if (s >= far) return false;
+        if (cull_marked(cull_bits, cx, cy, cz)) { hit = true; t_end = ss + ds; }
+        if (s >= far) return hit;
     }
+    t_end = far;
     return true;
 }
 
@@ -495,8 +513,17 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
                                                     uint32_t C, uint32_t H, const uint8_t *__restrict__ grid,
                                                     const float *__restrict__ fars, float *__restrict__ xyzs, float *__restrict__ dirs,
                                                     float *__restrict__ deltas, const float *__restrict__ noises, uint32_t M_pad,
-                                                    const uint8_t *__restrict__ cull, uint32_t *__restrict__ live_idx,
+                                                    const uint32_t *__restrict__ cull, uint32_t *__restrict__ live_idx,
                                                     uint32_t *__restrict__ live_count) {
+    __shared__ uint4 s_cull4[FAST ? 256 : 1];  // 32^3 bits = 4 KiB
+    const uint32_t *s_cull = nullptr;
+    if constexpr (FAST) {
+        if (cull) {  // kernel-uniform
+            s_cull4[threadIdx.x] = reinterpret_cast<const uint4 *>(cull)[threadIdx.x];
+            __syncthreads();
+            s_cull = reinterpret_cast<const uint32_t *>(s_cull4);
+        }
+    }
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t step = 0;
@@ -510,10 +537,11 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
         t += m.step_size(t) * (noises ? noises[n] : 0.0f);
         float last_t = t, x, y, z, dt;
         bool go = t < far;
-        if (FAST && cull && go) go = ray_may_hit(cull, m.ox, m.oy, m.oz, m.dx, m.dy, m.dz, t, far);
+        float t_end = far;
+        if (FAST && s_cull && go) go = ray_may_hit(s_cull, m.ox, m.oy, m.oz, m.dx, m.dy, m.dz, t, far, t_end);
         if (go) {
-            while (t < far && step < n_step) {
-                if (m.probe(t, x, y, z, dt)) {
+            while (t < far && t < t_end && step < n_step) {
+                if (m.probe(t, x, y, z, dt, s_cull)) {
                     px[0] = x; px[1] = y; px[2] = z;
                     pd[0] = m.dx; pd[1] = m.dy; pd[2] = m.dz;
                     t += dt;
@@ -736,7 +764,7 @@ int sdn_composite_rays_train_backward(const float *grad_weights_sum, const float
 static int launch_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
                              const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
                              const uint8_t *grid, const float *fars, float *xyzs, float *dirs, float *deltas, const float *noises,
-                             uint32_t M_pad, const uint8_t *cull, uint32_t *live_idx, uint32_t *live_count, hipStream_t st) {
+                             uint32_t M_pad, const uint32_t *cull, uint32_t *live_idx, uint32_t *live_count, hipStream_t st) {
     if (n_alive == 0 || n_step == 0) return 0;
     if (!rays_alive || !rays_t || !rays_o || !rays_d || !grid || !fars || !xyzs || !dirs || !deltas) return SDN_E_BADARG;
     if (C == 0 || C > 16 || H == 0 || max_steps == 0) return SDN_E_BADARG;
@@ -751,7 +779,7 @@ static int launch_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *r
                            grid, fars, xyzs, dirs, deltas, noises, M_pad, cull, live_idx, live_count);
     } else {
         hipLaunchKernelGGL(k_march_rays<false>, g, b, 0, st, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
-                           grid, fars, xyzs, dirs, deltas, noises, M_pad, (const uint8_t *)nullptr, live_idx, live_count);
+                           grid, fars, xyzs, dirs, deltas, noises, M_pad, (const uint32_t *)nullptr, live_idx, live_count);
     }
     return sdn_launch_status();
 }
@@ -770,16 +798,17 @@ int sdn_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_t *rays_ali
                       const uint8_t *grid, const float *fars, float *xyzs, float *dirs, float *deltas, const float *noises,
                       uint32_t M_pad, const uint8_t *cull_grid, uint32_t *live_idx, uint32_t *live_count, void *stream) {
     return launch_march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs,
-                             deltas, noises, M_pad, cull_grid, live_idx, live_count, (hipStream_t)stream);
+                             deltas, noises, M_pad, (const uint32_t *)cull_grid, live_idx, live_count, (hipStream_t)stream);
 }
 
-uint32_t sdn_cull_grid_bytes(void) { return kCullRes * kCullRes * kCullRes; }
+uint32_t sdn_cull_grid_bytes(void) { return kCullRes * kCullRes * kCullRes / 8; }
 
 int sdn_build_cull_grid(const uint8_t *bitfield, uint32_t H, uint8_t *cull_grid, void *stream) {
     if (!bitfield || !cull_grid) return SDN_E_BADARG;
     if (H != 128) return SDN_E_UNSUPPORTED;
-    if (((uintptr_t)bitfield & 7u) != 0) return SDN_E_BADARG;
-    hipLaunchKernelGGL(k_build_cull_grid, dim3(kCullRes * kCullRes * kCullRes / 256), dim3(256), 0, (hipStream_t)stream, bitfield, cull_grid);
+    if (((uintptr_t)bitfield & 7u) != 0 || ((uintptr_t)cull_grid & 15u) != 0) return SDN_E_BADARG;
+    hipLaunchKernelGGL(k_build_cull_grid, dim3(kCullRes * kCullRes * kCullRes / 256), dim3(256), 0, (hipStream_t)stream, bitfield,
+                       (uint32_t *)cull_grid);
     return sdn_launch_status();
 }
 

@@ -117,7 +117,8 @@ def test_march_rays_ex_cull_and_live_list_are_exact(cam, n_step):
         for b in range(3):
             for c in range(3):
                 dil |= pad[a:a + 32, b:b + 32, c:c + 32]
-    assert np.array_equal(cull.cpu().numpy().reshape(32, 32, 32).astype(bool), dil.transpose(2, 1, 0))  # stored x fastest
+    cull_bits = np.unpackbits(cull.cpu().numpy(), bitorder="little").reshape(32, 32, 32).astype(bool)   # bit c = (z*32 + y)*32 + x
+    assert np.array_equal(cull_bits, dil.transpose(2, 1, 0))
     alive = np.arange(N, dtype=np.int32)
     for advance in (0.0, 0.15, 0.6, 1.5):
         rays_t = (cam["nears"] + np.float32(advance)).astype(np.float32)
