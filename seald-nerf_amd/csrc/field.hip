@@ -11,19 +11,22 @@
 // round-tripping [M,128] activations through HBM.  Here it is ONE launch and activations never leave registers.
 //
 // Mapping (see DESIGN.md "fused field kernel"):
-//   * one wave = 32 sample points = the N dimension of v_mfma_f32_32x32x16_f16; weights are the A operand
-//     (M = output features), activations the B operand (K = input features).  The accumulator of layer i
-//     (feature rows in registers, point on the lane) converts in place (ReLU, cvt_pk_f16) into the B operand
-//     of layer i+1 -- no LDS, no barriers, no cross-lane traffic between layers.  The k-order this implies
-//     (element j of lane-half h <-> feature 16s + 8(j>>2) + 4h + (j&3)) is baked into the host-side weight
-//     packing (dnerf_amd/fused.py), as are the first layer's freq-feature order, the grid-feature order and
-//     the SH / geo_feat order of the colour net.
+//   * workgroup = 4 waves = 128 sample points; one wave = 32 points = the N dimension of
+//     v_mfma_f32_32x32x16_f16.  Weights are the A operand (M = output features), activations the B operand
+//     (K = input features).  The accumulator of layer i (feature rows in registers, point on the lane) converts
+//     in place (ReLU, cvt_pk_f16) into the B operand of layer i+1 -- no cross-lane traffic between layers.  The
+//     k-order this implies (element j of lane-half h <-> feature 16s + 8(j>>2) + 4h + (j&3)) is baked into the
+//     host-side weight packing (dnerf_amd/fused.py), as are the first layer's freq-feature order, the
+//     grid-feature order and the SH / geo_feat order of the colour net.
+//   * weights (240 fragments of 1 KiB, fragment order) are streamed through LDS in 8 stages
+//     (D0 16 KiB | D1..D6 32 KiB each | D7+S0+S1+C0+C1+C2 32 KiB) with direct-to-LDS loads
+//     (global_load_lds_dwordx4), double-buffered, one barrier per stage: stage s+1 lands while stage s feeds
+//     the MFMAs through conflict-free ds_read_b128 (lane-linear fragments).  HBM/L2 sees each weight byte once
+//     per 128 points instead of once per 32.
 //   * the time encoding is the same for every point: its contribution W0[:,63:76] . enc(t) is a per-frame
 //     bias vector (computed on the host) loaded as the initial accumulator of the first layer.
-//   * weights (240 fragments of 1 KiB, fragment order) are streamed from L2 with one 16-byte load per lane
-//     per MFMA; every wave of the chip reads the same 240 KiB.
-//   * the 128 table gathers per point are split over the two lane-halves (levels 0-7 / 8-15): 64 independent
-//     4-byte loads per lane, issued per level before the blend.
+//   * the 128 table gathers per point are split over the two lane-halves (levels 0-7 / 8-15); row strides,
+//     wrap masks and scales of the tiled levels are host-precomputed (no integer division on the device).
 //   * optional live-sample index list: only slots that hold a sample are evaluated (the reference evaluates
 //     the network on every padded slot).
 #include <math.h>
@@ -34,11 +37,10 @@
 
 namespace {
 
-using namespace sdn_grid;
-
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// fragment (1 KiB block) indices inside the packed weight buffer
 constexpr int kBlkD0 = 0;                 // 4 Mt x 4 ks
 constexpr int kBlkD1 = kBlkD0 + 16;       // 6 layers x (4 Mt x 8 ks)
 constexpr int kBlkD7 = kBlkD1 + 6 * 32;   // 1 Mt x 8 ks
@@ -48,6 +50,19 @@ constexpr int kBlkC0 = kBlkS1 + 4;        // 2 Mt x 2 ks
 constexpr int kBlkC1 = kBlkC0 + 4;        // 2 Mt x 4 ks
 constexpr int kBlkC2 = kBlkC1 + 8;        // 1 Mt x 4 ks
 constexpr int kBlkTotal = kBlkC2 + 4;     // 240
+static_assert(kBlkTotal - kBlkD7 == 32, "the tail stage must be exactly one 32 KiB buffer");
+
+constexpr int kStageBytes = 32768;
+
+// tiled-grid level constants (D = 3, align_corners = false), host-precomputed: gridencoder.cu:66-84,138-139
+struct TiledLevels {
+    uint32_t offset[16];  // first row of the level
+    uint32_t s1[16];      // row stride of +1 in y (0 if the dimension is dropped: stride > rows)
+    uint32_t s2[16];      // row stride of +1 in z (0 if dropped)
+    uint32_t hsize[16];   // rows in the level
+    uint32_t mask[16];    // hsize - 1 if hsize is a power of two, else 0
+    float scale[16];
+};
 
 struct FieldArgs {
     const float *xyzs;        // [M,3]
@@ -55,7 +70,7 @@ struct FieldArgs {
     const uint32_t *live_idx; // [<=M] slot indices to evaluate, or nullptr = all M slots
     const uint32_t *live_count;
     uint32_t M;
-    const half8 *weights;     // kBlkTotal x 64 lanes x 8 halfs
+    const unsigned char *weights;  // kBlkTotal KiB, fragment order
     const float *bias0;       // [128] time-encoding contribution to the first deform layer
     const __half *table;      // grid embeddings, fp16 [rows, 2]
     float *sigmas;            // [M]
@@ -66,8 +81,6 @@ struct FieldArgs {
 };
 
 __device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-
-__device__ __forceinline__ half8 ldw(const half8 *w, int blk, uint32_t lane) { return w[(size_t)blk * 64 + lane]; }
 
 // accumulator tile -> the two B fragments (k-steps) it provides to the next layer
 template <bool RELU>
@@ -100,18 +113,34 @@ __device__ __forceinline__ float fast_sin(float a) {
     return __int_as_float(__float_as_int(s) ^ ((ki & 1) << 31));
 }
 
-__global__ void __launch_bounds__(256) k_field_f16(FieldArgs P, LevelParams lp) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+// Stage `nbytes` (multiple of 4 KiB) of packed weights global -> LDS, all 256 threads, 16 B per lane per instruction.
+// One wave-instruction moves 1 KiB to a wave-uniform LDS base + lane * 16 (global_load_lds_dwordx4).
+__device__ __forceinline__ void stage_load(const unsigned char *__restrict__ g, unsigned char *lds, int nbytes, uint32_t wave, uint32_t lane) {
+    for (int c = (int)wave; c < nbytes / 1024; c += 4) {
+        const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)c * 1024u);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(lds + off), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ half8 lds_frag(const unsigned char *buf, int blk, uint32_t lane) {
+    return *reinterpret_cast<const half8 *>(buf + (size_t)blk * 1024 + lane * 16);
+}
+
+__global__ void __launch_bounds__(256, 2) k_field_f16(FieldArgs P, TiledLevels lv) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_w[2][kStageBytes];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t count = P.live_idx ? *P.live_count : P.M;
-    const uint32_t base = gw * 32u;
-    if (base >= count) return;  // wave-uniform
+    if (blockIdx.x * 128u >= count) return;  // workgroup-uniform: nothing to do, no barrier touched
     const uint32_t n = lane & 31u, h = lane >> 5;
-    const uint32_t i = base + n;
+    const uint32_t i = blockIdx.x * 128u + wave * 32u + n;
     const bool valid = i < count;
-    const uint32_t ii = valid ? i : (count - 1);
+    const uint32_t ii = valid ? i : (count - 1);  // idle lanes recompute the last point and store nothing
     const uint32_t p = P.live_idx ? P.live_idx[ii] : ii;
-    const half8 *__restrict__ W = P.weights;
+
+    // stage 0 (D0, 16 KiB) -> buf 0 and stage 1 (D1) -> buf 1 start now and land under the feature computation
+    stage_load(P.weights + (size_t)kBlkD0 * 1024, s_w[0], 16 * 1024, wave, lane);
+    stage_load(P.weights + (size_t)kBlkD1 * 1024, s_w[1], kStageBytes, wave, lane);
 
     const float x0 = P.xyzs[(size_t)p * 3], x1 = P.xyzs[(size_t)p * 3 + 1], x2 = P.xyzs[(size_t)p * 3 + 2];
     const float d0 = P.dirs[(size_t)p * 3], d1 = P.dirs[(size_t)p * 3 + 1], d2 = P.dirs[(size_t)p * 3 + 2];
@@ -130,7 +159,7 @@ __global__ void __launch_bounds__(256) k_field_f16(FieldArgs P, LevelParams lp) 
                 float v;
                 if (q < 30) {
                     const int pr = q >> 1, f = pr / 3, dd = pr % 3;
-                    // kernel_freq (freqencoder.cu:52-56): sin(x * 2^f + (col % 2) * pi/2), same float ops as encoders.hip
+                    // kernel_freq (freqencoder.cu:52-56): sin(x * 2^f + (col % 2) * pi/2), same float argument as encoders.hip
                     const float arg = scalbnf(xs[dd], f) * fscale + (float)(q & 1) * (3.141592653589793f / 2);
                     v = fast_sin(arg);
                 } else if (q == 30) {
@@ -148,38 +177,51 @@ __global__ void __launch_bounds__(256) k_field_f16(FieldArgs P, LevelParams lp) 
         #pragma unroll
         for (int r = 0; r < 16; r++) acc[mt][r] = P.bias0[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h];
     }
+    __syncthreads();  // (waits this thread's direct-to-LDS loads, then the workgroup's): D0 and D1 are resident
     #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
         #pragma unroll
-        for (int mt = 0; mt < 4; mt++) acc[mt] = mfma(ldw(W, kBlkD0 + mt * 4 + ks, lane), bf[ks], acc[mt]);
+        for (int mt = 0; mt < 4; mt++) acc[mt] = mfma(lds_frag(s_w[0], mt * 4 + ks, lane), bf[ks], acc[mt]);
     }
 
-    // ---------------- deform layers 1..6 (128 -> 128, ReLU) ----------------
+    // ---------------- deform layers 1..6 (128 -> 128, ReLU): stage l+1 uses buffer (l+1)&1 ----------------
     for (int l = 0; l < 6; l++) {
+        const unsigned char *cur = s_w[(l + 1) & 1];
         #pragma unroll
         for (int t = 0; t < 4; t++) acc_to_frags<true>(acc[t], bf[2 * t], bf[2 * t + 1]);
-        #pragma unroll
-        for (int mt = 0; mt < 4; mt++) {
-            #pragma unroll
-            for (int r = 0; r < 16; r++) acc[mt][r] = 0.0f;
-        }
-        const int blk = kBlkD1 + l * 32;
+        __syncthreads();  // stage l+1 landed for everyone; everyone is done reading the other buffer (layer l)
+        // refill the other buffer with stage l+2 (D(l+2) for l < 5, the tail stage for l == 5); it lands under this layer's MFMAs
+        stage_load(P.weights + (size_t)(l < 5 ? kBlkD1 + (l + 1) * 32 : kBlkD7) * 1024, s_w[l & 1], kStageBytes, wave, lane);
         #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
             #pragma unroll
-            for (int mt = 0; mt < 4; mt++) acc[mt] = mfma(ldw(W, blk + mt * 8 + ks, lane), bf[ks], acc[mt]);
+            for (int mt = 0; mt < 4; mt++) {
+                const half8 a = lds_frag(cur, mt * 8 + ks, lane);
+                if (ks == 0) {
+                    f32x16 z;
+                    #pragma unroll
+                    for (int r = 0; r < 16; r++) z[r] = 0.0f;
+                    acc[mt] = mfma(a, bf[0], z);
+                } else {
+                    acc[mt] = mfma(a, bf[ks], acc[mt]);
+                }
+            }
         }
     }
+    #pragma unroll
+    for (int t = 0; t < 4; t++) acc_to_frags<true>(acc[t], bf[2 * t], bf[2 * t + 1]);
+    __syncthreads();  // tail stage (D7 | S0 | S1 | C0 | C1 | C2) resident in buffer 1
+    const unsigned char *tail = s_w[1];
+    constexpr int tD7 = 0, tS0 = kBlkS0 - kBlkD7, tS1 = kBlkS1 - kBlkD7, tC0 = kBlkC0 - kBlkD7, tC1 = kBlkC1 - kBlkD7, tC2 = kBlkC2 - kBlkD7;
+
     // ---------------- deform layer 7 (128 -> 3) ----------------
     float u[3];
     {
-        #pragma unroll
-        for (int t = 0; t < 4; t++) acc_to_frags<true>(acc[t], bf[2 * t], bf[2 * t + 1]);
         f32x16 o;
         #pragma unroll
         for (int r = 0; r < 16; r++) o[r] = 0.0f;
         #pragma unroll
-        for (int ks = 0; ks < 8; ks++) o = mfma(ldw(W, kBlkD7 + ks, lane), bf[ks], o);
+        for (int ks = 0; ks < 8; ks++) o = mfma(lds_frag(tail, tD7 + ks, lane), bf[ks], o);
         // rows 0..2 = registers 0..2 of lane-half 0; broadcast to both halves
         float df[3];
         #pragma unroll
@@ -198,10 +240,12 @@ __global__ void __launch_bounds__(256) k_field_f16(FieldArgs P, LevelParams lp) 
         const bool oob = (u[0] < 0) | (u[0] > 1) | (u[1] < 0) | (u[1] > 1) | (u[2] < 0) | (u[2] > 1);
         #pragma unroll
         for (int li = 0; li < 8; li++) {
-            const uint32_t offset = h ? lp.offset[8 + li] : lp.offset[li];
-            const uint32_t hsize = h ? lp.hashmap_size[8 + li] : lp.hashmap_size[li];
-            const float scale = h ? lp.scale[8 + li] : lp.scale[li];
-            const uint32_t res = h ? lp.resolution[8 + li] : lp.resolution[li];
+            const uint32_t offset = h ? lv.offset[8 + li] : lv.offset[li];
+            const uint32_t s1 = h ? lv.s1[8 + li] : lv.s1[li];
+            const uint32_t s2 = h ? lv.s2[8 + li] : lv.s2[li];
+            const uint32_t hsize = h ? lv.hsize[8 + li] : lv.hsize[li];
+            const uint32_t mask = h ? lv.mask[8 + li] : lv.mask[li];
+            const float scale = h ? lv.scale[8 + li] : lv.scale[li];
             const __half2 *__restrict__ tab = reinterpret_cast<const __half2 *>(P.table) + offset;
             float pos[3];
             uint32_t pg[3];
@@ -211,19 +255,19 @@ __global__ void __launch_bounds__(256) k_field_f16(FieldArgs P, LevelParams lp) 
                 pg[d] = (uint32_t)floorf(pos[d]);
                 pos[d] -= (float)pg[d];
             }
+            const uint32_t base = oob ? 0u : pg[0] + pg[1] * s1 + pg[2] * s2;  // uint32 wrap-around as in get_grid_index
             float2 vals[8];
             float wgt[8];
             #pragma unroll
             for (uint32_t idx = 0; idx < 8; idx++) {
                 float w = 1;
-                uint32_t pgl[3];
                 #pragma unroll
-                for (uint32_t d = 0; d < 3; d++) {
-                    if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pgl[d] = pg[d]; }
-                    else { w *= pos[d]; pgl[d] = pg[d] + 1; }
-                }
+                for (uint32_t d = 0; d < 3; d++) w *= (idx & (1u << d)) ? pos[d] : 1 - pos[d];
                 wgt[idx] = w;
-                const uint32_t row = oob ? 0u : grid_index<3, 1>(1u, false, hsize, res, pgl);
+                uint32_t row = base + (idx & 1u) + ((idx & 2u) ? s1 : 0u) + ((idx & 4u) ? s2 : 0u);
+                if (mask) row &= mask;
+                else if (row >= hsize) row %= hsize;  // dense levels: never taken in range, kept for exactness
+                if (oob) row = 0;
                 vals[idx] = __half22float2(tab[row]);
             }
             float r0 = 0, r1 = 0;
@@ -245,7 +289,7 @@ __global__ void __launch_bounds__(256) k_field_f16(FieldArgs P, LevelParams lp) 
         #pragma unroll
         for (int r = 0; r < 16; r++) s0[mt][r] = 0.0f;
         #pragma unroll
-        for (int ks = 0; ks < 2; ks++) s0[mt] = mfma(ldw(W, kBlkS0 + mt * 2 + ks, lane), gf[ks], s0[mt]);
+        for (int ks = 0; ks < 2; ks++) s0[mt] = mfma(lds_frag(tail, tS0 + mt * 2 + ks, lane), gf[ks], s0[mt]);
     }
     half8 sf[4];
     acc_to_frags<true>(s0[0], sf[0], sf[1]);
@@ -254,7 +298,7 @@ __global__ void __launch_bounds__(256) k_field_f16(FieldArgs P, LevelParams lp) 
     #pragma unroll
     for (int r = 0; r < 16; r++) hv[r] = 0.0f;
     #pragma unroll
-    for (int ks = 0; ks < 4; ks++) hv = mfma(ldw(W, kBlkS1 + ks, lane), sf[ks], hv);
+    for (int ks = 0; ks < 4; ks++) hv = mfma(lds_frag(tail, tS1 + ks, lane), sf[ks], hv);
     // h[0] (lane-half 0, register 0) is the density logit; trunc_exp = exp in fp32 of the fp16 value
     const float sigma = P.density_scale * expf(round_h(hv[0]));
 
@@ -280,7 +324,7 @@ __global__ void __launch_bounds__(256) k_field_f16(FieldArgs P, LevelParams lp) 
         #pragma unroll
         for (int r = 0; r < 16; r++) c0[mt][r] = 0.0f;
         #pragma unroll
-        for (int ks = 0; ks < 2; ks++) c0[mt] = mfma(ldw(W, kBlkC0 + mt * 2 + ks, lane), cf[ks], c0[mt]);
+        for (int ks = 0; ks < 2; ks++) c0[mt] = mfma(lds_frag(tail, tC0 + mt * 2 + ks, lane), cf[ks], c0[mt]);
     }
     half8 c1f[4];
     acc_to_frags<true>(c0[0], c1f[0], c1f[1]);
@@ -291,7 +335,7 @@ __global__ void __launch_bounds__(256) k_field_f16(FieldArgs P, LevelParams lp) 
         #pragma unroll
         for (int r = 0; r < 16; r++) c1[mt][r] = 0.0f;
         #pragma unroll
-        for (int ks = 0; ks < 4; ks++) c1[mt] = mfma(ldw(W, kBlkC1 + mt * 4 + ks, lane), c1f[ks], c1[mt]);
+        for (int ks = 0; ks < 4; ks++) c1[mt] = mfma(lds_frag(tail, tC1 + mt * 4 + ks, lane), c1f[ks], c1[mt]);
     }
     half8 c2f[4];
     acc_to_frags<true>(c1[0], c2f[0], c2f[1]);
@@ -300,7 +344,7 @@ __global__ void __launch_bounds__(256) k_field_f16(FieldArgs P, LevelParams lp) 
     #pragma unroll
     for (int r = 0; r < 16; r++) co[r] = 0.0f;
     #pragma unroll
-    for (int ks = 0; ks < 4; ks++) co = mfma(ldw(W, kBlkC2 + ks, lane), c2f[ks], co);
+    for (int ks = 0; ks < 4; ks++) co = mfma(lds_frag(tail, tC2 + ks, lane), c2f[ks], co);
 
     if (h == 0 && valid) {
         P.sigmas[p] = sigma;
@@ -310,6 +354,29 @@ __global__ void __launch_bounds__(256) k_field_f16(FieldArgs P, LevelParams lp) 
             P.rgbs[(size_t)p * 3 + c] = round_h(1.0f / (1.0f + expf(-logit)));  // torch.sigmoid on fp16: fp32 math, fp16 result
         }
     }
+}
+
+int fill_tiled_levels(TiledLevels &lv, const int32_t *offsets_host, float S, uint32_t H) {
+    for (uint32_t l = 0; l < 16; l++) {
+        const uint32_t hsize = (uint32_t)(offsets_host[l + 1] - offsets_host[l]);
+        if (hsize == 0) return SDN_E_BADARG;
+        const float scale = exp2f((float)l * S) * (float)H - 1.0f;  // gridencoder.cu:138
+        const uint32_t res = (uint32_t)ceil((double)scale) + 1;      // gridencoder.cu:139
+        // get_grid_index (gridencoder.cu:66-84) for D = 3, align_corners = false, gridtype = tiled:
+        //   stride = 1; for d: if (stride <= hsize) { index += pos[d] * stride; stride *= res + 1; }
+        uint32_t stride = 1, s[3] = {0, 0, 0};
+        for (int d = 0; d < 3; d++) {
+            if (stride <= hsize) { s[d] = stride; stride *= (res + 1); }
+        }
+        if (s[0] != 1) return SDN_E_BADARG;
+        lv.offset[l] = (uint32_t)offsets_host[l];
+        lv.s1[l] = s[1];
+        lv.s2[l] = s[2];
+        lv.hsize[l] = hsize;
+        lv.mask[l] = (hsize & (hsize - 1)) == 0 ? hsize - 1 : 0;
+        lv.scale[l] = scale;
+    }
+    return 0;
 }
 
 }  // namespace
@@ -326,16 +393,15 @@ int sdn_field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *
     if (M == 0) return 0;
     if (!xyzs || !dirs || !weights || !bias0 || !table || !offsets_host || !sigmas || !rgbs) return SDN_E_BADARG;
     if ((live_idx == nullptr) != (live_count == nullptr)) return SDN_E_BADARG;
-    if (((uintptr_t)weights & 15u) != 0) return SDN_E_BADARG;
-    LevelParams lp;
-    int rc = fill_levels(lp, offsets_host, 16, S, H);
+    if (((uintptr_t)weights & 15u) != 0 || ((uintptr_t)table & 3u) != 0) return SDN_E_BADARG;
+    TiledLevels lv;
+    int rc = fill_tiled_levels(lv, offsets_host, S, H);
     if (rc) return rc;
     FieldArgs a;
     a.xyzs = xyzs; a.dirs = dirs; a.live_idx = live_idx; a.live_count = live_count; a.M = M;
-    a.weights = (const half8 *)weights; a.bias0 = bias0; a.table = (const __half *)table;
+    a.weights = (const unsigned char *)weights; a.bias0 = bias0; a.table = (const __half *)table;
     a.sigmas = sigmas; a.rgbs = rgbs; a.bound = bound; a.density_scale = density_scale; a.zero_deform = zero_deform;
-    const uint32_t waves = sdn_div_up(M, 32u);
-    hipLaunchKernelGGL(k_field_f16, dim3(sdn_div_up(waves, 4u)), dim3(256), 0, (hipStream_t)stream, a, lp);
+    hipLaunchKernelGGL(k_field_f16, dim3(sdn_div_up(M, 128u)), dim3(256), 0, (hipStream_t)stream, a, lv);
     return sdn_launch_status();
 }
 
