@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--size", type=int, default=800, help="image side (800 = BASELINE config)")
     ap.add_argument("--fp32", action="store_true", help="fp32 field network instead of the -O (fp16) configuration")
     ap.add_argument("--field", default="auto", choices=["auto", "ops", "fused"], help="field network implementation")
+    ap.add_argument("--loop", default="auto", choices=["auto", "host", "device"], help="loop driver: per-iteration host sync, or device-driven")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-side", type=int, default=96, help="side of the CPU-baseline sample image")
     return ap.parse_args()
@@ -83,18 +84,28 @@ def main():
     field = fused.FusedField(sc.model, sc.time, fp16=fp16) if field_kind == "fused" else None
     import sdn_backend
     timers = sdn_backend.KernelTimers()
+    loop_kind = args.loop
+    if loop_kind == "auto":
+        loop_kind = "device" if field is not None else "host"
+    dloop = None
+    if loop_kind == "device":
+        from dnerf_amd.renderer import DeviceLoop
+        dloop = DeviceLoop(sc.model, field, n_local, dev)
 
     def step(count=False, timed=False):
         sdn_backend.timers = timers if timed else None  # HIP events around the tracked launches, timed steps only
-        out = render_frame(sc.model, rays_o, rays_d, sc.time, fp16=fp16, workspace=ws, field=field, count_samples=count)
+        if dloop is not None:
+            out = dloop.render(rays_o, rays_d, sc.time, want_stats=count)
+        else:
+            out = render_frame(sc.model, rays_o, rays_d, sc.time, fp16=fp16, workspace=ws, field=field, count_samples=count)
         sdn_backend.timers = None
         if world > 1:
             gather(out["image"], out["depth"])  # one RCCL all-gather per frame + local un-permute
         return out
 
     # untimed: sample count of this rank's shard (deterministic), then warm-up
-    n_samples_local = step(count=True)["n_samples"]
-    n_iters = len(step()["trace"])
+    first = step(count=True)
+    n_samples_local, n_iters = first["n_samples"], len(first["trace"])
     for _ in range(args.warmup):
         step()
 
@@ -131,10 +142,10 @@ def main():
                                f"{'-O (fp16 field network, fp16 grid table)' if fp16 else 'fp32'}, 1 timestep (t=0.5), "
                                f"T_thresh 1e-2, max_steps 1024, dt_gamma 0",
                    "rays": n_total, "sampled_points_per_frame": n_samples, "loop_iterations": n_iters,
-                   "field": field_kind, "parallelism": f"ray-tiles x{world}" if world > 1 else "single GPU"},
+                   "field": field_kind, "loop": loop_kind, "parallelism": f"ray-tiles x{world}" if world > 1 else "single GPU"},
     }
     if rank == 0:
-        result["roofline"], result["kernel_times"] = roofline(timers, fp16, n_samples_local, n_iters)
+        result["roofline"], result["kernel_times"] = roofline(timers, fp16, n_samples_local, n_iters, args.steps)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sc, args.cpu_baseline_side)
         print(json.dumps(result))
@@ -142,7 +153,7 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline(timers, fp16, n_samples, n_iters):
+def roofline(timers, fp16, n_samples, n_iters, steps):
     """Roofline entry of the dominant TRACKED kernel: achieved = algorithmic bytes (or flops) per launch / average launch
     duration, both from the HIP events recorded around the launches inside the timed region.  The fused field kernel
     evaluates only the live samples of each iteration (device-side list), so its units per launch are the frame's sampled
@@ -151,8 +162,11 @@ def roofline(timers, fp16, n_samples, n_iters):
     if not summ:
         return None, {}
     if "field_forward_f16" in summ:
-        summ["field_forward_f16"]["avg_units"] = n_samples / max(n_iters, 1)
-        summ["field_forward_f16"]["units"] = int(summ["field_forward_f16"]["avg_units"] * summ["field_forward_f16"]["launches"])
+        # every timed frame evaluates n_samples points in total; the device-driven loop also launches (and times) one trailing
+        # no-op iteration per frame, which is counted as a launch with zero units
+        f = summ["field_forward_f16"]
+        f["units"] = int(n_samples * steps)
+        f["avg_units"] = f["units"] / f["launches"]
     name = max(summ, key=lambda k: summ[k]["total_ms"])
     s = summ[name]
     if name.startswith("grid_encode_fwd"):

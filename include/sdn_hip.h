@@ -190,6 +190,47 @@ int sdn_field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *
                           const int32_t *offsets_host, float S, uint32_t H, float bound, float density_scale,
                           int zero_deform, float *sigmas, float *rgbs, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * device-driven inference loop for one frame  (reference: the Python loop dnerf/renderer.py:333-381)
+ * ------------------------------------------------------------------------- */
+/* All pointers are device pointers owned by the caller except grid_offsets (17 host ints, copied by value).
+ * Buffer sizes: per-ray arrays N; sample arrays M_cap >= N + 128 rows; live_counts n_counters >= max_steps + 8;
+ * trace 2 * n_counters; block_totals ceil(N / 1024) + 1; cull_bits sdn_cull_grid_bytes(); state 8 ints. */
+typedef struct SdnRenderCtx {
+    const float *rays_o, *rays_d, *nears, *fars;
+    const uint8_t *bitfield;
+    void *cull_bits;
+    int32_t *alive_a, *alive_b;
+    float *rays_t, *weights_sum, *depth, *image;
+    float *xyzs, *dirs, *deltas, *sigmas, *rgbs;
+    uint32_t *live_idx;
+    int32_t *live_counts, *state, *trace, *n_out;
+    void *block_totals;
+    const void *field_weights;
+    const float *field_bias0;
+    const void *grid_table;
+    int32_t grid_offsets[17];
+    float grid_S;
+    uint32_t grid_H;
+    uint32_t N, M_cap, n_counters, max_steps, C, H;
+    float bound, dt_gamma, T_thresh, density_scale;
+    int32_t zero_deform;
+} SdnRenderCtx;
+
+/* Resets per-ray state (alive = 0..N-1, rays_t = nears, accumulators = 0), the loop record and the counters, and builds
+ * the cull grid of `bitfield`. */
+int sdn_render_begin(const SdnRenderCtx *ctx, void *stream);
+/* Enqueues one loop iteration (march -> fused field -> composite -> compact -> advance).  bound_alive: any upper bound of
+ * the current number of alive rays (N is always valid; tighter bounds launch fewer idle workgroups).  The record is
+ * state = {n_alive, n_step, steps done, iteration, side, N, max_steps, -}; an iteration with n_alive == 0 is a no-op. */
+int sdn_render_step_f16(const SdnRenderCtx *ctx, uint32_t bound_alive, void *stream);
+/* Same, recording the two given hipEvent_t (may be NULL) on `stream` immediately before / after the fused-field launch, so
+ * a caller can time the dominant kernel in place (bench.py's roofline). */
+int sdn_render_step_f16_ev(const SdnRenderCtx *ctx, uint32_t bound_alive, void *ev_field_begin, void *ev_field_end,
+                           void *stream);
+/* image_out [N,3] = image + (1 - weights_sum) * bg; depth_out [N] = clamp(depth - nears, 0) / (fars - nears). */
+int sdn_render_finish(const SdnRenderCtx *ctx, float bg_color, float *image_out, float *depth_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,7 +60,7 @@ struct TiledLevels {
     uint32_t s1[16];      // row stride of +1 in y (0 if the dimension is dropped: stride > rows)
     uint32_t s2[16];      // row stride of +1 in z (0 if dropped)
     uint32_t hsize[16];   // rows in the level
-    uint32_t mask[16];    // hsize - 1 if hsize is a power of two, else 0
+    uint32_t mask[16];    // hsize - 1 if hsize is a power of two (wrapping level), else 0xFFFFFFFF (dense level)
     float scale[16];
 };
 
@@ -69,6 +69,7 @@ struct FieldArgs {
     const float *dirs;        // [M,3]
     const uint32_t *live_idx; // [<=M] slot indices to evaluate, or nullptr = all M slots
     const uint32_t *live_count;
+    const int32_t *state;     // device-driven loop: the count is live_count[state[3]] (one counter per iteration), else nullptr
     uint32_t M;
     const unsigned char *weights;  // kBlkTotal KiB, fragment order
     const float *bias0;       // [128] time-encoding contribution to the first deform layer
@@ -130,7 +131,7 @@ __device__ __forceinline__ half8 lds_frag(const unsigned char *buf, int blk, uin
 __global__ void __launch_bounds__(256, 2) k_field_f16(FieldArgs P, TiledLevels lv) {
     __shared__ __attribute__((aligned(16))) unsigned char s_w[2][kStageBytes];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t count = P.live_idx ? *P.live_count : P.M;
+    const uint32_t count = P.state ? P.live_count[P.state[3]] : (P.live_idx ? *P.live_count : P.M);
     if (blockIdx.x * 128u >= count) return;  // workgroup-uniform: nothing to do, no barrier touched
     const uint32_t n = lane & 31u, h = lane >> 5;
     const uint32_t i = blockIdx.x * 128u + wave * 32u + n;
@@ -264,10 +265,11 @@ __global__ void __launch_bounds__(256, 2) k_field_f16(FieldArgs P, TiledLevels l
                 #pragma unroll
                 for (uint32_t d = 0; d < 3; d++) w *= (idx & (1u << d)) ? pos[d] : 1 - pos[d];
                 wgt[idx] = w;
+                // `index % hashmap_size` of get_grid_index without a division and without a branch (a branch per corner would
+                // serialise the eight gathers): capped levels have a power-of-two row count (AND); dense levels hold every
+                // (res+1)^3 corner, so an in-range point never wraps -- the min() only guards memory safety.
                 uint32_t row = base + (idx & 1u) + ((idx & 2u) ? s1 : 0u) + ((idx & 4u) ? s2 : 0u);
-                if (mask) row &= mask;
-                else if (row >= hsize) row %= hsize;  // dense levels: never taken in range, kept for exactness
-                if (oob) row = 0;
+                row = min(row & mask, hsize - 1u);
                 vals[idx] = __half22float2(tab[row]);
             }
             float r0 = 0, r1 = 0;
@@ -373,13 +375,35 @@ int fill_tiled_levels(TiledLevels &lv, const int32_t *offsets_host, float S, uin
         lv.s1[l] = s[1];
         lv.s2[l] = s[2];
         lv.hsize[l] = hsize;
-        lv.mask[l] = (hsize & (hsize - 1)) == 0 ? hsize - 1 : 0;
+        const bool pow2 = (hsize & (hsize - 1)) == 0;
+        // a non-power-of-two level must be dense (every corner has its own row), otherwise the AND/min form would be wrong
+        if (!pow2 && (s[1] == 0 || s[2] == 0 || (uint64_t)(res + 1) * (res + 1) * (res + 1) > hsize)) return SDN_E_UNSUPPORTED;
+        lv.mask[l] = pow2 ? hsize - 1 : 0xFFFFFFFFu;
         lv.scale[l] = scale;
     }
     return 0;
 }
 
 }  // namespace
+
+namespace sdn_int {
+
+// launch used by both the C entry point and the device-driven render loop (render.hip)
+int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count, const int32_t *state,
+                      uint32_t M, const void *weights, const float *bias0, const void *table, const int32_t *offsets_host, float S,
+                      uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, hipStream_t st) {
+    TiledLevels lv;
+    int rc = fill_tiled_levels(lv, offsets_host, S, H);
+    if (rc) return rc;
+    FieldArgs a;
+    a.xyzs = xyzs; a.dirs = dirs; a.live_idx = live_idx; a.live_count = live_count; a.state = state; a.M = M;
+    a.weights = (const unsigned char *)weights; a.bias0 = bias0; a.table = (const __half *)table;
+    a.sigmas = sigmas; a.rgbs = rgbs; a.bound = bound; a.density_scale = density_scale; a.zero_deform = zero_deform;
+    hipLaunchKernelGGL(k_field_f16, dim3(sdn_div_up(M, 128u)), dim3(256), 0, st, a, lv);
+    return sdn_launch_status();
+}
+
+}  // namespace sdn_int
 
 extern "C" {
 
@@ -394,15 +418,8 @@ int sdn_field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *
     if (!xyzs || !dirs || !weights || !bias0 || !table || !offsets_host || !sigmas || !rgbs) return SDN_E_BADARG;
     if ((live_idx == nullptr) != (live_count == nullptr)) return SDN_E_BADARG;
     if (((uintptr_t)weights & 15u) != 0 || ((uintptr_t)table & 3u) != 0) return SDN_E_BADARG;
-    TiledLevels lv;
-    int rc = fill_tiled_levels(lv, offsets_host, S, H);
-    if (rc) return rc;
-    FieldArgs a;
-    a.xyzs = xyzs; a.dirs = dirs; a.live_idx = live_idx; a.live_count = live_count; a.M = M;
-    a.weights = (const unsigned char *)weights; a.bias0 = bias0; a.table = (const __half *)table;
-    a.sigmas = sigmas; a.rgbs = rgbs; a.bound = bound; a.density_scale = density_scale; a.zero_deform = zero_deform;
-    hipLaunchKernelGGL(k_field_f16, dim3(sdn_div_up(M, 128u)), dim3(256), 0, (hipStream_t)stream, a, lv);
-    return sdn_launch_status();
+    return sdn_int::field_forward_f16(xyzs, dirs, live_idx, live_count, nullptr, M, weights, bias0, table, offsets_host, S, H, bound,
+                                      density_scale, zero_deform, sigmas, rgbs, (hipStream_t)stream);
 }
 
 }  // extern "C"

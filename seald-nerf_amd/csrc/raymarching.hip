@@ -514,7 +514,17 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
                                                     const float *__restrict__ fars, float *__restrict__ xyzs, float *__restrict__ dirs,
                                                     float *__restrict__ deltas, const float *__restrict__ noises, uint32_t M_pad,
                                                     const uint32_t *__restrict__ cull, uint32_t *__restrict__ live_idx,
-                                                    uint32_t *__restrict__ live_count) {
+                                                    uint32_t *__restrict__ live_count, const int32_t *__restrict__ state,
+                                                    const int32_t *__restrict__ rays_alive_b) {
+    if (state) {  // device-driven loop: sizes, ping-pong side and the iteration's live counter come from the loop state
+        n_alive = (uint32_t)state[0];
+        n_step = (uint32_t)state[1];
+        if (n_alive == 0) return;
+        if (state[4]) rays_alive = rays_alive_b;
+        live_count += state[3];
+        const uint32_t m0 = n_alive * n_step;
+        M_pad = m0 + (128u - m0 % 128u);
+    }
     __shared__ uint4 s_cull4[FAST ? 256 : 1];  // 32^3 bits = 4 KiB
     const uint32_t *s_cull = nullptr;
     if constexpr (FAST) {
@@ -587,7 +597,13 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
 __global__ void __launch_bounds__(256) k_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *__restrict__ rays_alive,
                                                         float *__restrict__ rays_t, const float *__restrict__ sigmas,
                                                         const float *__restrict__ rgbs, const float *__restrict__ deltas,
-                                                        float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image) {
+                                                        float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image,
+                                                        const int32_t *__restrict__ state, int32_t *__restrict__ rays_alive_b) {
+    if (state) {
+        n_alive = (uint32_t)state[0];
+        n_step = (uint32_t)state[1];
+        if (state[4]) rays_alive = rays_alive_b;
+    }
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
     if (n >= n_alive) return;
     const int index = rays_alive[n];
@@ -618,7 +634,13 @@ __global__ void __launch_bounds__(256) k_composite_rays(uint32_t n_alive, uint32
 // stable compaction of rays_alive >= 0 (replaces the torch mask-select of dnerf/renderer.py:372)
 // two launches: per-block survivor counts (wave ballot + popcount), then scatter.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(kScanBlock) k_compact_count(const int32_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ block_totals) {
+__global__ void __launch_bounds__(kScanBlock) k_compact_count(const int32_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ block_totals,
+                                                              const int32_t *__restrict__ state, const int32_t *__restrict__ in_b) {
+    if (state) {
+        n = (uint32_t)state[0];
+        if (state[4]) in = in_b;
+        if (blockIdx.x * kScanBlock >= n) return;  // workgroup-uniform
+    }
     __shared__ uint32_t lds[16];
     const uint32_t i = blockIdx.x * kScanBlock + threadIdx.x;
     const bool keep = i < n && in[i] >= 0;
@@ -633,7 +655,20 @@ __global__ void __launch_bounds__(kScanBlock) k_compact_count(const int32_t *__r
 }
 
 __global__ void __launch_bounds__(kScanBlock) k_compact_scatter(const int32_t *__restrict__ in, uint32_t n, const uint32_t *__restrict__ block_totals,
-                                                                int32_t *__restrict__ out, int32_t *__restrict__ n_out) {
+                                                                int32_t *__restrict__ out, int32_t *__restrict__ n_out,
+                                                                const int32_t *__restrict__ state, const int32_t *__restrict__ in_b,
+                                                                int32_t *__restrict__ out_b) {
+    uint32_t last_block = gridDim.x - 1;
+    if (state) {
+        n = (uint32_t)state[0];
+        if (state[4]) { in = in_b; out = out_b; }
+        if (n == 0) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) n_out[0] = 0;
+            return;
+        }
+        last_block = (n - 1) / kScanBlock;
+        if (blockIdx.x > last_block) return;  // workgroup-uniform
+    }
     __shared__ uint32_t lds[16];
     __shared__ uint32_t s_prev;
     uint32_t part = 0;
@@ -657,9 +692,123 @@ __global__ void __launch_bounds__(kScanBlock) k_compact_scatter(const int32_t *_
         total += c;
     }
     if (keep) out[s_prev + carry + below] = v;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) n_out[0] = (int32_t)(s_prev + total);
+    if (blockIdx.x == last_block && threadIdx.x == 0) n_out[0] = (int32_t)(s_prev + total);
 }
 
+
+// ---------------------------------------------------------------------------
+// device-driven inference loop (dnerf/renderer.py:340-381 without a host round trip per iteration)
+// state: [0] n_alive  [1] n_step  [2] steps done  [3] iteration  [4] ping-pong side  [5] N  [6] max_steps  [7] -
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_loop_init(uint32_t N, uint32_t max_steps, const float *__restrict__ nears, int32_t *__restrict__ alive_a,
+                                                   float *__restrict__ rays_t, float *__restrict__ weights_sum, float *__restrict__ depth,
+                                                   float *__restrict__ image, int32_t *__restrict__ state, int32_t *__restrict__ live_counts,
+                                                   uint32_t n_counters) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n < N) {
+        alive_a[n] = (int32_t)n;
+        rays_t[n] = nears[n];
+        weights_sum[n] = 0; depth[n] = 0;
+        image[(size_t)n * 3] = 0; image[(size_t)n * 3 + 1] = 0; image[(size_t)n * 3 + 2] = 0;
+    }
+    if (n < n_counters) live_counts[n] = 0;
+    if (n == 0) {
+        state[0] = (int32_t)N; state[1] = 1; state[2] = 0; state[3] = 0; state[4] = 0;
+        state[5] = (int32_t)N; state[6] = (int32_t)max_steps; state[7] = 0;
+    }
+}
+
+__global__ void k_loop_advance(int32_t *__restrict__ state, const int32_t *__restrict__ n_out, int32_t *__restrict__ trace) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int32_t it = state[3];
+    if (state[0] > 0) {  // log only iterations that did work: (n_alive, n_step)
+        trace[2 * it] = state[0];
+        trace[2 * it + 1] = state[1];
+        state[2] += state[1];
+        state[3] = it + 1;
+        state[4] ^= 1;
+        int32_t n_new = n_out[0];
+        if (state[2] >= state[6]) n_new = 0;  // `while step < max_steps`
+        state[0] = n_new;
+        if (n_new > 0) {
+            int32_t ns = state[5] / n_new;  // n_step = max(min(N // n_alive, 8), 1)
+            state[1] = ns > 8 ? 8 : (ns < 1 ? 1 : ns);
+        }
+    }
+}
+
+// image = image + (1 - weights_sum) * bg ; depth = clamp(depth - nears, 0) / (fars - nears)   (dnerf/renderer.py:378-379)
+__global__ void __launch_bounds__(256) k_loop_finish(uint32_t N, const float *__restrict__ nears, const float *__restrict__ fars,
+                                                     const float *__restrict__ weights_sum, const float *__restrict__ depth,
+                                                     const float *__restrict__ image, float bg, float *__restrict__ image_out,
+                                                     float *__restrict__ depth_out) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const float w = (1 - weights_sum[n]) * bg;
+    image_out[(size_t)n * 3] = image[(size_t)n * 3] + w;
+    image_out[(size_t)n * 3 + 1] = image[(size_t)n * 3 + 1] + w;
+    image_out[(size_t)n * 3 + 2] = image[(size_t)n * 3 + 2] + w;
+    depth_out[n] = fmaxf(depth[n] - nears[n], 0.0f) / (fars[n] - nears[n]);
+}
+
+}  // namespace
+
+namespace sdn_int {
+
+int loop_begin(uint32_t N, uint32_t max_steps, const float *nears, int32_t *alive_a, float *rays_t, float *weights_sum, float *depth,
+               float *image, int32_t *state, int32_t *live_counts, uint32_t n_counters, hipStream_t st) {
+    const uint32_t threads = N > n_counters ? N : n_counters;
+    hipLaunchKernelGGL(k_loop_init, dim3(sdn_div_up(threads, 256u)), dim3(256), 0, st, N, max_steps, nears, alive_a, rays_t, weights_sum, depth,
+                       image, state, live_counts, n_counters);
+    return sdn_launch_status();
+}
+
+int loop_march(uint32_t bound_alive, const int32_t *alive_a, const int32_t *alive_b, const float *rays_t, const float *rays_o,
+               const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
+               const float *fars, float *xyzs, float *dirs, float *deltas, const uint32_t *cull, uint32_t *live_idx,
+               uint32_t *live_counts, const int32_t *state, hipStream_t st) {
+    const dim3 g(sdn_div_up(bound_alive + 128u, 256u)), b(256);
+    if (fast_config(bound, C, H)) {
+        if (cull && H != 128) cull = nullptr;
+        hipLaunchKernelGGL(k_march_rays<true>, g, b, 0, st, 0u, 0u, alive_a, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars,
+                           xyzs, dirs, deltas, (const float *)nullptr, 0u, cull, live_idx, live_counts, state, alive_b);
+    } else {
+        hipLaunchKernelGGL(k_march_rays<false>, g, b, 0, st, 0u, 0u, alive_a, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars,
+                           xyzs, dirs, deltas, (const float *)nullptr, 0u, (const uint32_t *)nullptr, live_idx, live_counts, state, alive_b);
+    }
+    return sdn_launch_status();
+}
+
+int loop_composite_compact(uint32_t bound_alive, float T_thresh, int32_t *alive_a, int32_t *alive_b, float *rays_t, const float *sigmas,
+                           const float *rgbs, const float *deltas, float *weights_sum, float *depth, float *image, int32_t *state,
+                           uint32_t *block_totals, int32_t *n_out, int32_t *trace, hipStream_t st) {
+    hipLaunchKernelGGL(k_composite_rays, dim3(sdn_div_up(bound_alive, 256u)), dim3(256), 0, st, 0u, 0u, T_thresh, alive_a, rays_t, sigmas, rgbs,
+                       deltas, weights_sum, depth, image, (const int32_t *)state, alive_b);
+    const uint32_t nb = sdn_div_up(bound_alive, kScanBlock);
+    hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(kScanBlock), 0, st, (const int32_t *)alive_a, 0u, block_totals, (const int32_t *)state,
+                       (const int32_t *)alive_b);
+    // side 0: in = a, out = b; side 1: in = b, out = a
+    hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(kScanBlock), 0, st, (const int32_t *)alive_a, 0u, (const uint32_t *)block_totals, alive_b,
+                       n_out, (const int32_t *)state, (const int32_t *)alive_b, alive_a);
+    hipLaunchKernelGGL(k_loop_advance, dim3(1), dim3(64), 0, st, state, (const int32_t *)n_out, trace);
+    return sdn_launch_status();
+}
+
+int loop_finish(uint32_t N, const float *nears, const float *fars, const float *weights_sum, const float *depth, const float *image, float bg,
+                float *image_out, float *depth_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_loop_finish, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, N, nears, fars, weights_sum, depth, image, bg, image_out,
+                       depth_out);
+    return sdn_launch_status();
+}
+
+int build_cull(const uint8_t *bitfield, uint32_t *cull_bits, hipStream_t st) {
+    hipLaunchKernelGGL(k_build_cull_grid, dim3(kCullRes * kCullRes * kCullRes / 256), dim3(256), 0, st, bitfield, cull_bits);
+    return sdn_launch_status();
+}
+
+}  // namespace sdn_int
+
+namespace {
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -776,10 +925,12 @@ static int launch_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *r
     if (fast_config(bound, C, H)) {
         if (cull && H != 128) cull = nullptr;  // the cull grid is built for the 128^3 grid only
         hipLaunchKernelGGL(k_march_rays<true>, g, b, 0, st, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
-                           grid, fars, xyzs, dirs, deltas, noises, M_pad, cull, live_idx, live_count);
+                           grid, fars, xyzs, dirs, deltas, noises, M_pad, cull, live_idx, live_count, (const int32_t *)nullptr,
+                           (const int32_t *)nullptr);
     } else {
         hipLaunchKernelGGL(k_march_rays<false>, g, b, 0, st, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
-                           grid, fars, xyzs, dirs, deltas, noises, M_pad, (const uint32_t *)nullptr, live_idx, live_count);
+                           grid, fars, xyzs, dirs, deltas, noises, M_pad, (const uint32_t *)nullptr, live_idx, live_count,
+                           (const int32_t *)nullptr, (const int32_t *)nullptr);
     }
     return sdn_launch_status();
 }
@@ -817,7 +968,7 @@ int sdn_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_
     if (n_alive == 0 || n_step == 0) return 0;
     if (!rays_alive || !rays_t || !sigmas || !rgbs || !deltas || !weights_sum || !depth || !image) return SDN_E_BADARG;
     hipLaunchKernelGGL(k_composite_rays, dim3(sdn_div_up(n_alive, 256u)), dim3(256), 0, (hipStream_t)stream, n_alive, n_step, T_thresh,
-                       rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+                       rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, (const int32_t *)nullptr, (int32_t *)nullptr);
     return sdn_launch_status();
 }
 
@@ -829,8 +980,10 @@ int sdn_compact_alive(const int32_t *in, uint32_t n, int32_t *out, int32_t *n_ou
     if (n == 0) return (int)hipMemsetAsync(n_out, 0, sizeof(int32_t), st);
     if (!in || !out || !scratch) return SDN_E_BADARG;
     const uint32_t nb = sdn_div_up(n, kScanBlock);
-    hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(kScanBlock), 0, st, in, n, (uint32_t *)scratch);
-    hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(kScanBlock), 0, st, in, n, (const uint32_t *)scratch, out, n_out);
+    hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(kScanBlock), 0, st, in, n, (uint32_t *)scratch, (const int32_t *)nullptr,
+                       (const int32_t *)nullptr);
+    hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(kScanBlock), 0, st, in, n, (const uint32_t *)scratch, out, n_out,
+                       (const int32_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr);
     return sdn_launch_status();
 }
 

@@ -399,3 +399,89 @@ def _field_eval(model, time, fp16):
             sigmas, rgbs, _ = model(xyzs, dirs, time)
         return (model.density_scale * sigmas).float().contiguous(), rgbs.float().contiguous()
     return run
+
+
+# ==================================================================================================
+# device-driven loop (csrc/render.hip): no host round trip inside an iteration
+# ==================================================================================================
+class DeviceLoop:
+    """Owns the buffers and the `SdnRenderCtx` of the device-driven inference loop for frames of N rays.
+
+    The host enqueues iteration k+1 while iteration k runs; grids are sized with the survivor count read back (async,
+    pinned memory) one iteration earlier, which is an upper bound of the current one.  Requires the fused field."""
+
+    RING = 4
+
+    def __init__(self, model, field, N, device, max_steps=1024, T_thresh=1e-2, dt_gamma=0.0):
+        import ctypes
+        from sdn_backend import lib, SdnRenderCtx
+        f32, i32 = torch.float32, torch.int32
+        self.model, self.field, self.N = model, field, N
+        M = N + 128 + 8 * 128
+        n_counters = max_steps + 8
+        z = lambda *shape, dt=f32: torch.empty(*shape, dtype=dt, device=device)  # noqa: E731
+        self.buf = dict(alive_a=z(N, dt=i32), alive_b=z(N, dt=i32), rays_t=z(N), weights_sum=z(N), depth=z(N), image=z(N, 3),
+                        xyzs=z(M, 3), dirs=z(M, 3), deltas=z(M, 2), sigmas=z(M), rgbs=z(M, 3), live_idx=z(M, dt=i32),
+                        live_counts=torch.zeros(n_counters, dtype=i32, device=device), state=torch.zeros(8, dtype=i32, device=device),
+                        trace=torch.zeros(2 * n_counters, dtype=i32, device=device), n_out=torch.zeros(1, dtype=i32, device=device),
+                        block_totals=z((N + 1023) // 1024 + 1, dt=i32),
+                        cull_bits=torch.empty(int(lib.sdn_cull_grid_bytes()), dtype=torch.uint8, device=device))
+        self.image_out, self.depth_out = z(N, 3), z(N)
+        self.host_state = torch.zeros(self.RING, 8, dtype=i32).pin_memory()
+        self.events = [torch.cuda.Event() for _ in range(self.RING)]
+        c = SdnRenderCtx()
+        for k, v in self.buf.items():
+            setattr(c, k, v.data_ptr())
+        c.field_weights, c.field_bias0, c.grid_table = field.weights.data_ptr(), field.bias0.data_ptr(), field.table.data_ptr()
+        c.grid_offsets = (ctypes.c_int32 * 17)(*[int(v) for v in field.offsets_host])
+        c.grid_S, c.grid_H = field.S, field.H
+        c.N, c.M_cap, c.n_counters, c.max_steps, c.C, c.H = N, M, n_counters, int(max_steps), int(model.cascade), int(model.grid_size)
+        c.bound, c.dt_gamma, c.T_thresh, c.density_scale = float(model.bound), float(dt_gamma), float(T_thresh), float(model.density_scale)
+        self.ctx = c
+        self.max_steps = int(max_steps)
+
+    @torch.no_grad()
+    def render(self, rays_o, rays_d, time, bg_color=1.0, want_stats=True):
+        import ctypes
+        from sdn_backend import lib, check, ptr, stream
+        import sdn_backend
+        c, model = self.ctx, self.model
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        assert rays_o.shape[0] == self.N
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, model.aabb_infer, model.min_near)
+        bitfield = model.density_bitfield[model.time_slice(time)]
+        c.rays_o, c.rays_d, c.nears, c.fars, c.bitfield = ptr(rays_o), ptr(rays_d), ptr(nears), ptr(fars), ptr(bitfield)
+        c.field_bias0, c.zero_deform = self.field.bias0.data_ptr(), int(self.field.zero_deform)
+        st = stream()
+        cref = ctypes.byref(c)
+        check(lib.sdn_render_begin(cref, st), "render_begin")
+        bound, it = self.N, 0
+        cur = torch.cuda.current_stream()
+        while True:
+            if sdn_backend.timers is not None:  # bench: time the fused-field launch in place
+                e0, e1 = sdn_backend.timers.raw_pair("field_forward_f16", 0)
+                check(lib.sdn_render_step_f16_ev(cref, bound, e0, e1, st), "render_step_f16")
+            else:
+                check(lib.sdn_render_step_f16(cref, bound, st), "render_step_f16")
+            slot = it % self.RING
+            self.host_state[slot].copy_(self.buf["state"], non_blocking=True)
+            self.events[slot].record(cur)
+            if it >= 1:
+                prev = (it - 1) % self.RING
+                self.events[prev].synchronize()
+                n_prev = int(self.host_state[prev][0])  # alive rays entering iteration `it` (already enqueued)
+                if n_prev == 0:
+                    break
+                bound = n_prev
+            it += 1
+            if it > self.max_steps + 1:
+                break
+        check(lib.sdn_render_finish(cref, float(bg_color), ptr(self.image_out), ptr(self.depth_out), st), "render_finish")
+        out = {"image": self.image_out, "depth": self.depth_out, "weights_sum": self.buf["weights_sum"], "nears": nears, "fars": fars}
+        if want_stats:
+            iters = int(self.buf["state"][3].item())
+            tr = self.buf["trace"][: 2 * iters].cpu().view(-1, 2).tolist()
+            out["trace"] = [(a, s, a * s + (128 - (a * s) % 128)) for a, s in tr]
+            out["n_samples"] = int(self.buf["live_counts"][:iters].sum().item())
+        return out

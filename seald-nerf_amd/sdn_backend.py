@@ -39,8 +39,24 @@ PROTOTYPES = {
     "sdn_sh_encode_backward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp],
     "sdn_freq_encode_forward": [_vp, _u32, _u32, _u32, _u32, _vp, _vp],
     "sdn_freq_encode_backward": [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp],
+    "sdn_render_begin": [_vp, _vp],
+    "sdn_render_step_f16": [_vp, _u32, _vp],
+    "sdn_render_step_f16_ev": [_vp, _u32, _vp, _vp, _vp],
+    "sdn_render_finish": [_vp, _f32, _vp, _vp, _vp],
     "sdn_field_forward_f16": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _f32, _u32, _f32, _f32, _i32, _vp, _vp, _vp],
 }
+class SdnRenderCtx(ctypes.Structure):
+    """Mirror of `SdnRenderCtx` in include/sdn_hip.h (field order and types must match)."""
+    _fields_ = ([(n, _vp) for n in ("rays_o", "rays_d", "nears", "fars", "bitfield", "cull_bits", "alive_a", "alive_b", "rays_t",
+                                   "weights_sum", "depth", "image", "xyzs", "dirs", "deltas", "sigmas", "rgbs", "live_idx",
+                                   "live_counts", "state", "trace", "n_out", "block_totals", "field_weights", "field_bias0",
+                                   "grid_table")]
+                + [("grid_offsets", ctypes.c_int32 * 17), ("grid_S", _f32), ("grid_H", _u32)]
+                + [(n, _u32) for n in ("N", "M_cap", "n_counters", "max_steps", "C", "H")]
+                + [(n, _f32) for n in ("bound", "dt_gamma", "T_thresh", "density_scale")]
+                + [("zero_deform", ctypes.c_int32)])
+
+
 PROTOTYPES_U32 = {
     "sdn_field_weight_blocks": [],
     "sdn_cull_grid_bytes": [],
@@ -134,6 +150,13 @@ class KernelTimers:
         e = torch.cuda.Event(enable_timing=True)
         self.records.setdefault(name, []).append((s, e, units))
         return s, e
+
+    def raw_pair(self, name, units):
+        """Pair of events whose hipEvent_t handles are handed to a native entry point that records them itself."""
+        s, e = self.record(name, units)
+        cur = torch.cuda.current_stream()
+        s.record(cur); e.record(cur)  # materialises the handles; the native call re-records them in place
+        return s.cuda_event, e.cuda_event
 
     def summary(self):
         torch.cuda.synchronize()

@@ -188,3 +188,32 @@ def test_render_frame_fused_f16_vs_oracle(small_scene):
     assert np.abs(img - ref["image"]).max() < 5e-3 and np.abs(img - ref["image"]).mean() < 2e-4
     ops = render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=True)
     assert np.abs(img - ops["image"].cpu().numpy()).max() < 5e-3
+
+
+def test_device_driven_loop_is_bit_identical_to_host_loop(small_scene):
+    """csrc/render.hip (loop record on the device, no per-iteration host sync) against render_frame with the same fused
+    field: image, depth, weights, trace and sample count must be identical."""
+    from dnerf_amd import fused
+    from dnerf_amd.renderer import render_frame, DeviceLoop
+    sc = small_scene
+    f = fused.FusedField(sc.model, sc.time, fp16=True)
+    a = render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=True, field=f)
+    loop = DeviceLoop(sc.model, f, sc.rays_o.shape[0], sc.rays_o.device)
+    for _ in range(2):  # second pass reuses every buffer
+        b = loop.render(sc.rays_o, sc.rays_d, sc.time)
+        assert torch.equal(a["image"], b["image"])
+        assert torch.equal(torch.nan_to_num(a["depth"]), torch.nan_to_num(b["depth"]))
+        assert torch.equal(a["weights_sum"], b["weights_sum"])
+        assert [tuple(t) for t in a["trace"]] == [tuple(t) for t in b["trace"]]
+        assert a["n_samples"] == b["n_samples"]
+
+
+def test_device_driven_loop_full_frame():
+    from dnerf_amd import fused
+    from dnerf_amd.bench_scene import build_scene
+    from dnerf_amd.renderer import render_frame, DeviceLoop
+    sc = build_scene(H=800, W=800, device="cuda", seed=0)
+    f = fused.FusedField(sc.model, sc.time, fp16=True)
+    a = render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=True, field=f)
+    b = DeviceLoop(sc.model, f, 640000, sc.rays_o.device).render(sc.rays_o, sc.rays_d, sc.time)
+    assert torch.equal(a["image"], b["image"]) and a["n_samples"] == b["n_samples"] and len(a["trace"]) == len(b["trace"])
