@@ -11,7 +11,7 @@
 // round-tripping [M,128] activations through HBM.  Here it is ONE launch and activations never leave registers.
 //
 // Mapping (see DESIGN.md "fused field kernel"):
-//   * workgroup = 4 waves = 128 sample points; one wave = 32 points = the N dimension of
+//   * workgroup = 8 waves (2 per SIMD) = 256 sample points; one wave = 32 points = the N dimension of
 //     v_mfma_f32_32x32x16_f16.  Weights are the A operand (M = output features), activations the B operand
 //     (K = input features).  The accumulator of layer i (feature rows in registers, point on the lane) converts
 //     in place (ReLU, cvt_pk_f16) into the B operand of layer i+1 -- no cross-lane traffic between layers.  The
@@ -22,7 +22,7 @@
 //     (D0 16 KiB | D1..D6 32 KiB each | D7+S0+S1+C0+C1+C2 32 KiB) with direct-to-LDS loads
 //     (global_load_lds_dwordx4), double-buffered, one barrier per stage: stage s+1 lands while stage s feeds
 //     the MFMAs through conflict-free ds_read_b128 (lane-linear fragments).  HBM/L2 sees each weight byte once
-//     per 128 points instead of once per 32.
+//     per 256 points instead of once per 32.
 //   * the time encoding is the same for every point: its contribution W0[:,63:76] . enc(t) is a per-frame
 //     bias vector (computed on the host) loaded as the initial accumulator of the first layer.
 //   * the 128 table gathers per point are split over the two lane-halves (levels 0-7 / 8-15); row strides,
@@ -53,6 +53,8 @@ constexpr int kBlkTotal = kBlkC2 + 4;     // 240
 static_assert(kBlkTotal - kBlkD7 == 32, "the tail stage must be exactly one 32 KiB buffer");
 
 constexpr int kStageBytes = 32768;
+constexpr int kWaves = 8;                 // waves per workgroup (2 per SIMD), 32 points each
+constexpr int kPointsPerWG = 32 * kWaves;
 
 // tiled-grid level constants (D = 3, align_corners = false), host-precomputed: gridencoder.cu:66-84,138-139
 struct TiledLevels {
@@ -117,7 +119,7 @@ __device__ __forceinline__ float fast_sin(float a) {
 // Stage `nbytes` (multiple of 4 KiB) of packed weights global -> LDS, all 256 threads, 16 B per lane per instruction.
 // One wave-instruction moves 1 KiB to a wave-uniform LDS base + lane * 16 (global_load_lds_dwordx4).
 __device__ __forceinline__ void stage_load(const unsigned char *__restrict__ g, unsigned char *lds, int nbytes, uint32_t wave, uint32_t lane) {
-    for (int c = (int)wave; c < nbytes / 1024; c += 4) {
+    for (int c = (int)wave; c < nbytes / 1024; c += kWaves) {
         const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)c * 1024u);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off + lane * 16),
                                          (__attribute__((address_space(3))) void *)(lds + off), 16, 0, 0);
@@ -128,13 +130,13 @@ __device__ __forceinline__ half8 lds_frag(const unsigned char *buf, int blk, uin
     return *reinterpret_cast<const half8 *>(buf + (size_t)blk * 1024 + lane * 16);
 }
 
-__global__ void __launch_bounds__(256, 2) k_field_f16(FieldArgs P, TiledLevels lv) {
+__global__ void __launch_bounds__(64 * kWaves, 4) k_field_f16(FieldArgs P, TiledLevels lv) {
     __shared__ __attribute__((aligned(16))) unsigned char s_w[2][kStageBytes];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t count = P.state ? P.live_count[P.state[3]] : (P.live_idx ? *P.live_count : P.M);
-    if (blockIdx.x * 128u >= count) return;  // workgroup-uniform: nothing to do, no barrier touched
+    if (blockIdx.x * (uint32_t)kPointsPerWG >= count) return;  // workgroup-uniform: nothing to do, no barrier touched
     const uint32_t n = lane & 31u, h = lane >> 5;
-    const uint32_t i = blockIdx.x * 128u + wave * 32u + n;
+    const uint32_t i = blockIdx.x * (uint32_t)kPointsPerWG + wave * 32u + n;
     const bool valid = i < count;
     const uint32_t ii = valid ? i : (count - 1);  // idle lanes recompute the last point and store nothing
     const uint32_t p = P.live_idx ? P.live_idx[ii] : ii;
@@ -239,48 +241,55 @@ __global__ void __launch_bounds__(256, 2) k_field_f16(FieldArgs P, TiledLevels l
     half8 gf[2];
     {
         const bool oob = (u[0] < 0) | (u[0] > 1) | (u[1] < 0) | (u[1] > 1) | (u[2] < 0) | (u[2] > 1);
+        // two batches of 4 levels: the 32 row gathers of a batch are issued back to back (independent loads, L2 / Infinity
+        // Cache latency overlapped) before any of them is consumed
         #pragma unroll
-        for (int li = 0; li < 8; li++) {
-            const uint32_t offset = h ? lv.offset[8 + li] : lv.offset[li];
-            const uint32_t s1 = h ? lv.s1[8 + li] : lv.s1[li];
-            const uint32_t s2 = h ? lv.s2[8 + li] : lv.s2[li];
-            const uint32_t hsize = h ? lv.hsize[8 + li] : lv.hsize[li];
-            const uint32_t mask = h ? lv.mask[8 + li] : lv.mask[li];
-            const float scale = h ? lv.scale[8 + li] : lv.scale[li];
-            const __half2 *__restrict__ tab = reinterpret_cast<const __half2 *>(P.table) + offset;
-            float pos[3];
-            uint32_t pg[3];
+        for (int lb = 0; lb < 2; lb++) {
+            float2 vals[4][8];
+            float pos[4][3];
             #pragma unroll
-            for (int d = 0; d < 3; d++) {
-                pos[d] = u[d] * scale + 0.5f;
-                pg[d] = (uint32_t)floorf(pos[d]);
-                pos[d] -= (float)pg[d];
-            }
-            const uint32_t base = oob ? 0u : pg[0] + pg[1] * s1 + pg[2] * s2;  // uint32 wrap-around as in get_grid_index
-            float2 vals[8];
-            float wgt[8];
-            #pragma unroll
-            for (uint32_t idx = 0; idx < 8; idx++) {
-                float w = 1;
+            for (int lq = 0; lq < 4; lq++) {
+                const int li = lb * 4 + lq;
+                const uint32_t offset = h ? lv.offset[8 + li] : lv.offset[li];
+                const uint32_t s1 = h ? lv.s1[8 + li] : lv.s1[li];
+                const uint32_t s2 = h ? lv.s2[8 + li] : lv.s2[li];
+                const uint32_t hsize = h ? lv.hsize[8 + li] : lv.hsize[li];
+                const uint32_t mask = h ? lv.mask[8 + li] : lv.mask[li];
+                const float scale = h ? lv.scale[8 + li] : lv.scale[li];
+                const __half2 *__restrict__ tab = reinterpret_cast<const __half2 *>(P.table) + offset;
+                uint32_t pg[3];
                 #pragma unroll
-                for (uint32_t d = 0; d < 3; d++) w *= (idx & (1u << d)) ? pos[d] : 1 - pos[d];
-                wgt[idx] = w;
-                // `index % hashmap_size` of get_grid_index without a division and without a branch (a branch per corner would
-                // serialise the eight gathers): capped levels have a power-of-two row count (AND); dense levels hold every
-                // (res+1)^3 corner, so an in-range point never wraps -- the min() only guards memory safety.
-                uint32_t row = base + (idx & 1u) + ((idx & 2u) ? s1 : 0u) + ((idx & 4u) ? s2 : 0u);
-                row = min(row & mask, hsize - 1u);
-                vals[idx] = __half22float2(tab[row]);
+                for (int d = 0; d < 3; d++) {
+                    pos[lq][d] = u[d] * scale + 0.5f;
+                    pg[d] = (uint32_t)floorf(pos[lq][d]);
+                    pos[lq][d] -= (float)pg[d];
+                }
+                const uint32_t base = oob ? 0u : pg[0] + pg[1] * s1 + pg[2] * s2;  // uint32 wrap-around as in get_grid_index
+                #pragma unroll
+                for (uint32_t idx = 0; idx < 8; idx++) {
+                    // `index % hashmap_size` of get_grid_index without a division and without a branch (a branch per corner
+                    // would serialise the gathers): capped levels have a power-of-two row count (AND); dense levels hold every
+                    // (res+1)^3 corner, so an in-range point never wraps -- the min() only guards memory safety.
+                    uint32_t row = base + (idx & 1u) + ((idx & 2u) ? s1 : 0u) + ((idx & 4u) ? s2 : 0u);
+                    row = min(row & mask, hsize - 1u);
+                    vals[lq][idx] = __half22float2(tab[row]);
+                }
             }
-            float r0 = 0, r1 = 0;
             #pragma unroll
-            for (int idx = 0; idx < 8; idx++) {  // kernel_grid: half += float * half, rounded to half each step
-                r0 = round_h(r0 + wgt[idx] * vals[idx].x);
-                r1 = round_h(r1 + wgt[idx] * vals[idx].y);
+            for (int lq = 0; lq < 4; lq++) {
+                float r0 = 0, r1 = 0;
+                #pragma unroll
+                for (uint32_t idx = 0; idx < 8; idx++) {  // kernel_grid: half += float * half, rounded to half each step
+                    float w = 1;
+                    #pragma unroll
+                    for (uint32_t d = 0; d < 3; d++) w *= (idx & (1u << d)) ? pos[lq][d] : 1 - pos[lq][d];
+                    r0 = round_h(r0 + w * vals[lq][idx].x);
+                    r1 = round_h(r1 + w * vals[lq][idx].y);
+                }
+                if (oob) { r0 = 0; r1 = 0; }
+                gf[lb][2 * lq] = (_Float16)r0;
+                gf[lb][2 * lq + 1] = (_Float16)r1;
             }
-            if (oob) { r0 = 0; r1 = 0; }
-            gf[li >> 2][2 * (li & 3)] = (_Float16)r0;
-            gf[li >> 2][2 * (li & 3) + 1] = (_Float16)r1;
         }
     }
 
@@ -399,7 +408,7 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
     a.xyzs = xyzs; a.dirs = dirs; a.live_idx = live_idx; a.live_count = live_count; a.state = state; a.M = M;
     a.weights = (const unsigned char *)weights; a.bias0 = bias0; a.table = (const __half *)table;
     a.sigmas = sigmas; a.rgbs = rgbs; a.bound = bound; a.density_scale = density_scale; a.zero_deform = zero_deform;
-    hipLaunchKernelGGL(k_field_f16, dim3(sdn_div_up(M, 128u)), dim3(256), 0, st, a, lv);
+    hipLaunchKernelGGL(k_field_f16, dim3(sdn_div_up(M, (uint32_t)kPointsPerWG)), dim3(64 * kWaves), 0, st, a, lv);
     return sdn_launch_status();
 }
 

@@ -718,9 +718,14 @@ __global__ void __launch_bounds__(256) k_loop_init(uint32_t N, uint32_t max_step
     }
 }
 
-__global__ void k_loop_advance(int32_t *__restrict__ state, const int32_t *__restrict__ n_out, int32_t *__restrict__ trace) {
+// snap: 4 x {alive rays entering the next iteration, index of that iteration} -- an immutable per-iteration snapshot the
+// host copies out on a side stream while the main stream already runs the next iteration.
+__global__ void k_loop_advance(int32_t *__restrict__ state, const int32_t *__restrict__ n_out, int32_t *__restrict__ trace,
+                               int32_t *__restrict__ snap) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int32_t it = state[3];
+    const int32_t call = state[7];  // number of advance calls so far (no-op iterations included)
+    state[7] = call + 1;
     if (state[0] > 0) {  // log only iterations that did work: (n_alive, n_step)
         trace[2 * it] = state[0];
         trace[2 * it + 1] = state[1];
@@ -735,6 +740,8 @@ __global__ void k_loop_advance(int32_t *__restrict__ state, const int32_t *__res
             state[1] = ns > 8 ? 8 : (ns < 1 ? 1 : ns);
         }
     }
+    snap[(call & 3) * 2] = state[0];
+    snap[(call & 3) * 2 + 1] = call + 1;
 }
 
 // image = image + (1 - weights_sum) * bg ; depth = clamp(depth - nears, 0) / (fars - nears)   (dnerf/renderer.py:378-379)
@@ -781,7 +788,7 @@ int loop_march(uint32_t bound_alive, const int32_t *alive_a, const int32_t *aliv
 
 int loop_composite_compact(uint32_t bound_alive, float T_thresh, int32_t *alive_a, int32_t *alive_b, float *rays_t, const float *sigmas,
                            const float *rgbs, const float *deltas, float *weights_sum, float *depth, float *image, int32_t *state,
-                           uint32_t *block_totals, int32_t *n_out, int32_t *trace, hipStream_t st) {
+                           uint32_t *block_totals, int32_t *n_out, int32_t *trace, int32_t *snap, hipStream_t st) {
     hipLaunchKernelGGL(k_composite_rays, dim3(sdn_div_up(bound_alive, 256u)), dim3(256), 0, st, 0u, 0u, T_thresh, alive_a, rays_t, sigmas, rgbs,
                        deltas, weights_sum, depth, image, (const int32_t *)state, alive_b);
     const uint32_t nb = sdn_div_up(bound_alive, kScanBlock);
@@ -790,7 +797,7 @@ int loop_composite_compact(uint32_t bound_alive, float T_thresh, int32_t *alive_
     // side 0: in = a, out = b; side 1: in = b, out = a
     hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(kScanBlock), 0, st, (const int32_t *)alive_a, 0u, (const uint32_t *)block_totals, alive_b,
                        n_out, (const int32_t *)state, (const int32_t *)alive_b, alive_a);
-    hipLaunchKernelGGL(k_loop_advance, dim3(1), dim3(64), 0, st, state, (const int32_t *)n_out, trace);
+    hipLaunchKernelGGL(k_loop_advance, dim3(1), dim3(64), 0, st, state, (const int32_t *)n_out, trace, snap);
     return sdn_launch_status();
 }
 

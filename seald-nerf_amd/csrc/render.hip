@@ -49,7 +49,8 @@ int sdn_render_step_f16_ev(const SdnRenderCtx *c, uint32_t bound_alive, void *ev
     if (ev_field_end) (void)hipEventRecord((hipEvent_t)ev_field_end, st);
     if (rc) return rc;
     return sdn_int::loop_composite_compact(bound_alive, c->T_thresh, c->alive_a, c->alive_b, c->rays_t, c->sigmas, c->rgbs, c->deltas,
-                                           c->weights_sum, c->depth, c->image, c->state, (uint32_t *)c->block_totals, c->n_out, c->trace, st);
+                                           c->weights_sum, c->depth, c->image, c->state, (uint32_t *)c->block_totals, c->n_out, c->trace,
+                                           c->trace + 2 * (size_t)c->n_counters, st);
 }
 
 int sdn_render_finish(const SdnRenderCtx *c, float bg_color, float *image_out, float *depth_out, void *stream) {

@@ -423,12 +423,15 @@ class DeviceLoop:
         self.buf = dict(alive_a=z(N, dt=i32), alive_b=z(N, dt=i32), rays_t=z(N), weights_sum=z(N), depth=z(N), image=z(N, 3),
                         xyzs=z(M, 3), dirs=z(M, 3), deltas=z(M, 2), sigmas=z(M), rgbs=z(M, 3), live_idx=z(M, dt=i32),
                         live_counts=torch.zeros(n_counters, dtype=i32, device=device), state=torch.zeros(8, dtype=i32, device=device),
-                        trace=torch.zeros(2 * n_counters, dtype=i32, device=device), n_out=torch.zeros(1, dtype=i32, device=device),
+                        trace=torch.zeros(2 * n_counters + 8, dtype=i32, device=device), n_out=torch.zeros(1, dtype=i32, device=device),
                         block_totals=z((N + 1023) // 1024 + 1, dt=i32),
                         cull_bits=torch.empty(int(lib.sdn_cull_grid_bytes()), dtype=torch.uint8, device=device))
         self.image_out, self.depth_out = z(N, 3), z(N)
-        self.host_state = torch.zeros(self.RING, 8, dtype=i32).pin_memory()
+        self.snap = self.buf["trace"][2 * n_counters:].view(4, 2)  # device ring written by k_loop_advance
+        self.host_state = torch.zeros(self.RING, 2, dtype=i32).pin_memory()
         self.events = [torch.cuda.Event() for _ in range(self.RING)]
+        self.copy_events = [torch.cuda.Event() for _ in range(self.RING)]
+        self.side = torch.cuda.Stream(device=device)
         c = SdnRenderCtx()
         for k, v in self.buf.items():
             setattr(c, k, v.data_ptr())
@@ -465,11 +468,15 @@ class DeviceLoop:
             else:
                 check(lib.sdn_render_step_f16(cref, bound, st), "render_step_f16")
             slot = it % self.RING
-            self.host_state[slot].copy_(self.buf["state"], non_blocking=True)
+            # read the iteration's snapshot back on a side stream: the main stream goes straight on to the next iteration
             self.events[slot].record(cur)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.events[slot])
+                self.host_state[slot].copy_(self.snap[slot], non_blocking=True)
+                self.copy_events[slot].record(self.side)
             if it >= 1:
                 prev = (it - 1) % self.RING
-                self.events[prev].synchronize()
+                self.copy_events[prev].synchronize()
                 n_prev = int(self.host_state[prev][0])  # alive rays entering iteration `it` (already enqueued)
                 if n_prev == 0:
                     break
