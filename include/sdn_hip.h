@@ -112,7 +112,9 @@ int sdn_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_t *rays_ali
                       uint32_t *live_idx, uint32_t *live_count, void *stream);
 uint32_t sdn_cull_grid_bytes(void);
 /* bitfield: one 128^3 Morton-ordered occupancy slice (cascade 0), 8-byte aligned.  H must be 128.
- * cull_grid: 32^3 bits (bit (z*32+y)*32+x, 16-byte aligned): cell marked iff an occupied voxel lies in its 3x3x3 neighbourhood. */
+ * cull_grid: sdn_cull_grid_bytes() bytes, 16-byte aligned: 32^3 mark bits (bit (z*32+y)*32+x; cell marked iff an occupied voxel lies
+ * in its 3x3x3 neighbourhood) followed by 8 ints {x0,y0,z0,x1,y1,z1,-,-}, the inclusive bounding box of the marked cells (the
+ * marcher keeps the fine bits of that box in LDS when it fits 32 KiB). */
 int sdn_build_cull_grid(const uint8_t *bitfield, uint32_t H, uint8_t *cull_grid, void *stream);
 
 /* raymarching.h:17  composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas,
@@ -196,7 +198,7 @@ int sdn_field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *
 /* All pointers are device pointers owned by the caller except grid_offsets (17 host ints, copied by value).
  * Buffer sizes: per-ray arrays N; sample arrays M_cap >= N + 128 rows; live_counts n_counters >= max_steps + 8;
  * trace 2 * n_counters + 8 (the last 8 ints are a 4-deep ring of {alive rays entering the next iteration, iteration
- * number} snapshots for asynchronous read-back); block_totals ceil(N / 1024) + 1; cull_bits sdn_cull_grid_bytes(); state 8 ints. */
+ * number} snapshots for asynchronous read-back); block_totals ceil(N / 256) + 1; n_out 1 int, zero on entry (ticket counter); cull_bits sdn_cull_grid_bytes(); state 8 ints. */
 typedef struct SdnRenderCtx {
     const float *rays_o, *rays_d, *nears, *fars;
     const uint8_t *bitfield;

@@ -86,14 +86,18 @@ struct FieldArgs {
 __device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 // accumulator tile -> the two B fragments (k-steps) it provides to the next layer
+// (the reference rounds the Linear output to fp16 and applies ReLU on the fp16 tensor: round first, then a packed max)
 template <bool RELU>
 __device__ __forceinline__ void acc_to_frags(const f32x16 &acc, half8 &f0, half8 &f1) {
     #pragma unroll
     for (int j = 0; j < 8; j++) {
-        float a = acc[j], b = acc[8 + j];
-        if (RELU) { a = fmaxf(a, 0.0f); b = fmaxf(b, 0.0f); }
-        f0[j] = (_Float16)a;
-        f1[j] = (_Float16)b;
+        f0[j] = (_Float16)acc[j];
+        f1[j] = (_Float16)acc[8 + j];
+    }
+    if (RELU) {
+        const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        f0 = __builtin_elementwise_max(f0, zero);
+        f1 = __builtin_elementwise_max(f1, zero);
     }
 }
 

@@ -72,6 +72,10 @@ __host__ __device__ __forceinline__ uint32_t morton3D_invert_(uint32_t x) {
 // (raymarching.cu:359-400 == 427-479 == 750-804).
 // ---------------------------------------------------------------------------
 constexpr uint32_t kCullRes = 32;  // cull grid resolution (see "Exact early-out" below)
+constexpr uint32_t kCullWords = kCullRes * kCullRes * kCullRes / 32;  // 1024 words of marks, followed by 8 words of meta:
+// meta = {x0, y0, z0, x1, y1, z1 (inclusive bounding box of the marked cells), -, -}
+constexpr uint32_t kFineCacheCells = 4096;  // LDS budget for the fine-bit cache: 32 KiB
+__device__ __forceinline__ uint32_t m2(uint32_t v) { return (v & 1u) | ((v & 2u) << 2); }  // 2-bit Morton spread
 __device__ __forceinline__ bool cull_marked(const uint32_t *cull_bits, int cx, int cy, int cz) {
     const uint32_t c = ((uint32_t)cz * kCullRes + (uint32_t)cy) * kCullRes + (uint32_t)cx;
     return (cull_bits[c >> 5] >> (c & 31u)) & 1u;
@@ -86,8 +90,13 @@ struct MarcherT {
     float rH, H3, Hf, Cf, Hm1;
     float bound, dt_gamma, dt_min, dt_max;
     float halfH, twoRH, ex, ey, ez;  // FAST only
+    float dt_const;                  // step when dt_gamma == 0 (clamp(t * 0, dt_min, dt_max) for every finite t)
+    bool dt_is_const;
     double Hd;
     const uint8_t *__restrict__ grid;
+    // FAST only: LDS copy of the fine bits of the cull grid's bounding box (one 64-bit word = one 4x4x4 voxel block)
+    const unsigned long long *fine = nullptr;
+    int fx0 = 0, fy0 = 0, fz0 = 0, fnx = 0, fny = 0;
 
     __device__ __forceinline__ void init(const float *o, const float *d, float bound_, float dt_gamma_,
                                          uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid_) {
@@ -100,13 +109,15 @@ struct MarcherT {
         bound = bound_; dt_gamma = dt_gamma_;
         dt_min = 2 * kSqrt3 / (float)max_steps;
         dt_max = 2 * kSqrt3 * (float)(1 << (C - 1)) / (float)H;
+        dt_is_const = (dt_gamma_ == 0.0f);
+        dt_const = clampf_(0.0f, dt_min, dt_max);
         grid = grid_;
         halfH = 0.5f * Hf; twoRH = 2.0f * rH;
         // nx + 0.5f + 0.5f * signf(d) == nx + (signbit(d) ? 0 : 1), exactly
         ex = signbit(dx) ? 0.0f : 1.0f; ey = signbit(dy) ? 0.0f : 1.0f; ez = signbit(dz) ? 0.0f : 1.0f;
     }
 
-    __device__ __forceinline__ float step_size(float t) const { return clampf_(t * dt_gamma, dt_min, dt_max); }
+    __device__ __forceinline__ float step_size(float t) const { return dt_is_const ? dt_const : clampf_(t * dt_gamma, dt_min, dt_max); }
 
     // One loop-body evaluation at parameter t.  Occupied: returns true with the sample in
     // (x,y,z,dt), t untouched.  Empty: returns false with t advanced past the voxel.
@@ -122,8 +133,15 @@ struct MarcherT {
             bool occ = false;
             // an unmarked cull cell holds no occupied voxel: the fine bit (a dependent L2 load) is only fetched near the object
             if (!cull_bits || cull_marked(cull_bits, nx >> 2, ny >> 2, nz >> 2)) {
-                const uint32_t index = morton3D_8bit((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
-                occ = grid[index >> 3] & (1u << (index & 7u));
+                if (fine) {
+                    // marked cells lie inside the cached box by construction; bit = Morton code of the low two bits per axis
+                    const int slot = (((nz >> 2) - fz0) * fny + ((ny >> 2) - fy0)) * fnx + ((nx >> 2) - fx0);
+                    const uint32_t b = m2((uint32_t)nx & 3u) | (m2((uint32_t)ny & 3u) << 1) | (m2((uint32_t)nz & 3u) << 2);
+                    occ = (fine[slot] >> b) & 1ull;
+                } else {
+                    const uint32_t index = morton3D_8bit((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+                    occ = grid[index >> 3] & (1u << (index & 7u));
+                }
             }
             if (occ) return true;
             const float tx = ((((float)nx + ex) * twoRH - 1) - x) * rdx;
@@ -189,6 +207,20 @@ __global__ void __launch_bounds__(256) k_build_cull_grid(const uint8_t *__restri
     if ((threadIdx.x & 63u) == 0) {
         cull_bits[c >> 5] = (uint32_t)m;
         cull_bits[(c >> 5) + 1] = (uint32_t)(m >> 32);
+    }
+    if (any) {
+        int *meta = reinterpret_cast<int *>(cull_bits + kCullWords);
+        atomicMin(meta + 0, cx); atomicMin(meta + 1, cy); atomicMin(meta + 2, cz);
+        atomicMax(meta + 3, cx); atomicMax(meta + 4, cy); atomicMax(meta + 5, cz);
+    }
+}
+
+__global__ void k_cull_meta_init(uint32_t *__restrict__ cull_bits) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int *meta = reinterpret_cast<int *>(cull_bits + kCullWords);
+        meta[0] = meta[1] = meta[2] = (int)kCullRes;
+        meta[3] = meta[4] = meta[5] = -1;
+        meta[6] = meta[7] = 0;
     }
 }
 
@@ -526,10 +558,26 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
         M_pad = m0 + (128u - m0 % 128u);
     }
     __shared__ uint4 s_cull4[FAST ? 256 : 1];  // 32^3 bits = 4 KiB
+    __shared__ unsigned long long s_fine[FAST ? kFineCacheCells : 1];  // fine bits of the marked bounding box, <= 32 KiB
     const uint32_t *s_cull = nullptr;
+    const unsigned long long *fine = nullptr;
+    int fx0 = 0, fy0 = 0, fz0 = 0, fnx = 0, fny = 0;
     if constexpr (FAST) {
         if (cull) {  // kernel-uniform
             s_cull4[threadIdx.x] = reinterpret_cast<const uint4 *>(cull)[threadIdx.x];
+            const int *meta = reinterpret_cast<const int *>(cull + kCullWords);
+            fx0 = meta[0]; fy0 = meta[1]; fz0 = meta[2];
+            fnx = meta[3] - fx0 + 1; fny = meta[4] - fy0 + 1;
+            const int fnz = meta[5] - fz0 + 1;
+            if (fnx > 0 && fny > 0 && fnz > 0 && (uint32_t)(fnx * fny * fnz) <= kFineCacheCells) {
+                const unsigned long long *__restrict__ blocks = reinterpret_cast<const unsigned long long *>(grid);
+                const int cells = fnx * fny * fnz;
+                for (int i = (int)threadIdx.x; i < cells; i += 256) {
+                    const int cx = fx0 + i % fnx, cy = fy0 + (i / fnx) % fny, cz = fz0 + i / (fnx * fny);
+                    s_fine[i] = blocks[morton3D_8bit((uint32_t)cx, (uint32_t)cy, (uint32_t)cz)];
+                }
+                fine = s_fine;
+            }
             __syncthreads();
             s_cull = reinterpret_cast<const uint32_t *>(s_cull4);
         }
@@ -541,6 +589,7 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
         const int index = rays_alive[n];
         MarcherT<FAST> m;
         m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid);
+        m.fine = fine; m.fx0 = fx0; m.fy0 = fy0; m.fz0 = fz0; m.fnx = fnx; m.fny = fny;
         float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3, *pl = deltas + (size_t)n * n_step * 2;
         float t = rays_t[index];
         const float far = fars[index];
@@ -598,36 +647,46 @@ __global__ void __launch_bounds__(256) k_composite_rays(uint32_t n_alive, uint32
                                                         float *__restrict__ rays_t, const float *__restrict__ sigmas,
                                                         const float *__restrict__ rgbs, const float *__restrict__ deltas,
                                                         float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image,
-                                                        const int32_t *__restrict__ state, int32_t *__restrict__ rays_alive_b) {
+                                                        const int32_t *__restrict__ state, int32_t *__restrict__ rays_alive_b,
+                                                        uint32_t *__restrict__ block_totals) {
     if (state) {
         n_alive = (uint32_t)state[0];
         n_step = (uint32_t)state[1];
         if (state[4]) rays_alive = rays_alive_b;
     }
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
-    if (n >= n_alive) return;
-    const int index = rays_alive[n];
-    const float *s = sigmas + (size_t)n * n_step, *c = rgbs + (size_t)n * n_step * 3, *dl = deltas + (size_t)n * n_step * 2;
-    float t = rays_t[index];
-    float weight_sum = weights_sum[index], d = depth[index];
-    float r = image[(size_t)index * 3], g = image[(size_t)index * 3 + 1], b = image[(size_t)index * 3 + 2];
-    uint32_t step = 0;
-    while (step < n_step) {
-        if (dl[0] == 0) break;
-        const float alpha = 1.0f - sdn_exp_cr(-s[0] * dl[0]);
-        const float T = 1 - weight_sum;
-        const float weight = alpha * T;
-        weight_sum += weight;
-        t += dl[1];
-        d += weight * t;
-        r += weight * c[0]; g += weight * c[1]; b += weight * c[2];
-        if (T < T_thresh) break;
-        s++; c += 3; dl += 2; step++;
+    bool survives = false;
+    if (n < n_alive) {
+        const int index = rays_alive[n];
+        const float *s = sigmas + (size_t)n * n_step, *c = rgbs + (size_t)n * n_step * 3, *dl = deltas + (size_t)n * n_step * 2;
+        float t = rays_t[index];
+        float weight_sum = weights_sum[index], d = depth[index];
+        float r = image[(size_t)index * 3], g = image[(size_t)index * 3 + 1], b = image[(size_t)index * 3 + 2];
+        uint32_t step = 0;
+        while (step < n_step) {
+            if (dl[0] == 0) break;
+            const float alpha = 1.0f - sdn_exp_cr(-s[0] * dl[0]);
+            const float T = 1 - weight_sum;
+            const float weight = alpha * T;
+            weight_sum += weight;
+            t += dl[1];
+            d += weight * t;
+            r += weight * c[0]; g += weight * c[1]; b += weight * c[2];
+            if (T < T_thresh) break;
+            s++; c += 3; dl += 2; step++;
+        }
+        if (step < n_step) rays_alive[n] = -1;
+        else { rays_t[index] = t; survives = true; }
+        weights_sum[index] = weight_sum; depth[index] = d;
+        image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
     }
-    if (step < n_step) rays_alive[n] = -1;
-    else rays_t[index] = t;
-    weights_sum[index] = weight_sum; depth[index] = d;
-    image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
+    if (block_totals) {  // kernel-uniform: survivor count of this 256-ray block, for the fused compaction of the device loop
+        __shared__ uint32_t s_cnt[4];
+        const unsigned long long m = __ballot(survives);
+        if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) block_totals[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -744,6 +803,79 @@ __global__ void k_loop_advance(int32_t *__restrict__ state, const int32_t *__res
     snap[(call & 3) * 2 + 1] = call + 1;
 }
 
+__device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t *lds4) {
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();  // protects lds4 against the previous use
+    if ((threadIdx.x & 63u) == 0) lds4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+// Stable compaction of the alive list (256-ray blocks, totals produced by k_composite_rays) fused with the loop advance:
+// the workgroup that draws the last ticket -- every workgroup of the launch takes one after its last read of the loop
+// record -- sums the totals and advances the record, so no workgroup can see a half-updated record.
+__global__ void __launch_bounds__(256) k_scatter_advance(int32_t *__restrict__ alive_a, int32_t *__restrict__ alive_b,
+                                                         const uint32_t *__restrict__ block_totals, int32_t *__restrict__ state,
+                                                         int32_t *__restrict__ ticket, int32_t *__restrict__ trace, int32_t *__restrict__ snap) {
+    __shared__ uint32_t lds4[4];
+    __shared__ int s_last;
+    const uint32_t n = (uint32_t)state[0];
+    const int32_t *in = state[4] ? alive_b : alive_a;
+    int32_t *out = state[4] ? alive_a : alive_b;
+    const uint32_t nb = (n + 255u) / 256u;
+    if (blockIdx.x < nb) {
+        uint32_t part = 0;
+        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256) part += block_totals[b];
+        const uint32_t prev = block_sum_256(part, lds4);
+        const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+        const int32_t v = i < n ? in[i] : -1;
+        const bool keep = v >= 0;
+        const unsigned long long mask = __ballot(keep);
+        const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+        const uint32_t below = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (lane == 0) lds4[wid] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t carry = 0;
+        for (uint32_t w = 0; w < wid; w++) carry += lds4[w];
+        if (keep) out[prev + carry + below] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    uint32_t part = 0;
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) part += block_totals[b];
+    const uint32_t total = block_sum_256(part, lds4);
+    if (threadIdx.x == 0) {
+        *ticket = 0;
+        const int32_t it = state[3];
+        const int32_t call = state[7];
+        state[7] = call + 1;
+        if (state[0] > 0) {
+            trace[2 * it] = state[0];
+            trace[2 * it + 1] = state[1];
+            state[2] += state[1];
+            state[3] = it + 1;
+            state[4] ^= 1;
+            int32_t n_new = (int32_t)total;
+            if (state[2] >= state[6]) n_new = 0;  // `while step < max_steps`
+            state[0] = n_new;
+            if (n_new > 0) {
+                const int32_t ns = state[5] / n_new;  // n_step = max(min(N // n_alive, 8), 1)
+                state[1] = ns > 8 ? 8 : (ns < 1 ? 1 : ns);
+            }
+        }
+        snap[(call & 3) * 2] = state[0];
+        snap[(call & 3) * 2 + 1] = call + 1;
+    }
+}
+
 // image = image + (1 - weights_sum) * bg ; depth = clamp(depth - nears, 0) / (fars - nears)   (dnerf/renderer.py:378-379)
 __global__ void __launch_bounds__(256) k_loop_finish(uint32_t N, const float *__restrict__ nears, const float *__restrict__ fars,
                                                      const float *__restrict__ weights_sum, const float *__restrict__ depth,
@@ -789,15 +921,11 @@ int loop_march(uint32_t bound_alive, const int32_t *alive_a, const int32_t *aliv
 int loop_composite_compact(uint32_t bound_alive, float T_thresh, int32_t *alive_a, int32_t *alive_b, float *rays_t, const float *sigmas,
                            const float *rgbs, const float *deltas, float *weights_sum, float *depth, float *image, int32_t *state,
                            uint32_t *block_totals, int32_t *n_out, int32_t *trace, int32_t *snap, hipStream_t st) {
-    hipLaunchKernelGGL(k_composite_rays, dim3(sdn_div_up(bound_alive, 256u)), dim3(256), 0, st, 0u, 0u, T_thresh, alive_a, rays_t, sigmas, rgbs,
-                       deltas, weights_sum, depth, image, (const int32_t *)state, alive_b);
-    const uint32_t nb = sdn_div_up(bound_alive, kScanBlock);
-    hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(kScanBlock), 0, st, (const int32_t *)alive_a, 0u, block_totals, (const int32_t *)state,
-                       (const int32_t *)alive_b);
-    // side 0: in = a, out = b; side 1: in = b, out = a
-    hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(kScanBlock), 0, st, (const int32_t *)alive_a, 0u, (const uint32_t *)block_totals, alive_b,
-                       n_out, (const int32_t *)state, (const int32_t *)alive_b, alive_a);
-    hipLaunchKernelGGL(k_loop_advance, dim3(1), dim3(64), 0, st, state, (const int32_t *)n_out, trace, snap);
+    const dim3 g(sdn_div_up(bound_alive, 256u)), b(256);
+    hipLaunchKernelGGL(k_composite_rays, g, b, 0, st, 0u, 0u, T_thresh, alive_a, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
+                       (const int32_t *)state, alive_b, block_totals);
+    // n_out doubles as the ticket counter (zero between launches)
+    hipLaunchKernelGGL(k_scatter_advance, g, b, 0, st, alive_a, alive_b, (const uint32_t *)block_totals, state, n_out, trace, snap);
     return sdn_launch_status();
 }
 
@@ -809,6 +937,7 @@ int loop_finish(uint32_t N, const float *nears, const float *fars, const float *
 }
 
 int build_cull(const uint8_t *bitfield, uint32_t *cull_bits, hipStream_t st) {
+    hipLaunchKernelGGL(k_cull_meta_init, dim3(1), dim3(64), 0, st, cull_bits);
     hipLaunchKernelGGL(k_build_cull_grid, dim3(kCullRes * kCullRes * kCullRes / 256), dim3(256), 0, st, bitfield, cull_bits);
     return sdn_launch_status();
 }
@@ -959,12 +1088,13 @@ int sdn_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_t *rays_ali
                              deltas, noises, M_pad, (const uint32_t *)cull_grid, live_idx, live_count, (hipStream_t)stream);
 }
 
-uint32_t sdn_cull_grid_bytes(void) { return kCullRes * kCullRes * kCullRes / 8; }
+uint32_t sdn_cull_grid_bytes(void) { return kCullWords * 4 + 32; }  // marks + bounding-box record
 
 int sdn_build_cull_grid(const uint8_t *bitfield, uint32_t H, uint8_t *cull_grid, void *stream) {
     if (!bitfield || !cull_grid) return SDN_E_BADARG;
     if (H != 128) return SDN_E_UNSUPPORTED;
     if (((uintptr_t)bitfield & 7u) != 0 || ((uintptr_t)cull_grid & 15u) != 0) return SDN_E_BADARG;
+    hipLaunchKernelGGL(k_cull_meta_init, dim3(1), dim3(64), 0, (hipStream_t)stream, (uint32_t *)cull_grid);
     hipLaunchKernelGGL(k_build_cull_grid, dim3(kCullRes * kCullRes * kCullRes / 256), dim3(256), 0, (hipStream_t)stream, bitfield,
                        (uint32_t *)cull_grid);
     return sdn_launch_status();
@@ -975,7 +1105,8 @@ int sdn_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_
     if (n_alive == 0 || n_step == 0) return 0;
     if (!rays_alive || !rays_t || !sigmas || !rgbs || !deltas || !weights_sum || !depth || !image) return SDN_E_BADARG;
     hipLaunchKernelGGL(k_composite_rays, dim3(sdn_div_up(n_alive, 256u)), dim3(256), 0, (hipStream_t)stream, n_alive, n_step, T_thresh,
-                       rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, (const int32_t *)nullptr, (int32_t *)nullptr);
+                       rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, (const int32_t *)nullptr, (int32_t *)nullptr,
+                       (uint32_t *)nullptr);
     return sdn_launch_status();
 }
 

@@ -96,6 +96,31 @@ def test_march_rays_bit_exact(cam, n_step, dt_gamma):
     assert (ref[2][:, 0] > 0).sum() > 100  # the test actually sampled something
 
 
+@pytest.mark.parametrize("kind", ["lego", "scattered"])
+def test_march_rays_ex_other_occupancies(cam, kind):
+    """Cull grid / fine-bit cache on other occupancy shapes: a compact box (cache active, different bounding box) and voxels
+    scattered over the whole volume (bounding box too large for LDS: the marcher must fall back to global bit loads)."""
+    import raymarching
+    from dnerf_amd import scene
+    if kind == "lego":
+        bf = scene.lego_occupancy()
+    else:
+        rng = np.random.default_rng(5)
+        bits = (rng.random(128 ** 3) < 0.002).astype(np.uint8)
+        bf = np.packbits(bits.reshape(-1, 8), axis=1, bitorder="little").reshape(-1)
+    N = cam["N"]
+    alive = np.arange(N, dtype=np.int32)
+    cull = raymarching.build_cull_grid(_dev(bf))
+    for n_step, advance in ((1, 0.0), (8, 0.4)):
+        rays_t = (cam["nears"] + np.float32(advance)).astype(np.float32)
+        ref = O.march_rays(N, n_step, alive, rays_t, cam["ro"], cam["rd"], 1.0, bf, 1, 128, cam["nears"], cam["fars"], align=128)
+        out = raymarching.march_rays_ex(N, n_step, _dev(alive), _dev(rays_t), _dev(cam["ro"]), _dev(cam["rd"]), 1.0, _dev(bf), 1, 128,
+                                        _dev(cam["fars"]), 128, 0.0, 1024, cull, True)
+        for o, r, name in zip(out[:3], ref, ("xyzs", "dirs", "deltas")):
+            assert np.array_equal(o.cpu().numpy().view(np.uint32), r.view(np.uint32)), (kind, name, n_step)
+        assert int(out[4].item()) == int((ref[2][: N * n_step, 0] > 0).sum()) > 0
+
+
 @pytest.mark.parametrize("n_step", [1, 8])
 def test_march_rays_ex_cull_and_live_list_are_exact(cam, n_step):
     """The cull-grid early-out and the live list must not change a single bit of the samples, at any stage of a render:
@@ -117,8 +142,11 @@ def test_march_rays_ex_cull_and_live_list_are_exact(cam, n_step):
         for b in range(3):
             for c in range(3):
                 dil |= pad[a:a + 32, b:b + 32, c:c + 32]
-    cull_bits = np.unpackbits(cull.cpu().numpy(), bitorder="little").reshape(32, 32, 32).astype(bool)   # bit c = (z*32 + y)*32 + x
+    raw = cull.cpu().numpy()
+    cull_bits = np.unpackbits(raw[:4096], bitorder="little").reshape(32, 32, 32).astype(bool)   # bit c = (z*32 + y)*32 + x
     assert np.array_equal(cull_bits, dil.transpose(2, 1, 0))
+    xs, ys, zs = np.nonzero(dil)
+    assert list(raw[4096:4120].view(np.int32)) == [xs.min(), ys.min(), zs.min(), xs.max(), ys.max(), zs.max()]
     alive = np.arange(N, dtype=np.int32)
     for advance in (0.0, 0.15, 0.6, 1.5):
         rays_t = (cam["nears"] + np.float32(advance)).astype(np.float32)

@@ -217,3 +217,36 @@ def test_device_driven_loop_full_frame():
     a = render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=True, field=f)
     b = DeviceLoop(sc.model, f, 640000, sc.rays_o.device).render(sc.rays_o, sc.rays_d, sc.time)
     assert torch.equal(a["image"], b["image"]) and a["n_samples"] == b["n_samples"] and len(a["trace"]) == len(b["trace"])
+
+
+def test_seald_teacher_render_matches_native_loop(small_scene):
+    """SealD-NeRF teacher path (SealDNeRF/renderer.py:110-292): T_thresh 1e-4, raw depth, optional mapper hooks."""
+    from dnerf_amd.seald import SealDNeRFTeacher
+    from dnerf_amd.renderer import render_frame
+    sc = small_scene
+    teacher = SealDNeRFTeacher(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).cuda().eval()
+    teacher.load_state_dict(sc.model.state_dict(), strict=False)
+    with torch.no_grad():
+        a = teacher.render(sc.rays_o[None], sc.rays_d[None], sc.time, staged=True, perturb=False, bg_color=1)
+    b = render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=False, T_thresh=1e-4)
+    assert torch.equal(a["image"][0], b["image"])
+    raw_depth = b["depth"] * (b["fars"] - b["nears"]) + b["nears"]   # undo the dnerf normalisation ...
+    hit = b["depth"] > 0                                             # ... where its clamp(depth - near, 0) was not active
+    assert int(hit.sum()) > 50
+    assert torch.allclose(a["depth"][0][hit], raw_depth[hit], rtol=1e-4, atol=1e-4)
+    assert int(teacher.time_frame) == sc.t_idx
+
+    class Shift:  # a trivial mapper: translate a box of space, tint what lands in it
+        def map_to_origin(self, xyzs, dirs):
+            mask = (xyzs[:, 1] > 0.2)
+            out = xyzs.clone()
+            out[mask, 1] -= 0.1
+            return out, dirs, mask
+
+        def map_color(self, xyzs, dirs, rgbs):
+            return rgbs * 0.5
+
+    teacher.init_mapper(Shift())
+    with torch.no_grad():
+        c = teacher.render(sc.rays_o[None], sc.rays_d[None], sc.time, staged=True, perturb=False, bg_color=1)
+    assert torch.isfinite(c["image"]).all() and not torch.equal(c["image"], a["image"])
