@@ -39,13 +39,69 @@ def parse():
     ap.add_argument("--fp32", action="store_true", help="fp32 field network instead of the -O (fp16) configuration")
     ap.add_argument("--field", default="auto", choices=["auto", "ops", "fused"], help="field network implementation")
     ap.add_argument("--loop", default="auto", choices=["auto", "host", "device"], help="loop driver: per-iteration host sync, or device-driven")
+    ap.add_argument("--mode", default="render", choices=["render", "train"],
+                    help="render: the headline 800x800 inference frame; train: one dnerf training step on 4096 rays (BASELINE config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-side", type=int, default=96, help="side of the CPU-baseline sample image")
     return ap.parse_args()
 
 
+def train_mode(args):
+    """BASELINE config 3: one dnerf training step (march_rays_train, field network under autocast, composite_rays_train forward +
+    backward, grid_encode backward atomics, Adam) on 4096 rays of the 800x800 camera, fp16 autocast + GradScaler as `-O` sets it
+    (main_dnerf.py:70-73,129; nerf/utils.py:869-886).  The MLPs run as torch (hipBLASLt) GEMMs: the fused kernel is inference-only."""
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    import sdn_backend
+    from dnerf_amd.bench_scene import build_scene
+    sc = build_scene(H=args.size, W=args.size, device=dev, seed=0)
+    model = sc.model.train()
+    n_rays = 4096
+    g = torch.Generator(device="cpu").manual_seed(0)
+    idx = torch.randint(0, sc.rays_o.shape[0], (n_rays,), generator=g).to(dev)
+    rays_o, rays_d = sc.rays_o[idx][None].contiguous(), sc.rays_d[idx][None].contiguous()
+    target = torch.rand(1, n_rays, 3, generator=torch.Generator(device="cpu").manual_seed(2)).to(dev)
+    opt = torch.optim.Adam(model.get_params(1e-2, 1e-3), betas=(0.9, 0.99), eps=1e-15)
+    scaler = torch.amp.GradScaler("cuda", enabled=not args.fp32)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=not args.fp32):
+            out = model.render(rays_o, rays_d, sc.time, staged=False, perturb=True, bg_color=1, force_all_rays=False, max_steps=1024)
+            loss = ((out["image"] - target) ** 2).mean()
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        return loss
+
+    torch.manual_seed(1)
+    for _ in range(2):  # first steps: unknown point budget (M = N * max_steps buffers, host read-back), as in the reference
+        step()
+    model.mean_count = int(model.step_counter[:2, 0].sum().item() / 2)  # what update_extra_state does (dnerf/renderer.py:550-552)
+    for _ in range(args.warmup):
+        step()
+    n_points = int(model.step_counter[(model.local_step - 1) % 16, 0].item())
+    timers = sdn_backend.KernelTimers()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sdn_backend.timers = timers
+        step()
+    sdn_backend.timers = None
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    summ = timers.summary()
+    print(json.dumps({"metric": "dnerf training step, 4096 rays (march_rays_train + field + composite_rays_train fwd/bwd + grid backward + Adam)",
+                      "value": args.steps / dt, "unit": "steps/s", "points_per_s": n_points * args.steps / dt, "rays_per_s": n_rays * args.steps / dt,
+                      "ms_per_step": dt / args.steps * 1e3, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "dtype": "f32" if args.fp32 else "f16",
+                      "data": "synthetic", "config": {"workload": "BASELINE config 3", "rays": n_rays, "sampled_points_per_step": n_points,
+                                                      "mean_count": model.mean_count}, "kernel_times": summ}))
+
+
 def main():
     args = parse()
+    if args.mode == "train":
+        return train_mode(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -53,13 +109,21 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
+    # rehearsal switch for a one-GPU box: every rank renders on device 0 and the frame is gathered over gloo (host staging);
+    # exercises the sharding / gather / timing protocol only -- never use its numbers
+    rehearse = os.environ.get("SDN_REHEARSE_ON_ONE_GPU", "0") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from dnerf_amd.bench_scene import build_scene
     from dnerf_amd.renderer import render_frame, FrameWorkspace
@@ -121,10 +185,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = "cpu" if rehearse else dev
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        ns = torch.tensor([n_samples_local], dtype=torch.int64, device=dev)
+        ns = torch.tensor([n_samples_local], dtype=torch.int64, device=cdev)
         dist.all_reduce(ns)
         n_samples = int(ns.item())
     else:
@@ -142,7 +207,7 @@ def main():
                                f"{'-O (fp16 field network, fp16 grid table)' if fp16 else 'fp32'}, 1 timestep (t=0.5), "
                                f"T_thresh 1e-2, max_steps 1024, dt_gamma 0",
                    "rays": n_total, "sampled_points_per_frame": n_samples, "loop_iterations": n_iters,
-                   "field": field_kind, "loop": loop_kind, "parallelism": f"ray-tiles x{world}" if world > 1 else "single GPU"},
+                   "field": field_kind, "loop": loop_kind, "parallelism": (f"ray-tiles x{world}" + (" (ONE-GPU REHEARSAL, numbers invalid)" if rehearse else "")) if world > 1 else "single GPU"},
     }
     if rank == 0:
         result["roofline"], result["kernel_times"] = roofline(timers, fp16, n_samples_local, n_iters, args.steps)

@@ -94,7 +94,18 @@ __device__ __forceinline__ void acc_to_frags(const f32x16 &acc, half8 &f0, half8
         f0[j] = (_Float16)acc[j];
         f1[j] = (_Float16)acc[8 + j];
     }
+#ifdef SDN_RELU_F32
     if (RELU) {
+        #pragma unroll
+        for (int j = 0; j < 8; j++) {
+            f0[j] = (_Float16)fmaxf(acc[j], 0.0f);
+            f1[j] = (_Float16)fmaxf(acc[8 + j], 0.0f);
+        }
+    }
+    if (false) {
+#else
+    if (RELU) {
+#endif
         const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
         f0 = __builtin_elementwise_max(f0, zero);
         f1 = __builtin_elementwise_max(f1, zero);
@@ -128,6 +139,14 @@ __device__ __forceinline__ void stage_load(const unsigned char *__restrict__ g, 
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off + lane * 16),
                                          (__attribute__((address_space(3))) void *)(lds + off), 16, 0, 0);
     }
+}
+
+// A staged buffer may be read once (a) every wave's own direct-to-LDS loads have landed -- they are pending LDS writes on the
+// VM counter, and hipcc does NOT reliably emit the vmcnt wait in front of __syncthreads() for them (checked in the ISA:
+// only lgkmcnt was waited) -- and (b) the workgroup has met at the barrier.
+__device__ __forceinline__ void stage_wait_and_sync() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 }
 
 __device__ __forceinline__ half8 lds_frag(const unsigned char *buf, int blk, uint32_t lane) {
@@ -184,7 +203,7 @@ __global__ void __launch_bounds__(64 * kWaves, 4) k_field_f16(FieldArgs P, Tiled
         #pragma unroll
         for (int r = 0; r < 16; r++) acc[mt][r] = P.bias0[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h];
     }
-    __syncthreads();  // (waits this thread's direct-to-LDS loads, then the workgroup's): D0 and D1 are resident
+    stage_wait_and_sync();  // D0 and D1 are resident
     #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
         #pragma unroll
@@ -196,7 +215,7 @@ __global__ void __launch_bounds__(64 * kWaves, 4) k_field_f16(FieldArgs P, Tiled
         const unsigned char *cur = s_w[(l + 1) & 1];
         #pragma unroll
         for (int t = 0; t < 4; t++) acc_to_frags<true>(acc[t], bf[2 * t], bf[2 * t + 1]);
-        __syncthreads();  // stage l+1 landed for everyone; everyone is done reading the other buffer (layer l)
+        stage_wait_and_sync();  // stage l+1 landed for everyone; everyone is done reading the other buffer (layer l)
         // refill the other buffer with stage l+2 (D(l+2) for l < 5, the tail stage for l == 5); it lands under this layer's MFMAs
         stage_load(P.weights + (size_t)(l < 5 ? kBlkD1 + (l + 1) * 32 : kBlkD7) * 1024, s_w[l & 1], kStageBytes, wave, lane);
         #pragma unroll
@@ -217,7 +236,7 @@ __global__ void __launch_bounds__(64 * kWaves, 4) k_field_f16(FieldArgs P, Tiled
     }
     #pragma unroll
     for (int t = 0; t < 4; t++) acc_to_frags<true>(acc[t], bf[2 * t], bf[2 * t + 1]);
-    __syncthreads();  // tail stage (D7 | S0 | S1 | C0 | C1 | C2) resident in buffer 1
+    stage_wait_and_sync();  // tail stage (D7 | S0 | S1 | C0 | C1 | C2) resident in buffer 1
     const unsigned char *tail = s_w[1];
     constexpr int tD7 = 0, tS0 = kBlkS0 - kBlkD7, tS1 = kBlkS1 - kBlkD7, tC0 = kBlkC0 - kBlkD7, tC1 = kBlkC1 - kBlkD7, tC2 = kBlkC2 - kBlkD7;
 

@@ -45,6 +45,11 @@ class FrameGather:
         """image_local [per,3], depth_local [per] of this rank -> full frame [n_rays, 4] (rgb, depth) on every rank."""
         import torch.distributed as dist
         local = torch.cat([image_local, depth_local.unsqueeze(-1)], dim=1).contiguous()
-        dist.all_gather_into_tensor(self.gathered, local)
+        if local.is_cuda and dist.get_backend() == "gloo":  # one-GPU rehearsal only: gloo moves host memory
+            host = torch.empty(self.gathered.shape, dtype=torch.float32)
+            dist.all_gather_into_tensor(host, local.cpu())
+            self.gathered.copy_(host)
+        else:
+            dist.all_gather_into_tensor(self.gathered, local)  # RCCL over xGMI when the backend is "nccl"
         self.frame[self.all_idx] = self.gathered  # padding rows rewrite a pixel with its own value
         return self.frame

@@ -74,9 +74,10 @@ class _grid_encode(Function):
         grad_embeddings = torch.zeros_like(embeddings)
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
         _, off_ptr = _host_offsets(offsets)
-        _check(_lib.sdn_grid_encode_backward(_ptr(grad), _ptr(inputs), off_ptr, _ptr(grad_embeddings), B, D, C, L, S, H, _ptr(dy_dx),
-                                             _ptr(grad_inputs), int(gridtype), int(bool(ctx.align_corners)), int(interpolation),
-                                             _dtype_id(embeddings.dtype), _stream()), "grid_encode_backward")
+        with _sdn.timed("grid_encode_bwd_f16" if embeddings.dtype == torch.float16 else "grid_encode_bwd_f32", B):
+            _check(_lib.sdn_grid_encode_backward(_ptr(grad), _ptr(inputs), off_ptr, _ptr(grad_embeddings), B, D, C, L, S, H, _ptr(dy_dx),
+                                                 _ptr(grad_inputs), int(gridtype), int(bool(ctx.align_corners)), int(interpolation),
+                                                 _dtype_id(embeddings.dtype), _stream()), "grid_encode_backward")
         if dy_dx is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
         return grad_inputs, grad_embeddings, None, None, None, None, None, None, None

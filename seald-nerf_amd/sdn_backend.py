@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsdn_hip.so")
+LIB_PATH = os.environ.get("SDN_LIB_PATH") or os.path.join(_HERE, "lib", "libsdn_hip.so")
 
 SDN_F32 = 0
 SDN_F16 = 1
