@@ -231,6 +231,14 @@ int sdn_render_step_f16(const SdnRenderCtx *ctx, uint32_t bound_alive, void *str
  * a caller can time the dominant kernel in place (bench.py's roofline). */
 int sdn_render_step_f16_ev(const SdnRenderCtx *ctx, uint32_t bound_alive, void *ev_field_begin, void *ev_field_end,
                            void *stream);
+/* Whole frame in one call (begin, iterations until no ray is alive, finish).  This is the one entry point that waits on the
+ * device: after enqueuing iteration k it blocks on the (side-stream, pinned-memory) read-back of iteration k-1's survivor
+ * count, which bounds the grids of iteration k+1 and ends the loop.  ev_main[4] / ev_copy[4]: hipEvent_t created by the
+ * caller; host_snap: 8 ints of pinned host memory; ev_field: NULL or 2 * max_field_events timing events recorded around the
+ * fused-field launches (iteration k uses 2k, 2k+1); iterations_out: step calls enqueued (incl. the trailing no-op). */
+int sdn_render_frame_f16(const SdnRenderCtx *ctx, float bg_color, float *image_out, float *depth_out, void *stream,
+                         void *side_stream, void **ev_main, void **ev_copy, int32_t *host_snap, void **ev_field,
+                         uint32_t max_field_events, uint32_t *iterations_out);
 /* image_out [N,3] = image + (1 - weights_sum) * bg; depth_out [N] = clamp(depth - nears, 0) / (fars - nears). */
 int sdn_render_finish(const SdnRenderCtx *ctx, float bg_color, float *image_out, float *depth_out, void *stream);
 

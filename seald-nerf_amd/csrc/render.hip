@@ -12,6 +12,9 @@
 
 extern "C" {
 
+int sdn_render_finish(const SdnRenderCtx *c, float bg_color, float *image_out, float *depth_out, void *stream);
+int sdn_render_step_f16_ev(const SdnRenderCtx *c, uint32_t bound_alive, void *ev_field_begin, void *ev_field_end, void *stream);
+
 int sdn_render_begin(const SdnRenderCtx *c, void *stream) {
     if (!c || !c->rays_o || !c->rays_d || !c->nears || !c->fars || !c->bitfield || !c->alive_a || !c->alive_b || !c->rays_t ||
         !c->weights_sum || !c->depth || !c->image || !c->state || !c->live_counts || !c->cull_bits)
@@ -23,8 +26,6 @@ int sdn_render_begin(const SdnRenderCtx *c, void *stream) {
     if (c->H == 128 && c->C == 1) rc = sdn_int::build_cull(c->bitfield, (uint32_t *)c->cull_bits, st);
     return rc;
 }
-
-int sdn_render_step_f16_ev(const SdnRenderCtx *c, uint32_t bound_alive, void *ev_field_begin, void *ev_field_end, void *stream);
 
 int sdn_render_step_f16(const SdnRenderCtx *c, uint32_t bound_alive, void *stream) {
     return sdn_render_step_f16_ev(c, bound_alive, nullptr, nullptr, stream);
@@ -51,6 +52,49 @@ int sdn_render_step_f16_ev(const SdnRenderCtx *c, uint32_t bound_alive, void *ev
     return sdn_int::loop_composite_compact(bound_alive, c->T_thresh, c->alive_a, c->alive_b, c->rays_t, c->sigmas, c->rgbs, c->deltas,
                                            c->weights_sum, c->depth, c->image, c->state, (uint32_t *)c->block_totals, c->n_out, c->trace,
                                            c->trace + 2 * (size_t)c->n_counters, st);
+}
+
+// Whole-frame driver: begin + iterations + finish in one call, so the per-iteration host work is a handful of HIP API
+// calls in C (a Python loop costs 100-250 us per iteration on a slow host core, more than the GPU needs for the iteration).
+// The loop record's snapshot is copied to pinned host memory on `side_stream` behind an event, so the main stream never
+// waits for the host; the host waits for the snapshot of iteration k-1 after it has enqueued iteration k.
+//   ev_main[4], ev_copy[4]: caller-created hipEvent_t (no timing needed); host_snap: pinned, 8 ints (4 x {n_alive, call});
+//   ev_field: NULL or 2 * max_field_events hipEvent_t with timing enabled, recorded around the fused-field launches
+//   (pairs 2k, 2k+1 for iteration k; iterations beyond max_field_events are not timed);
+//   iterations_out: number of step calls enqueued (including the trailing no-op one).
+int sdn_render_frame_f16(const SdnRenderCtx *c, float bg_color, float *image_out, float *depth_out, void *stream, void *side_stream,
+                         void **ev_main, void **ev_copy, int32_t *host_snap, void **ev_field, uint32_t max_field_events,
+                         uint32_t *iterations_out) {
+    if (!c || !image_out || !depth_out || !side_stream || !ev_main || !ev_copy || !host_snap) return SDN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream, side = (hipStream_t)side_stream;
+    int rc = sdn_render_begin(c, stream);
+    if (rc) return rc;
+    const int32_t *snap_dev = c->trace + 2 * (size_t)c->n_counters;
+    uint32_t bound = c->N, it = 0;
+    for (;;) {
+        void *e0 = (ev_field && it < max_field_events) ? ev_field[2 * it] : nullptr;
+        void *e1 = (ev_field && it < max_field_events) ? ev_field[2 * it + 1] : nullptr;
+        rc = sdn_render_step_f16_ev(c, bound, e0, e1, stream);
+        if (rc) return rc;
+        const uint32_t slot = it & 3u;
+        hipError_t e = hipEventRecord((hipEvent_t)ev_main[slot], st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(side, (hipEvent_t)ev_main[slot], 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(host_snap + 2 * slot, snap_dev + 2 * slot, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, side);
+        if (e == hipSuccess) e = hipEventRecord((hipEvent_t)ev_copy[slot], side);
+        if (e != hipSuccess) return (int)e;
+        if (it >= 1) {
+            const uint32_t prev = (it - 1) & 3u;
+            e = hipEventSynchronize((hipEvent_t)ev_copy[prev]);
+            if (e != hipSuccess) return (int)e;
+            const int32_t n_prev = host_snap[2 * prev];  // alive rays entering iteration `it` (already enqueued)
+            if (n_prev <= 0) break;
+            bound = (uint32_t)n_prev;
+        }
+        it++;
+        if (it > c->max_steps + 1) break;
+    }
+    if (iterations_out) *iterations_out = it + 1;
+    return sdn_render_finish(c, bg_color, image_out, depth_out, stream);
 }
 
 int sdn_render_finish(const SdnRenderCtx *c, float bg_color, float *image_out, float *depth_out, void *stream) {

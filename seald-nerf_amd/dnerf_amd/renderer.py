@@ -411,6 +411,7 @@ class DeviceLoop:
     pinned memory) one iteration earlier, which is an upper bound of the current one.  Requires the fused field."""
 
     RING = 4
+    MAX_TIMED = 24  # iterations whose fused-field launch can be timed in place (the headline frame has 11 + 1)
 
     def __init__(self, model, field, N, device, max_steps=1024, T_thresh=1e-2, dt_gamma=0.0):
         import ctypes
@@ -432,6 +433,8 @@ class DeviceLoop:
         self.events = [torch.cuda.Event() for _ in range(self.RING)]
         self.copy_events = [torch.cuda.Event() for _ in range(self.RING)]
         self.side = torch.cuda.Stream(device=device)
+        self._handles = None
+        self._timing_queue = []
         c = SdnRenderCtx()
         for k, v in self.buf.items():
             setattr(c, k, v.data_ptr())
@@ -442,6 +445,22 @@ class DeviceLoop:
         c.bound, c.dt_gamma, c.T_thresh, c.density_scale = float(model.bound), float(dt_gamma), float(T_thresh), float(model.density_scale)
         self.ctx = c
         self.max_steps = int(max_steps)
+
+    def prepare_timing(self, frames):
+        """Pre-creates (outside any timed region) the HIP event pairs for `frames` timed renders: MAX_TIMED pairs per frame,
+        recorded by the native loop around each fused-field launch."""
+        import ctypes
+        cur = torch.cuda.current_stream()
+        self._timing_queue = []
+        for _ in range(frames):
+            recs = []
+            for _ in range(self.MAX_TIMED):
+                s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_.record(cur); e_.record(cur)  # materialises the handles; the native call re-records them in place
+                recs.append((s_, e_, 0))
+            arr = (ctypes.c_void_p * (2 * self.MAX_TIMED))(*[h for r in recs for h in (r[0].cuda_event, r[1].cuda_event)])
+            self._timing_queue.append((arr, recs))
+        torch.cuda.synchronize()
 
     @torch.no_grad()
     def render(self, rays_o, rays_d, time, bg_color=1.0, want_stats=True):
@@ -458,33 +477,24 @@ class DeviceLoop:
         c.field_bias0, c.zero_deform = self.field.bias0.data_ptr(), int(self.field.zero_deform)
         st = stream()
         cref = ctypes.byref(c)
-        check(lib.sdn_render_begin(cref, st), "render_begin")
-        bound, it = self.N, 0
         cur = torch.cuda.current_stream()
-        while True:
-            if sdn_backend.timers is not None:  # bench: time the fused-field launch in place
-                e0, e1 = sdn_backend.timers.raw_pair("field_forward_f16", 0)
-                check(lib.sdn_render_step_f16_ev(cref, bound, e0, e1, st), "render_step_f16")
-            else:
-                check(lib.sdn_render_step_f16(cref, bound, st), "render_step_f16")
-            slot = it % self.RING
-            # read the iteration's snapshot back on a side stream: the main stream goes straight on to the next iteration
-            self.events[slot].record(cur)
-            with torch.cuda.stream(self.side):
-                self.side.wait_event(self.events[slot])
-                self.host_state[slot].copy_(self.snap[slot], non_blocking=True)
-                self.copy_events[slot].record(self.side)
-            if it >= 1:
-                prev = (it - 1) % self.RING
-                self.copy_events[prev].synchronize()
-                n_prev = int(self.host_state[prev][0])  # alive rays entering iteration `it` (already enqueued)
-                if n_prev == 0:
-                    break
-                bound = n_prev
-            it += 1
-            if it > self.max_steps + 1:
-                break
-        check(lib.sdn_render_finish(cref, float(bg_color), ptr(self.image_out), ptr(self.depth_out), st), "render_finish")
+        if self._handles is None:  # materialise raw hipEvent_t / hipStream_t handles once
+            for e in self.events + self.copy_events:
+                e.record(cur)
+            self._ev_main = (ctypes.c_void_p * self.RING)(*[e.cuda_event for e in self.events])
+            self._ev_copy = (ctypes.c_void_p * self.RING)(*[e.cuda_event for e in self.copy_events])
+            self._iters = ctypes.c_uint32(0)
+            self._handles = True
+        ev_field, n_ev, recs = None, 0, None
+        if sdn_backend.timers is not None and self._timing_queue:  # bench: time the fused-field launches in place
+            ev_field, recs = self._timing_queue.pop()
+            n_ev = self.MAX_TIMED
+        self.side.wait_stream(cur)
+        check(lib.sdn_render_frame_f16(cref, float(bg_color), ptr(self.image_out), ptr(self.depth_out), st, self.side.cuda_stream,
+                                       self._ev_main, self._ev_copy, self.host_state.data_ptr(), ev_field, n_ev,
+                                       ctypes.byref(self._iters)), "render_frame_f16")
+        if recs is not None:  # keep the pairs of the iterations that ran
+            sdn_backend.timers.records.setdefault("field_forward_f16", []).extend(recs[: min(n_ev, int(self._iters.value))])
         out = {"image": self.image_out, "depth": self.depth_out, "weights_sum": self.buf["weights_sum"], "nears": nears, "fars": fars}
         if want_stats:
             iters = int(self.buf["state"][3].item())

@@ -43,6 +43,7 @@ PROTOTYPES = {
     "sdn_render_step_f16": [_vp, _u32, _vp],
     "sdn_render_step_f16_ev": [_vp, _u32, _vp, _vp, _vp],
     "sdn_render_finish": [_vp, _f32, _vp, _vp, _vp],
+    "sdn_render_frame_f16": [_vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     "sdn_field_forward_f16": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _f32, _u32, _f32, _f32, _i32, _vp, _vp, _vp],
 }
 class SdnRenderCtx(ctypes.Structure):
