@@ -922,6 +922,19 @@ int loop_composite_compact(uint32_t bound_alive, float T_thresh, int32_t *alive_
                            const float *rgbs, const float *deltas, float *weights_sum, float *depth, float *image, int32_t *state,
                            uint32_t *block_totals, int32_t *n_out, int32_t *trace, int32_t *snap, hipStream_t st) {
     const dim3 g(sdn_div_up(bound_alive, 256u)), b(256);
+    if (bound_alive > 65536u) {
+        // many rays (the first one or two iterations): every scatter workgroup would re-sum thousands of 256-ray totals;
+        // use the 1024-ray count / scatter pair and a separate one-thread advance instead
+        hipLaunchKernelGGL(k_composite_rays, g, b, 0, st, 0u, 0u, T_thresh, alive_a, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
+                           (const int32_t *)state, alive_b, (uint32_t *)nullptr);
+        const uint32_t nb = sdn_div_up(bound_alive, kScanBlock);
+        hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(kScanBlock), 0, st, (const int32_t *)alive_a, 0u, block_totals,
+                           (const int32_t *)state, (const int32_t *)alive_b);
+        hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(kScanBlock), 0, st, (const int32_t *)alive_a, 0u, (const uint32_t *)block_totals,
+                           alive_b, snap + 8, (const int32_t *)state, (const int32_t *)alive_b, alive_a);
+        hipLaunchKernelGGL(k_loop_advance, dim3(1), dim3(64), 0, st, state, (const int32_t *)(snap + 8), trace, snap);
+        return sdn_launch_status();
+    }
     hipLaunchKernelGGL(k_composite_rays, g, b, 0, st, 0u, 0u, T_thresh, alive_a, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
                        (const int32_t *)state, alive_b, block_totals);
     // n_out doubles as the ticket counter (zero between launches)
