@@ -11,7 +11,8 @@
 // round-tripping [M,128] activations through HBM.  Here it is ONE launch and activations never leave registers.
 //
 // Mapping (see DESIGN.md "fused field kernel"):
-//   * workgroup = 6 waves = 192 sample points (two workgroups per CU: 3 waves per SIMD, <= 168 VGPRs); one wave = 32 points = the N dimension of
+//   * workgroup = 8 waves = 256 sample points (two workgroups per CU: 4 waves per SIMD, <= 128 VGPRs -- measured faster
+//     than 6-wave workgroups at 3 waves per SIMD with deeper LDS prefetch: occupancy wins); one wave = 32 points = the N dimension of
 //     v_mfma_f32_32x32x16_f16.  Weights are the A operand (M = output features), activations the B operand
 //     (K = input features).  The accumulator of layer i (feature rows in registers, point on the lane) converts
 //     in place (ReLU, cvt_pk_f16) into the B operand of layer i+1 -- no cross-lane traffic between layers.  The
@@ -22,7 +23,7 @@
 //     (D0 16 KiB | D1..D6 32 KiB each | D7+S0+S1+C0+C1+C2 32 KiB) with direct-to-LDS loads
 //     (global_load_lds_dwordx4), double-buffered, one barrier per stage: stage s+1 lands while stage s feeds
 //     the MFMAs through conflict-free ds_read_b128 (lane-linear fragments).  HBM/L2 sees each weight byte once
-//     per 192 points instead of once per 32.
+//     per 256 points instead of once per 32.
 //   * the time encoding is the same for every point: its contribution W0[:,63:76] . enc(t) is a per-frame
 //     bias vector (computed on the host) loaded as the initial accumulator of the first layer.
 //   * the 128 table gathers per point are split over the two lane-halves (levels 0-7 / 8-15); row strides,
@@ -53,7 +54,7 @@ constexpr int kBlkTotal = kBlkC2 + 4;     // 240
 static_assert(kBlkTotal - kBlkD7 == 32, "the tail stage must be exactly one 32 KiB buffer");
 
 constexpr int kStageBytes = 32768;
-constexpr int kWaves = 6;                 // waves per workgroup, 32 points each; two workgroups per CU = 3 waves per SIMD
+constexpr int kWaves = 8;                 // waves per workgroup, 32 points each; two workgroups per CU = 4 waves per SIMD
 constexpr int kPointsPerWG = 32 * kWaves;
 
 // tiled-grid level constants (D = 3, align_corners = false), host-precomputed: gridencoder.cu:66-84,138-139
@@ -153,7 +154,7 @@ __device__ __forceinline__ half8 lds_frag(const unsigned char *buf, int blk, uin
     return *reinterpret_cast<const half8 *>(buf + (size_t)blk * 1024 + lane * 16);
 }
 
-__global__ void __launch_bounds__(64 * kWaves, 3) k_field_f16(FieldArgs P, TiledLevels lv) {
+__global__ void __launch_bounds__(64 * kWaves, 4) k_field_f16(FieldArgs P, TiledLevels lv) {
     __shared__ __attribute__((aligned(16))) unsigned char s_w[2][kStageBytes];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t count = P.state ? P.live_count[P.state[3]] : (P.live_idx ? *P.live_count : P.M);
@@ -218,32 +219,22 @@ __global__ void __launch_bounds__(64 * kWaves, 3) k_field_f16(FieldArgs P, Tiled
         stage_wait_and_sync();  // stage l+1 landed for everyone; everyone is done reading the other buffer (layer l)
         // refill the other buffer with stage l+2 (D(l+2) for l < 5, the tail stage for l == 5); it lands under this layer's MFMAs
         stage_load(P.weights + (size_t)(l < 5 ? kBlkD1 + (l + 1) * 32 : kBlkD7) * 1024, s_w[l & 1], kStageBytes, wave, lane);
-        // software pipeline over the 8 k-steps: the four A fragments of step ks+1 are read from LDS while the four MFMAs of
-        // step ks execute (an LDS read issued right in front of its MFMA exposes ~100 cycles of latency per MFMA)
-        half8 a_cur[4], a_nxt[4];
-        #pragma unroll
-        for (int mt = 0; mt < 4; mt++) a_cur[mt] = lds_frag(cur, mt * 8, lane);
+        // (a software-pipelined variant -- fragments of k-step ks+1 read while the MFMAs of ks run -- needs 32 more VGPRs,
+        // i.e. 3 waves per SIMD instead of 4, and measured 20 % slower: latency is hidden by occupancy here)
         #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
-            if (ks < 7) {
-                #pragma unroll
-                for (int mt = 0; mt < 4; mt++) a_nxt[mt] = lds_frag(cur, mt * 8 + ks + 1, lane);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // keep the four reads of step ks+1 in front of the MFMAs of step ks
             #pragma unroll
             for (int mt = 0; mt < 4; mt++) {
+                const half8 a = lds_frag(cur, mt * 8 + ks, lane);
                 if (ks == 0) {
                     f32x16 z;
                     #pragma unroll
                     for (int r = 0; r < 16; r++) z[r] = 0.0f;
-                    acc[mt] = mfma(a_cur[mt], bf[0], z);
+                    acc[mt] = mfma(a, bf[0], z);
                 } else {
-                    acc[mt] = mfma(a_cur[mt], bf[ks], acc[mt]);
+                    acc[mt] = mfma(a, bf[ks], acc[mt]);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            #pragma unroll
-            for (int mt = 0; mt < 4; mt++) a_cur[mt] = a_nxt[mt];
         }
     }
     #pragma unroll
