@@ -247,6 +247,11 @@ def roofline(timers, fp16, n_samples, n_iters, steps):
         roof = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": None, "flop_per_point": FIELD_FLOP_PER_POINT,
                 "avg_launch_ms": s["avg_ms"], "avg_points_per_launch": s["avg_units"]}
+        pmc = os.path.join(ROOT, "profiles", "r01_field_pmc_summary.json")
+        if os.path.exists(pmc):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, raw)
+            f = json.load(open(pmc))["field_forward_f16"]
+            roof["traffic"] = (f["fetch_bytes_per_frame_raw"] + f["write_bytes_per_frame"]) * steps / s["launches"]
+            roof["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/r01_field_pmc_summary.json)"
     return roof, summ
 
 
