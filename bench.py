@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--fp32", action="store_true", help="fp32 field network instead of the -O (fp16) configuration")
     ap.add_argument("--field", default="auto", choices=["auto", "ops", "fused"], help="field network implementation")
     ap.add_argument("--loop", default="auto", choices=["auto", "host", "device"], help="loop driver: per-iteration host sync, or device-driven")
+    ap.add_argument("--groups", type=int, default=1, help="device loop only: render the frame as G interleaved ray groups on G streams")
     ap.add_argument("--mode", default="render", choices=["render", "train"],
                     help="render: the headline 800x800 inference frame; train: one dnerf training step on 4096 rays (BASELINE config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -153,12 +154,17 @@ def main():
         loop_kind = "device" if field is not None else "host"
     dloop = None
     if loop_kind == "device":
-        from dnerf_amd.renderer import DeviceLoop
-        dloop = DeviceLoop(sc.model, field, n_local, dev)
+        from dnerf_amd.renderer import DeviceLoop, GroupedDeviceLoop
+        if args.groups > 1:
+            dloop = GroupedDeviceLoop(sc.model, field, rays_o, rays_d, args.groups, args.size, dev)
+        else:
+            dloop = DeviceLoop(sc.model, field, n_local, dev)
 
     def step(count=False, timed=False):
         sdn_backend.timers = timers if timed else None  # HIP events around the tracked launches, timed steps only
-        if dloop is not None:
+        if dloop is not None and args.groups > 1:
+            out = dloop.render(sc.time, want_stats=count)
+        elif dloop is not None:
             out = dloop.render(rays_o, rays_d, sc.time, want_stats=count)
         else:
             out = render_frame(sc.model, rays_o, rays_d, sc.time, fp16=fp16, workspace=ws, field=field, count_samples=count)
@@ -209,7 +215,7 @@ def main():
                                f"{'-O (fp16 field network, fp16 grid table)' if fp16 else 'fp32'}, 1 timestep (t=0.5), "
                                f"T_thresh 1e-2, max_steps 1024, dt_gamma 0",
                    "rays": n_total, "sampled_points_per_frame": n_samples, "loop_iterations": n_iters,
-                   "field": field_kind, "loop": loop_kind, "parallelism": (f"ray-tiles x{world}" + (" (ONE-GPU REHEARSAL, numbers invalid)" if rehearse else "")) if world > 1 else "single GPU"},
+                   "field": field_kind, "loop": loop_kind, "ray_groups": args.groups, "parallelism": (f"ray-tiles x{world}" + (" (ONE-GPU REHEARSAL, numbers invalid)" if rehearse else "")) if world > 1 else "single GPU"},
     }
     if rank == 0:
         result["roofline"], result["kernel_times"] = roofline(timers, fp16, n_samples_local, n_iters, args.steps)

@@ -502,3 +502,61 @@ class DeviceLoop:
             out["trace"] = [(a, s, a * s + (128 - (a * s) % 128)) for a, s in tr]
             out["n_samples"] = int(self.buf["live_counts"][:iters].sum().item())
         return out
+
+
+class GroupedDeviceLoop:
+    """G independent device-driven loops over disjoint, interleaved subsets of the frame's rays, each on its own HIP stream
+    and driven by its own host thread (the native frame driver releases the GIL), so that the latency-bound phases of one
+    group (the marcher's dependent probe chains, launch / read-back gaps) overlap with the throughput-bound field kernel of
+    another.  Exact by construction: per-ray results do not depend on which rays share a launch; only the
+    per-group n_step schedule -- hence the number of samples marched past a ray's termination -- can differ from the
+    one-group schedule when N_g // n_alive_g falls on the other side of an integer than N // n_alive."""
+
+    def __init__(self, model, field, rays_o, rays_d, groups, W, device, **kw):
+        from concurrent.futures import ThreadPoolExecutor
+        from .dist import shard_rays
+        N = rays_o.shape[0]
+        self.N, self.G, self.device = N, groups, device
+        self.idx, self.rays, self.loops, self.streams = [], [], [], []
+        for g in range(groups):
+            idx, _ = shard_rays(N, W, g, groups)
+            idx = torch.from_numpy(np.unique(idx)).to(device)  # no padding needed on one GPU
+            self.idx.append(idx)
+            self.rays.append((rays_o[idx].contiguous(), rays_d[idx].contiguous()))
+            self.loops.append(DeviceLoop(model, field, idx.shape[0], device, **kw))
+            self.streams.append(torch.cuda.Stream(device=device))
+        self.image = torch.empty(N, 3, dtype=torch.float32, device=device)
+        self.depth = torch.empty(N, dtype=torch.float32, device=device)
+        self.pool = ThreadPoolExecutor(max_workers=groups)
+
+    def prepare_timing(self, frames):
+        for lp in self.loops:
+            lp.prepare_timing(frames)
+
+    def _one(self, g, time, bg_color, want_stats, timers):
+        import sdn_backend
+        torch.cuda.set_device(self.device)
+        with torch.cuda.stream(self.streams[g]):
+            sdn_backend.timers = timers  # module-global, set identically by every worker
+            out = self.loops[g].render(self.rays[g][0], self.rays[g][1], time, bg_color=bg_color, want_stats=want_stats)
+            self.image[self.idx[g]] = out["image"]
+            self.depth[self.idx[g]] = out["depth"]
+        return out
+
+    @torch.no_grad()
+    def render(self, time, bg_color=1.0, want_stats=True):
+        import sdn_backend
+        cur = torch.cuda.current_stream()
+        for st in self.streams:
+            st.wait_stream(cur)
+        timers = sdn_backend.timers
+        futs = [self.pool.submit(self._one, g, time, bg_color, want_stats, timers) for g in range(self.G)]
+        outs = [f.result() for f in futs]
+        for st in self.streams:
+            cur.wait_stream(st)
+        res = {"image": self.image, "depth": self.depth}
+        if want_stats:
+            res["n_samples"] = sum(o["n_samples"] for o in outs)
+            res["trace"] = max((o["trace"] for o in outs), key=len)
+            res["group_traces"] = [o["trace"] for o in outs]
+        return res
