@@ -197,8 +197,8 @@ int sdn_field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *
  * ------------------------------------------------------------------------- */
 /* All pointers are device pointers owned by the caller except grid_offsets (17 host ints, copied by value).
  * Buffer sizes: per-ray arrays N; sample arrays M_cap >= N + 128 rows; live_counts n_counters >= max_steps + 8;
- * trace 2 * n_counters + 16 (ints 2 * n_counters .. +8 are a 4-deep ring of {alive rays entering the next iteration, iteration
- * number} snapshots for asynchronous read-back, the int after them a survivor-count scratch word); block_totals ceil(N / 256) + 1; n_out 1 int, zero on entry (ticket counter); cull_bits sdn_cull_grid_bytes(); state 8 ints. */
+ * state 16 ints; trace 2 * n_counters + 16 (ints 2 * n_counters .. +8 are a 4-deep ring of {alive rays entering the next iteration, iteration
+ * number} snapshots for asynchronous read-back, the int after them a survivor-count scratch word); block_totals ceil(N / 256) + 1; n_out 1 int, zero on entry (ticket counter); cull_bits sdn_cull_grid_bytes(). */
 typedef struct SdnRenderCtx {
     const float *rays_o, *rays_d, *nears, *fars;
     const uint8_t *bitfield;

@@ -538,6 +538,125 @@ __global__ void __launch_bounds__(256) k_composite_train_bwd(const float *__rest
 //   * cull: exact early-out for rays that cannot produce a sample (see ray_may_hit);
 //   * live_idx / live_count: the slots that received a sample are appended (one atomicAdd per wave, ballot-free prefix
 //     via wave shuffles) to a compact list so that the field network is evaluated on samples, not on padded slots.
+// LDS-resident occupancy caches of the marching kernels (FAST configuration with a cull grid only)
+struct OccCache {
+    const uint32_t *s_cull = nullptr;            // 32^3 mark bits
+    const unsigned long long *fine = nullptr;    // fine bits of the marked bounding box (one word = 4x4x4 voxels)
+    int fx0 = 0, fy0 = 0, fz0 = 0, fnx = 0, fny = 0;
+};
+
+// Cooperative load by a 256-thread workgroup; contains a barrier, so every thread of the workgroup must call it.
+template <bool FAST>
+__device__ __forceinline__ void occ_cache_load(const uint32_t *__restrict__ cull, const uint8_t *__restrict__ grid, uint4 *s_cull4,
+                                               unsigned long long *s_fine, OccCache &oc) {
+    if constexpr (FAST) {
+        if (cull) {  // kernel-uniform
+            s_cull4[threadIdx.x] = reinterpret_cast<const uint4 *>(cull)[threadIdx.x];
+            const int *meta = reinterpret_cast<const int *>(cull + kCullWords);
+            oc.fx0 = meta[0]; oc.fy0 = meta[1]; oc.fz0 = meta[2];
+            oc.fnx = meta[3] - oc.fx0 + 1; oc.fny = meta[4] - oc.fy0 + 1;
+            const int fnz = meta[5] - oc.fz0 + 1;
+            if (oc.fnx > 0 && oc.fny > 0 && fnz > 0 && (uint32_t)(oc.fnx * oc.fny * fnz) <= kFineCacheCells) {
+                const unsigned long long *__restrict__ blocks = reinterpret_cast<const unsigned long long *>(grid);
+                const int cells = oc.fnx * oc.fny * fnz;
+                for (int i = (int)threadIdx.x; i < cells; i += 256) {
+                    const int cx = oc.fx0 + i % oc.fnx, cy = oc.fy0 + (i / oc.fnx) % oc.fny, cz = oc.fz0 + i / (oc.fnx * oc.fny);
+                    s_fine[i] = blocks[morton3D_8bit((uint32_t)cx, (uint32_t)cy, (uint32_t)cz)];
+                }
+                oc.fine = s_fine;
+            }
+            __syncthreads();
+            oc.s_cull = reinterpret_cast<const uint32_t *>(s_cull4);
+        }
+    }
+}
+
+// Marches one ray from parameter t for up to n_step samples into its slots (the loop of raymarching.cu:750-804), zero-fills
+// the unused slots and returns the number of samples written.
+template <bool FAST>
+__device__ __forceinline__ uint32_t march_ray(MarcherT<FAST> &m, const OccCache &oc, float t, float far, uint32_t n_step, float *px, float *pd,
+                                              float *pl) {
+    m.fine = oc.fine; m.fx0 = oc.fx0; m.fy0 = oc.fy0; m.fz0 = oc.fz0; m.fnx = oc.fnx; m.fny = oc.fny;
+    uint32_t step = 0;
+    float last_t = t, x, y, z, dt;
+    bool go = t < far;
+    float t_end = far;
+    if (FAST && oc.s_cull && go) go = ray_may_hit(oc.s_cull, m.ox, m.oy, m.oz, m.dx, m.dy, m.dz, t, far, t_end);
+    if (go) {
+        while (t < far && t < t_end && step < n_step) {
+            if (m.probe(t, x, y, z, dt, oc.s_cull)) {
+                px[0] = x; px[1] = y; px[2] = z;
+                pd[0] = m.dx; pd[1] = m.dy; pd[2] = m.dz;
+                t += dt;
+                pl[0] = dt;
+                pl[1] = t - last_t;
+                last_t = t;
+                px += 3; pd += 3; pl += 2;
+                step++;
+            }
+        }
+    }
+    for (uint32_t k = step; k < n_step; k++) {
+        px[0] = 0; px[1] = 0; px[2] = 0;
+        pd[0] = 0; pd[1] = 0; pd[2] = 0;
+        pl[0] = 0; pl[1] = 0;
+        px += 3; pd += 3; pl += 2;
+    }
+    return step;
+}
+
+// Appends the slots n*n_step .. +step of every lane to the live list: one atomicAdd per wave, prefix by wave shuffles.
+// Must be called by all 64 lanes of the wave.
+__device__ __forceinline__ void live_append(uint32_t step, uint32_t n, uint32_t n_step, uint32_t *__restrict__ live_idx,
+                                            uint32_t *__restrict__ live_count) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t incl = step;
+    #pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(incl, off, 64);
+        if (lane >= (uint32_t)off) incl += u;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    uint32_t base = 0;
+    if (lane == 63 && total) base = atomicAdd(live_count, total);
+    base = __shfl(base, 63, 64);
+    const uint32_t dst = base + incl - step;
+    for (uint32_t k = 0; k < step; k++) live_idx[dst + k] = n * n_step + k;
+}
+
+// Resumes the compositing of one ray over its n_step slots (raymarching.cu:845-904).  Returns true if the ray survives.
+__device__ __forceinline__ bool composite_ray(int index, uint32_t n_step, float T_thresh, const float *s, const float *c, const float *dl,
+                                              float *__restrict__ rays_t, float *__restrict__ weights_sum, float *__restrict__ depth,
+                                              float *__restrict__ image) {
+    float t = rays_t[index];
+    float weight_sum = weights_sum[index], d = depth[index];
+    float r = image[(size_t)index * 3], g = image[(size_t)index * 3 + 1], b = image[(size_t)index * 3 + 2];
+    uint32_t step = 0;
+    while (step < n_step) {
+        if (dl[0] == 0) break;
+        const float alpha = 1.0f - sdn_exp_cr(-s[0] * dl[0]);
+        const float T = 1 - weight_sum;
+        const float weight = alpha * T;
+        weight_sum += weight;
+        t += dl[1];
+        d += weight * t;
+        r += weight * c[0]; g += weight * c[1]; b += weight * c[2];
+        if (T < T_thresh) break;
+        s++; c += 3; dl += 2; step++;
+    }
+    const bool survives = !(step < n_step);
+    if (survives) rays_t[index] = t;
+    weights_sum[index] = weight_sum; depth[index] = d;
+    image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
+    return survives;
+}
+
+// raymarching.cu:701-805.  Extras over the reference kernel (all optional, none changes a sample):
+//   * slots [step, n_step) of each alive ray are written as zeros here and the alignment tail [n_alive*n_step, M_pad)
+//     is cleared by the same launch, so the caller never memsets the sample buffers;
+//   * cull: exact early-out for rays that cannot produce a sample (see ray_may_hit), LDS occupancy caches;
+//   * live_idx / live_count: the slots that received a sample are appended to a compact list so that the field network is
+//     evaluated on samples, not on padded slots.
 template <bool FAST>
 __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
                                                     const float *__restrict__ rays_t, const float *__restrict__ rays_o,
@@ -558,66 +677,19 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
         M_pad = m0 + (128u - m0 % 128u);
     }
     __shared__ uint4 s_cull4[FAST ? 256 : 1];  // 32^3 bits = 4 KiB
-    __shared__ unsigned long long s_fine[FAST ? kFineCacheCells : 1];  // fine bits of the marked bounding box, <= 32 KiB
-    const uint32_t *s_cull = nullptr;
-    const unsigned long long *fine = nullptr;
-    int fx0 = 0, fy0 = 0, fz0 = 0, fnx = 0, fny = 0;
-    if constexpr (FAST) {
-        if (cull) {  // kernel-uniform
-            s_cull4[threadIdx.x] = reinterpret_cast<const uint4 *>(cull)[threadIdx.x];
-            const int *meta = reinterpret_cast<const int *>(cull + kCullWords);
-            fx0 = meta[0]; fy0 = meta[1]; fz0 = meta[2];
-            fnx = meta[3] - fx0 + 1; fny = meta[4] - fy0 + 1;
-            const int fnz = meta[5] - fz0 + 1;
-            if (fnx > 0 && fny > 0 && fnz > 0 && (uint32_t)(fnx * fny * fnz) <= kFineCacheCells) {
-                const unsigned long long *__restrict__ blocks = reinterpret_cast<const unsigned long long *>(grid);
-                const int cells = fnx * fny * fnz;
-                for (int i = (int)threadIdx.x; i < cells; i += 256) {
-                    const int cx = fx0 + i % fnx, cy = fy0 + (i / fnx) % fny, cz = fz0 + i / (fnx * fny);
-                    s_fine[i] = blocks[morton3D_8bit((uint32_t)cx, (uint32_t)cy, (uint32_t)cz)];
-                }
-                fine = s_fine;
-            }
-            __syncthreads();
-            s_cull = reinterpret_cast<const uint32_t *>(s_cull4);
-        }
-    }
+    __shared__ unsigned long long s_fine[FAST ? kFineCacheCells : 1];  // <= 32 KiB
+    OccCache oc;
+    occ_cache_load<FAST>(cull, grid, s_cull4, s_fine, oc);
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
-    const uint32_t lane = threadIdx.x & 63u;
     uint32_t step = 0;
     if (n < n_alive) {
         const int index = rays_alive[n];
         MarcherT<FAST> m;
         m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid);
-        m.fine = fine; m.fx0 = fx0; m.fy0 = fy0; m.fz0 = fz0; m.fnx = fnx; m.fny = fny;
-        float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3, *pl = deltas + (size_t)n * n_step * 2;
         float t = rays_t[index];
-        const float far = fars[index];
         t += m.step_size(t) * (noises ? noises[n] : 0.0f);
-        float last_t = t, x, y, z, dt;
-        bool go = t < far;
-        float t_end = far;
-        if (FAST && s_cull && go) go = ray_may_hit(s_cull, m.ox, m.oy, m.oz, m.dx, m.dy, m.dz, t, far, t_end);
-        if (go) {
-            while (t < far && t < t_end && step < n_step) {
-                if (m.probe(t, x, y, z, dt, s_cull)) {
-                    px[0] = x; px[1] = y; px[2] = z;
-                    pd[0] = m.dx; pd[1] = m.dy; pd[2] = m.dz;
-                    t += dt;
-                    pl[0] = dt;
-                    pl[1] = t - last_t;
-                    last_t = t;
-                    px += 3; pd += 3; pl += 2;
-                    step++;
-                }
-            }
-        }
-        for (uint32_t k = step; k < n_step; k++) {
-            px[0] = 0; px[1] = 0; px[2] = 0;
-            pd[0] = 0; pd[1] = 0; pd[2] = 0;
-            pl[0] = 0; pl[1] = 0;
-            px += 3; pd += 3; pl += 2;
-        }
+        step = march_ray<FAST>(m, oc, t, fars[index], n_step, xyzs + (size_t)n * n_step * 3, dirs + (size_t)n * n_step * 3,
+                               deltas + (size_t)n * n_step * 2);
     } else {
         const uint32_t slot = n_alive * n_step + (n - n_alive);  // spare lanes of the last blocks clear the alignment tail
         if (slot < M_pad) {
@@ -626,20 +698,7 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
             deltas[(size_t)slot * 2] = 0; deltas[(size_t)slot * 2 + 1] = 0;
         }
     }
-    if (live_idx) {  // kernel-uniform
-        uint32_t incl = step;
-        #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t u = __shfl_up(incl, off, 64);
-            if (lane >= (uint32_t)off) incl += u;
-        }
-        const uint32_t total = __shfl(incl, 63, 64);
-        uint32_t base = 0;
-        if (lane == 63 && total) base = atomicAdd(live_count, total);
-        base = __shfl(base, 63, 64);
-        uint32_t dst = base + incl - step;
-        for (uint32_t k = 0; k < step; k++) live_idx[dst + k] = n * n_step + k;
-    }
+    if (live_idx) live_append(step, n, n_step, live_idx, live_count);  // kernel-uniform condition
 }
 
 // raymarching.cu:819-905
@@ -658,27 +717,9 @@ __global__ void __launch_bounds__(256) k_composite_rays(uint32_t n_alive, uint32
     bool survives = false;
     if (n < n_alive) {
         const int index = rays_alive[n];
-        const float *s = sigmas + (size_t)n * n_step, *c = rgbs + (size_t)n * n_step * 3, *dl = deltas + (size_t)n * n_step * 2;
-        float t = rays_t[index];
-        float weight_sum = weights_sum[index], d = depth[index];
-        float r = image[(size_t)index * 3], g = image[(size_t)index * 3 + 1], b = image[(size_t)index * 3 + 2];
-        uint32_t step = 0;
-        while (step < n_step) {
-            if (dl[0] == 0) break;
-            const float alpha = 1.0f - sdn_exp_cr(-s[0] * dl[0]);
-            const float T = 1 - weight_sum;
-            const float weight = alpha * T;
-            weight_sum += weight;
-            t += dl[1];
-            d += weight * t;
-            r += weight * c[0]; g += weight * c[1]; b += weight * c[2];
-            if (T < T_thresh) break;
-            s++; c += 3; dl += 2; step++;
-        }
-        if (step < n_step) rays_alive[n] = -1;
-        else { rays_t[index] = t; survives = true; }
-        weights_sum[index] = weight_sum; depth[index] = d;
-        image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
+        survives = composite_ray(index, n_step, T_thresh, sigmas + (size_t)n * n_step, rgbs + (size_t)n * n_step * 3,
+                                 deltas + (size_t)n * n_step * 2, rays_t, weights_sum, depth, image);
+        if (!survives) rays_alive[n] = -1;
     }
     if (block_totals) {  // kernel-uniform: survivor count of this 256-ray block, for the fused compaction of the device loop
         __shared__ uint32_t s_cnt[4];
@@ -774,6 +815,7 @@ __global__ void __launch_bounds__(256) k_loop_init(uint32_t N, uint32_t max_step
     if (n == 0) {
         state[0] = (int32_t)N; state[1] = 1; state[2] = 0; state[3] = 0; state[4] = 0;
         state[5] = (int32_t)N; state[6] = (int32_t)max_steps; state[7] = 0;
+        for (int k = 8; k < 16; k++) state[k] = 0;  // [8] frozen list length of the steady mode, [9] survivor accumulator
     }
 }
 
@@ -876,6 +918,87 @@ __global__ void __launch_bounds__(256) k_scatter_advance(int32_t *__restrict__ a
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// steady mode of the device loop: once n_alive <= N / 8 the schedule is n_step = 8 for good (n_alive only shrinks), so
+// compositing iteration k and marching iteration k+1 of the same ray can be ONE kernel, and the alive list need not be
+// compacted any more (dead entries are skipped; the field network only sees live samples through the live list).
+// Two launches per iteration (fused field, composite+march) instead of five.  Samples, schedule and counts are unchanged.
+// ---------------------------------------------------------------------------
+__global__ void k_steady_begin(int32_t *__restrict__ state) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { state[8] = state[0]; state[9] = 0; }
+}
+
+template <bool FAST>
+__global__ void __launch_bounds__(256) k_composite_march(float T_thresh, int32_t *__restrict__ alive_a, int32_t *__restrict__ alive_b,
+                                                         float *__restrict__ rays_t, const float *__restrict__ rays_o,
+                                                         const float *__restrict__ rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                                                         uint32_t C, uint32_t H, const uint8_t *__restrict__ grid, const float *__restrict__ fars,
+                                                         const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                                         float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
+                                                         float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image,
+                                                         const uint32_t *__restrict__ cull, uint32_t *__restrict__ live_idx,
+                                                         uint32_t *__restrict__ live_counts, int32_t *__restrict__ state,
+                                                         int32_t *__restrict__ ticket, int32_t *__restrict__ trace, int32_t *__restrict__ snap) {
+    __shared__ uint4 s_cull4[FAST ? 256 : 1];
+    __shared__ unsigned long long s_fine[FAST ? kFineCacheCells : 1];
+    __shared__ uint32_t s_cnt[4];
+    __shared__ int s_last;
+    const uint32_t n_alive = (uint32_t)state[0], n_step = (uint32_t)state[1], list_len = (uint32_t)state[8];
+    const int32_t it = state[3];
+    int32_t *__restrict__ alive = state[4] ? alive_b : alive_a;
+    const bool march_next = (uint32_t)state[2] + n_step < (uint32_t)state[6];  // `while step < max_steps` admits another iteration
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    bool survives = false;
+    uint32_t emitted = 0;
+    if (n_alive > 0 && blockIdx.x * 256u < list_len) {  // workgroup-uniform
+        OccCache oc;
+        occ_cache_load<FAST>(cull, grid, s_cull4, s_fine, oc);
+        const int index = n < list_len ? alive[n] : -1;
+        if (index >= 0) {
+            float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3, *pl = deltas + (size_t)n * n_step * 2;
+            survives = composite_ray(index, n_step, T_thresh, sigmas + (size_t)n * n_step, rgbs + (size_t)n * n_step * 3, pl, rays_t,
+                                     weights_sum, depth, image);
+            if (!survives) {
+                alive[n] = -1;
+            } else if (march_next) {
+                MarcherT<FAST> m;
+                m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid);
+                emitted = march_ray<FAST>(m, oc, rays_t[index], fars[index], n_step, px, pd, pl);
+            }
+        }
+        live_append(emitted, n, n_step, live_idx, live_counts + it + 1);
+    }
+    // survivors of this workgroup -> global accumulator; the last workgroup of the launch advances the loop record
+    const unsigned long long mask = __ballot(survives);
+    if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t c = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (c) atomicAdd(state + 9, (int32_t)c);
+        __threadfence();
+        s_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x != 0) return;
+    __threadfence();
+    *ticket = 0;
+    const int32_t call = state[7];
+    state[7] = call + 1;
+    if (state[0] > 0) {
+        trace[2 * it] = state[0];
+        trace[2 * it + 1] = state[1];
+        state[2] += state[1];
+        state[3] = it + 1;
+        int32_t n_new = atomicAdd(state + 9, 0);
+        state[9] = 0;
+        if (state[2] >= state[6]) n_new = 0;
+        state[0] = n_new;  // n_step stays 8: N / n_new >= 8 holds from here on
+    }
+    snap[(call & 3) * 2] = state[0];
+    snap[(call & 3) * 2 + 1] = call + 1;
+}
+
 // image = image + (1 - weights_sum) * bg ; depth = clamp(depth - nears, 0) / (fars - nears)   (dnerf/renderer.py:378-379)
 __global__ void __launch_bounds__(256) k_loop_finish(uint32_t N, const float *__restrict__ nears, const float *__restrict__ fars,
                                                      const float *__restrict__ weights_sum, const float *__restrict__ depth,
@@ -939,6 +1062,35 @@ int loop_composite_compact(uint32_t bound_alive, float T_thresh, int32_t *alive_
                        (const int32_t *)state, alive_b, block_totals);
     // n_out doubles as the ticket counter (zero between launches)
     hipLaunchKernelGGL(k_scatter_advance, g, b, 0, st, alive_a, alive_b, (const uint32_t *)block_totals, state, n_out, trace, snap);
+    return sdn_launch_status();
+}
+
+
+int loop_steady_begin(uint32_t bound_alive, const int32_t *alive_a, const int32_t *alive_b, const float *rays_t, const float *rays_o,
+                      const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
+                      const float *fars, float *xyzs, float *dirs, float *deltas, const uint32_t *cull, uint32_t *live_idx,
+                      uint32_t *live_counts, int32_t *state, hipStream_t st) {
+    hipLaunchKernelGGL(k_steady_begin, dim3(1), dim3(64), 0, st, state);
+    return loop_march(bound_alive, alive_a, alive_b, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas,
+                      cull, live_idx, live_counts, state, st);
+}
+
+int loop_composite_march(uint32_t bound_list, float T_thresh, int32_t *alive_a, int32_t *alive_b, float *rays_t, const float *rays_o,
+                         const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
+                         const float *fars, const float *sigmas, const float *rgbs, float *xyzs, float *dirs, float *deltas,
+                         float *weights_sum, float *depth, float *image, const uint32_t *cull, uint32_t *live_idx, uint32_t *live_counts,
+                         int32_t *state, int32_t *ticket, int32_t *trace, int32_t *snap, hipStream_t st) {
+    const dim3 g(sdn_div_up(bound_list, 256u)), b(256);
+    if (fast_config(bound, C, H)) {
+        if (cull && H != 128) cull = nullptr;
+        hipLaunchKernelGGL(k_composite_march<true>, g, b, 0, st, T_thresh, alive_a, alive_b, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
+                           grid, fars, sigmas, rgbs, xyzs, dirs, deltas, weights_sum, depth, image, cull, live_idx, live_counts, state, ticket,
+                           trace, snap);
+    } else {
+        hipLaunchKernelGGL(k_composite_march<false>, g, b, 0, st, T_thresh, alive_a, alive_b, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C,
+                           H, grid, fars, sigmas, rgbs, xyzs, dirs, deltas, weights_sum, depth, image, (const uint32_t *)nullptr, live_idx,
+                           live_counts, state, ticket, trace, snap);
+    }
     return sdn_launch_status();
 }
 

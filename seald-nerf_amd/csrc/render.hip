@@ -69,12 +69,29 @@ int sdn_render_frame_f16(const SdnRenderCtx *c, float bg_color, float *image_out
     hipStream_t st = (hipStream_t)stream, side = (hipStream_t)side_stream;
     int rc = sdn_render_begin(c, stream);
     if (rc) return rc;
-    const int32_t *snap_dev = c->trace + 2 * (size_t)c->n_counters;
+    int32_t *snap_dev = c->trace + 2 * (size_t)c->n_counters;
+    const uint32_t *cull = (c->H == 128 && c->C == 1) ? (const uint32_t *)c->cull_bits : nullptr;
     uint32_t bound = c->N, it = 0;
+    bool steady = false;  // see k_composite_march: two launches per iteration once n_alive <= N / 8
     for (;;) {
         void *e0 = (ev_field && it < max_field_events) ? ev_field[2 * it] : nullptr;
         void *e1 = (ev_field && it < max_field_events) ? ev_field[2 * it + 1] : nullptr;
-        rc = sdn_render_step_f16_ev(c, bound, e0, e1, stream);
+        if (!steady) {
+            rc = sdn_render_step_f16_ev(c, bound, e0, e1, stream);
+        } else {
+            uint64_t m_bound = (uint64_t)bound * 8u;
+            if (m_bound > c->N) m_bound = c->N;
+            if (e0) (void)hipEventRecord((hipEvent_t)e0, st);
+            rc = sdn_int::field_forward_f16(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, (uint32_t)m_bound,
+                                            c->field_weights, c->field_bias0, c->grid_table, c->grid_offsets, c->grid_S, c->grid_H, c->bound,
+                                            c->density_scale, c->zero_deform, c->sigmas, c->rgbs, st);
+            if (e1) (void)hipEventRecord((hipEvent_t)e1, st);
+            if (!rc)
+                rc = sdn_int::loop_composite_march(bound, c->T_thresh, c->alive_a, c->alive_b, c->rays_t, c->rays_o, c->rays_d, c->bound,
+                                                   c->dt_gamma, c->max_steps, c->C, c->H, c->bitfield, c->fars, c->sigmas, c->rgbs, c->xyzs,
+                                                   c->dirs, c->deltas, c->weights_sum, c->depth, c->image, cull, c->live_idx,
+                                                   (uint32_t *)c->live_counts, c->state, c->n_out, c->trace, snap_dev, st);
+        }
         if (rc) return rc;
         const uint32_t slot = it & 3u;
         hipError_t e = hipEventRecord((hipEvent_t)ev_main[slot], st);
@@ -88,7 +105,17 @@ int sdn_render_frame_f16(const SdnRenderCtx *c, float bg_color, float *image_out
             if (e != hipSuccess) return (int)e;
             const int32_t n_prev = host_snap[2 * prev];  // alive rays entering iteration `it` (already enqueued)
             if (n_prev <= 0) break;
-            bound = (uint32_t)n_prev;
+            if (!steady) {
+                bound = (uint32_t)n_prev;
+                if ((uint64_t)n_prev * 8u <= c->N) {
+                    // iteration `it` (enqueued above, normal mode) ends with a compacted list; freeze it and march iteration it+1
+                    rc = sdn_int::loop_steady_begin(bound, c->alive_a, c->alive_b, c->rays_t, c->rays_o, c->rays_d, c->bound, c->dt_gamma,
+                                                    c->max_steps, c->C, c->H, c->bitfield, c->fars, c->xyzs, c->dirs, c->deltas, cull,
+                                                    c->live_idx, (uint32_t *)c->live_counts, c->state, st);
+                    if (rc) return rc;
+                    steady = true;
+                }
+            }
         }
         it++;
         if (it > c->max_steps + 1) break;

@@ -423,7 +423,7 @@ class DeviceLoop:
         z = lambda *shape, dt=f32: torch.empty(*shape, dtype=dt, device=device)  # noqa: E731
         self.buf = dict(alive_a=z(N, dt=i32), alive_b=z(N, dt=i32), rays_t=z(N), weights_sum=z(N), depth=z(N), image=z(N, 3),
                         xyzs=z(M, 3), dirs=z(M, 3), deltas=z(M, 2), sigmas=z(M), rgbs=z(M, 3), live_idx=z(M, dt=i32),
-                        live_counts=torch.zeros(n_counters, dtype=i32, device=device), state=torch.zeros(8, dtype=i32, device=device),
+                        live_counts=torch.zeros(n_counters, dtype=i32, device=device), state=torch.zeros(16, dtype=i32, device=device),
                         trace=torch.zeros(2 * n_counters + 16, dtype=i32, device=device), n_out=torch.zeros(1, dtype=i32, device=device),
                         block_totals=z((N + 255) // 256 + 1, dt=i32),
                         cull_bits=torch.empty(int(lib.sdn_cull_grid_bytes()), dtype=torch.uint8, device=device))
