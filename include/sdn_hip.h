@@ -193,6 +193,43 @@ int sdn_field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *
                           int zero_deform, float *sigmas, float *rgbs, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * ffmlp: fully fused bias-free MLP on fp16  (reference: ffmlp/src/ffmlp.h:8-14, ffmlp/src/ffmlp.cu:630-894,
+ * Python wrapper ffmlp/ffmlp.py:15-168).  Layout as in the reference: inputs [B, input_dim], outputs [B, 16],
+ * forward_buffer / backward_buffer [num_layers, B, hidden_dim], all fp16 and point-major; weights flat fp16,
+ * row-major [hidden, input] ++ (num_layers - 1) x [hidden, hidden] ++ [16, hidden]  (ffmlp.cu:631).
+ * Supported (SDN_E_UNSUPPORTED otherwise, where the reference threw): hidden_dim in {16,32,64,128,256},
+ * input_dim % 16 == 0 (<= 512), output_dim == 16 (the wrapper pads, ffmlp.py:120), num_layers >= 2,
+ * activation 0..6 = relu, exponential, sine, sigmoid, squareplus, softplus, none (ffmlp.py:88-96),
+ * output_activation == 6 (none; "not supported currently", ffmlp.py:108).  B need not be a multiple of 128.
+ * `scratch`: sdn_ffmlp_scratch_bytes() bytes, 16-byte aligned, owned by the caller (packed weight fragments and the
+ * split-K partial sums; replaces the reference's internal CUTLASS workspaces and allocate_splitk() side streams,
+ * ffmlp.cu:711-740).
+ * ------------------------------------------------------------------------- */
+uint64_t sdn_ffmlp_scratch_bytes(uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers);
+
+/* ffmlp.h:8  ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
+ * output_activation, forward_buffer, outputs): training forward, keeps every hidden post-activation. */
+int sdn_ffmlp_forward(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                      uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                      void *forward_buffer, void *outputs, void *scratch, void *stream);
+
+/* ffmlp.h:9  ffmlp_inference(...): same result, nothing kept (the reference's inference_buffer is not needed:
+ * activations stay in registers). */
+int sdn_ffmlp_inference(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                        uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                        void *outputs, void *scratch, void *stream);
+
+/* ffmlp.h:11  ffmlp_backward(grad, inputs, weights, forward_buffer, B, ..., calc_grad_inputs, backward_buffer,
+ * grad_inputs, grad_weights).  grad [B,16]; writes backward_buffer (pre-activation gradients, output side first),
+ * grad_weights (flat, same layout as weights) and, if calc_grad_inputs, grad_inputs [B, input_dim].
+ * activation 2 (sine) is rejected: its derivative needs pre-activations (the reference silently passes the gradient
+ * through, utils.h:552-556). */
+int sdn_ffmlp_backward(const void *grad, const void *inputs, const void *weights, const void *forward_buffer, uint32_t B,
+                       uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                       uint32_t activation, uint32_t output_activation, int calc_grad_inputs, void *backward_buffer,
+                       void *grad_inputs, void *grad_weights, void *scratch, void *stream);
+
+/* ---------------------------------------------------------------------------
  * device-driven inference loop for one frame  (reference: the Python loop dnerf/renderer.py:333-381)
  * ------------------------------------------------------------------------- */
 /* All pointers are device pointers owned by the caller except grid_offsets (17 host ints, copied by value).

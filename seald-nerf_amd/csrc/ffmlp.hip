@@ -1,0 +1,597 @@
+// Fully fused MLP operator on MFMA for gfx950 (MI355X): forward / inference / backward of the reference's `ffmlp`
+// extension (ffmlp/src/ffmlp.h:8-14, ffmlp/src/ffmlp.cu:331-407 forward, :411-523 backward, :770-894 weight gradients).
+//
+// Behavioural contract (ffmlp/ffmlp.py:100-168): a bias-free MLP  in -> hidden (x num_layers) -> 16  on fp16 tensors,
+//   flat fp16 weights, row-major [hidden, in] ++ (num_layers - 1) x [hidden, hidden] ++ [16, hidden]   (ffmlp.cu:631),
+//   inputs [B, in], outputs [B, 16] point-major (the reference's "col-major [dim, B]"), hidden in {16,32,64,128,256},
+//   in % 16 == 0, activation on every hidden layer (ReLU / exp / sine / sigmoid / squareplus / softplus / none,
+//   utils.h:425-470), none on the output.  The training forward keeps the num_layers post-activation tensors
+//   (forward_buffer), the backward derives the activation gradient from them (utils.h:538-583) and keeps the
+//   pre-activation gradients (backward_buffer) for the weight-gradient products  dW_l = G_l^T X_l.
+// Numerics: products accumulate in fp32 on the matrix cores and are rounded to fp16 once per layer output (the reference
+// accumulates in fp16 wmma fragments, which is hardware-defined and cannot be restated; see oracle/ffmlp.py header).
+//
+// Mapping -- nothing here is a translation of the wmma / CUTLASS structure:
+//   * weights are the A operand of v_mfma_f32_32x32x16_f16 (M = output features), activations the B operand
+//     (N = 32 points, K = input features).  A layer's accumulator (feature rows in registers, point on the lane) converts in
+//     place (fp16 round, activation) into the B fragments of the next layer, so activations never leave registers
+//     (the reference round-trips them through shared memory between layers).  The k order this implies
+//     (element j of lane-half h <-> feature 16s + 8(j>>2) + 4h + (j&3)) is produced by a tiny pack kernel that
+//     rewrites the flat weights into 1-KiB lane-linear fragments ([layer][M-tile][k-step]; transposed for backward).
+//   * one wave = NT x 32 points (NT = 2 up to hidden 128: every A fragment read from LDS feeds two MFMAs),
+//     workgroup = 4 waves; the packed fragments stream through LDS in <= 32 KiB stages, double-buffered with
+//     direct-to-LDS loads (global_load_lds_dwordx4), one barrier per stage.
+//   * weight gradients: split-K MFMA kernel, batch rows staged row-major in LDS and read column-wise with the gfx950
+//     transposing LDS read (ds_read_b64_tr_b16), fp32 partials per split + a deterministic reduction (no atomics).
+#include <math.h>
+
+#include "sdn_common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWaves = 4;
+constexpr int kStageFrags = 32;                 // 32 KiB per LDS buffer
+constexpr int kStageBytes = kStageFrags * 1024;
+constexpr float kAct = 10.0f;                   // utils.h:41 K_ACT
+
+enum { ACT_RELU = 0, ACT_EXP = 1, ACT_SINE = 2, ACT_SIGMOID = 3, ACT_SQUAREPLUS = 4, ACT_SOFTPLUS = 5, ACT_NONE = 6 };
+
+__device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+// utils.h:425-470 (forward) on the fp16-rounded layer output.  The transcendental ones use the hardware
+// v_exp_f32 / v_log_f32 / v_sin_f32 forms (relative error ~1e-6, far inside the fp16 rounding of the result;
+// sine is accurate to ~1e-5 absolute for |x| < 100 and degrades with |x| like any fp32 argument reduction by 2 pi).
+__device__ __forceinline__ _Float16 act_forward(uint32_t act, _Float16 v) {
+    const float x = (float)v;
+    switch (act) {
+        case ACT_RELU: return v > (_Float16)0 ? v : (_Float16)0;
+        case ACT_EXP: return (_Float16)__expf(x);
+        case ACT_SINE: return (_Float16)__sinf(x);
+        case ACT_SIGMOID: return (_Float16)__fdividef(1.0f, 1.0f + __expf(-x));
+        case ACT_SQUAREPLUS: { const float s = x * kAct; return (_Float16)(0.5f * (s + __fsqrt_rn(s * s + 4.0f)) / kAct); }
+        case ACT_SOFTPLUS: return (_Float16)(__logf(__expf(x * kAct) + 1.0f) / kAct);
+        default: return v;
+    }
+}
+
+// utils.h:538-583 (backward from the stored post-activation value `f`), half arithmetic for the product as there
+__device__ __forceinline__ _Float16 act_backward(uint32_t act, _Float16 g, _Float16 f) {
+    switch (act) {
+        case ACT_RELU: return f > (_Float16)0 ? g : (_Float16)0;
+        case ACT_EXP: return g * f;
+        case ACT_SIGMOID: return g * (_Float16)(f * ((_Float16)1.0f - f));
+        case ACT_SQUAREPLUS: { const float y = (float)f * kAct; return g * (_Float16)__fdividef(y * y, y * y + 1.0f); }
+        case ACT_SOFTPLUS: return g * (_Float16)(1.0f - __expf(-(float)f * kAct));
+        default: return g;   // none; sine is rejected on the host (needs pre-activations the buffers do not hold)
+    }
+}
+
+__device__ __forceinline__ void stage_load(const unsigned char *__restrict__ g, unsigned char *lds, int nfrags, uint32_t wave, uint32_t lane) {
+    for (int c = (int)wave; c < nfrags; c += kWaves) {
+        const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)c * 1024u);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(lds + off), 16, 0, 0);
+    }
+}
+
+// direct-to-LDS loads are pending LDS writes on the VM counter; hipcc does not reliably wait for them before a barrier
+__device__ __forceinline__ void stage_wait_and_sync() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+struct Stager {
+    const unsigned char *g;   // next fragment to prefetch
+    unsigned char *lds;       // two kStageBytes buffers
+    int cur;                  // buffer of the stage being consumed
+    uint32_t wave, lane;
+    __device__ __forceinline__ void prefetch(int nfrags) {
+        stage_load(g, lds + (cur ^ 1) * kStageBytes, nfrags, wave, lane);
+        g += (size_t)nfrags * 1024;
+    }
+    // the stage prefetched last becomes current; start fetching the one after it (next_frags of it, 0 = none)
+    __device__ __forceinline__ void begin_stage(int next_frags) {
+        stage_wait_and_sync();
+        cur ^= 1;
+        if (next_frags) prefetch(next_frags);
+    }
+    __device__ __forceinline__ const unsigned char *buf() const { return lds + cur * kStageBytes; }
+};
+
+__device__ __forceinline__ half8 lds_frag(const unsigned char *buf, int blk, uint32_t lane) {
+    return *reinterpret_cast<const half8 *>(buf + (size_t)blk * 1024 + lane * 16);
+}
+
+__host__ __device__ inline int tiles_per_stage(int KS) { return KS >= kStageFrags ? 1 : kStageFrags / KS; }
+__host__ __device__ inline int first_stage_frags(int MT, int KS) { const int g = tiles_per_stage(KS); return (MT < g ? MT : g) * KS; }
+
+struct FfArgs {
+    const _Float16 *x;            // forward: inputs [B, K0]; backward: grad [B, 16]
+    const unsigned char *packed;  // fragments in consumption order
+    _Float16 *buf;                // forward (training): forward_buffer [L, B, W]; backward: backward_buffer [L, B, W]
+    const _Float16 *fwd;          // backward: forward_buffer
+    _Float16 *out;                // forward: outputs [B, 16]; backward: grad_inputs [B, Mlast] or nullptr
+    uint32_t B, K0, Mlast, L, act;
+};
+
+// MODE 0 inference, 1 training forward (stores the post-activations), 2 backward
+template <int WIDTH, int NT, int MODE>
+__global__ void __launch_bounds__(64 * kWaves, 2) k_ffmlp(FfArgs P) {
+    constexpr int KS = WIDTH / 16;               // k-steps of a hidden activation
+    constexpr int MT = (WIDTH + 31) / 32;        // M-tiles of a hidden layer
+    constexpr int GM = KS >= kStageFrags ? 1 : (kStageFrags / KS < MT ? kStageFrags / KS : MT);   // hidden M-tiles per stage
+    __shared__ __attribute__((aligned(16))) unsigned char s_w[2 * kStageBytes];
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n = lane & 31u, h = lane >> 5;
+    const uint32_t p0 = (blockIdx.x * kWaves + wave) * (32u * NT) + n;   // point of n-tile 0
+    uint32_t pt[NT];
+    bool live[NT];
+    #pragma unroll
+    for (int t = 0; t < NT; t++) { live[t] = p0 + 32u * t < P.B; pt[t] = live[t] ? p0 + 32u * t : P.B - 1; }
+
+    const int KS0 = (int)P.K0 / 16;
+    const int MTL = ((int)P.Mlast + 31) / 32;
+    const bool has_last = P.out != nullptr;
+
+    Stager S{P.packed, s_w, 1, wave, lane};
+    S.prefetch(first_stage_frags(MT, KS0));     // stage 0 -> buffer 0
+
+    half8 fa[KS][NT], fb[KS][NT];
+
+    // hidden-layer epilogue: accumulator tile -> next layer's B fragments (+ buffers)
+    auto epilogue = [&](int k, int Mt, const f32x16 (&acc)[NT], half8 (&dst)[KS][NT]) __attribute__((always_inline)) {
+        #pragma unroll
+        for (int t = 0; t < NT; t++) {
+            half8 f[2];
+            #pragma unroll
+            for (int s = 0; s < 2; s++) {
+                if (2 * Mt + s >= KS) continue;                       // hidden 16: rows 16..31 of the tile do not exist
+                #pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const uint32_t feat = 32u * Mt + 16u * s + 8u * q + 4u * h;
+                    half4 v;
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = (_Float16)acc[t][8 * s + 4 * q + e];
+                    if (MODE == 2) {
+                        const size_t at = ((size_t)(P.L - 1 - k) * P.B + pt[t]) * WIDTH + feat;
+                        const half4 fw = *reinterpret_cast<const half4 *>(P.fwd + at);
+                        #pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = act_backward(P.act, v[e], fw[e]);
+                    } else {
+                        #pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = act_forward(P.act, v[e]);
+                    }
+                    if (MODE != 0 && live[t]) *reinterpret_cast<half4 *>(P.buf + ((size_t)k * P.B + pt[t]) * WIDTH + feat) = v;
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++) f[s][4 * q + e] = v[e];
+                }
+                dst[2 * Mt + s][t] = f[s];
+            }
+        }
+    };
+
+    // ---- first layer: B operand from global memory (row length K0), M = WIDTH -------------------------------------------------
+    {
+        const int g0 = tiles_per_stage(KS0);
+        const int after = first_stage_frags(P.L > 1 ? MT : MTL, KS);       // first stage of the layer that follows
+        const bool preload = KS0 <= KS;
+        if (preload) {
+            #pragma unroll
+            for (int s = 0; s < KS; s++) {
+                if (s < KS0) {
+                    #pragma unroll
+                    for (int t = 0; t < NT; t++) {
+                        const _Float16 *row = P.x + (size_t)pt[t] * P.K0 + 16 * s + 4 * h;
+                        const half4 lo = *reinterpret_cast<const half4 *>(row), hi = *reinterpret_cast<const half4 *>(row + 8);
+                        fb[s][t] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+                }
+            }
+        }
+        #pragma unroll
+        for (int Mt = 0; Mt < MT; Mt++) {
+            if (Mt % g0 == 0) {
+                const int left = MT - Mt - g0;
+                const bool more = P.L > 1 || has_last;
+                S.begin_stage(left > 0 ? (left < g0 ? left : g0) * KS0 : (more ? after : 0));
+            }
+            const unsigned char *base = S.buf() + (size_t)(Mt % g0) * KS0 * 1024;
+            f32x16 acc[NT];
+            #pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (preload) {
+                #pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    if (s < KS0) {
+                        const half8 a = lds_frag(base, s, lane);
+                        #pragma unroll
+                        for (int t = 0; t < NT; t++) acc[t] = mfma(a, fb[s][t], acc[t]);
+                    }
+                }
+            } else {
+                for (int s = 0; s < KS0; s++) {
+                    const half8 a = lds_frag(base, s, lane);
+                    #pragma unroll
+                    for (int t = 0; t < NT; t++) {
+                        const _Float16 *row = P.x + (size_t)pt[t] * P.K0 + 16 * s + 4 * h;
+                        const half4 lo = *reinterpret_cast<const half4 *>(row), hi = *reinterpret_cast<const half4 *>(row + 8);
+                        acc[t] = mfma(a, half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, acc[t]);
+                    }
+                }
+            }
+            epilogue(0, Mt, acc, fa);
+        }
+    }
+
+    // ---- hidden layers 1 .. L-1: WIDTH x WIDTH, operands ping-pong between fa and fb ---------------------------------------------
+    auto hidden = [&](int k, const half8 (&src)[KS][NT], half8 (&dst)[KS][NT]) __attribute__((always_inline)) {
+        const int after = (k + 1 < (int)P.L) ? GM * KS : (has_last ? first_stage_frags(MTL, KS) : 0);
+        #pragma unroll
+        for (int Mt = 0; Mt < MT; Mt++) {
+            if (Mt % GM == 0) {
+                const int left = MT - Mt - GM;
+                S.begin_stage(left > 0 ? (left < GM ? left : GM) * KS : after);
+            }
+            const unsigned char *base = S.buf() + (size_t)(Mt % GM) * KS * 1024;
+            f32x16 acc[NT];
+            #pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            #pragma unroll
+            for (int s = 0; s < KS; s++) {
+                const half8 a = lds_frag(base, s, lane);
+                #pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = mfma(a, src[s][t], acc[t]);
+            }
+            epilogue(k, Mt, acc, dst);
+        }
+    };
+    // ---- last layer: M = Mlast rows written to global memory ---------------------------------------------------------------------
+    auto last = [&](const half8 (&src)[KS][NT]) __attribute__((always_inline)) {
+        const int gl = tiles_per_stage(KS);
+        for (int Mt = 0; Mt < MTL; Mt++) {
+            if (Mt % gl == 0) {
+                const int left = MTL - Mt - gl;
+                S.begin_stage(left > 0 ? (left < gl ? left : gl) * KS : 0);
+            }
+            const unsigned char *base = S.buf() + (size_t)(Mt % gl) * KS * 1024;
+            f32x16 acc[NT];
+            #pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            #pragma unroll
+            for (int s = 0; s < KS; s++) {
+                const half8 a = lds_frag(base, s, lane);
+                #pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = mfma(a, src[s][t], acc[t]);
+            }
+            #pragma unroll
+            for (int t = 0; t < NT; t++) {
+                #pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t feat = 32u * Mt + 8u * q + 4u * h;
+                    if (feat < P.Mlast && live[t]) {
+                        half4 v;
+                        #pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = (_Float16)acc[t][4 * q + e];
+                        *reinterpret_cast<half4 *>(P.out + (size_t)pt[t] * P.Mlast + feat) = v;
+                    }
+                }
+            }
+        }
+    };
+
+    int k = 1;
+    for (; k + 1 < (int)P.L; k += 2) {
+        hidden(k, fa, fb);
+        hidden(k + 1, fb, fa);
+    }
+    if (k < (int)P.L) {
+        hidden(k, fa, fb);
+        if (has_last) last(fb);
+    } else if (has_last) {
+        last(fa);
+    }
+}
+
+// ---- weight packing ---------------------------------------------------------------------------------------------------------------
+struct PackArgs {
+    const _Float16 *w;
+    unsigned char *packed;
+    uint32_t in_dim, W, L;
+    int backward;
+    int with_last;       // backward: pack W0^T for grad_inputs
+};
+
+struct LayerDesc { uint32_t M, K, off; uint32_t sm, sk; };
+
+// layer i of the consumption order (forward: 0..L; backward: 0..L, reversed and transposed)
+__device__ __forceinline__ LayerDesc layer_desc(const PackArgs &P, uint32_t i) {
+    const uint32_t W = P.W, in = P.in_dim, L = P.L;
+    const uint32_t off_mid = W * in, off_out = W * in + (L - 1) * W * W;
+    LayerDesc d;
+    if (!P.backward) {
+        if (i == 0) d = {W, in, 0, in, 1};
+        else if (i < L) d = {W, W, off_mid + (i - 1) * W * W, W, 1};
+        else d = {16, W, off_out, W, 1};
+    } else {
+        if (i == 0) d = {W, 16, off_out, 1, W};                              // A[m][k] = Wout[k][m]
+        else if (i < L) d = {W, W, off_mid + (L - 1 - i) * W * W, 1, W};     // A = W_{L-i}^T
+        else d = {in, W, 0, 1, in};                                          // A = W0^T
+    }
+    return d;
+}
+
+__global__ void k_ffmlp_pack(PackArgs P, uint32_t total_frags) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t frag = gid >> 6;
+    const uint32_t lane = gid & 63u;
+    if (frag >= total_frags) return;
+    const uint32_t dst = frag;
+    const uint32_t nlayers = P.L + ((P.backward && !P.with_last) ? 0u : 1u);
+    LayerDesc d{};
+    for (uint32_t i = 0; i < nlayers; i++) {
+        d = layer_desc(P, i);
+        const uint32_t nf = ((d.M + 31) / 32) * (d.K / 16);
+        if (frag < nf) break;
+        frag -= nf;
+    }
+    const uint32_t KSl = d.K / 16, Mt = frag / KSl, s = frag % KSl;
+    const uint32_t m = 32 * Mt + (lane & 31u), hh = lane >> 5;
+    half8 v;
+    #pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t kk = 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
+        v[j] = m < d.M ? P.w[d.off + (size_t)m * d.sm + (size_t)kk * d.sk] : (_Float16)0;
+    }
+    *reinterpret_cast<half8 *>(P.packed + (size_t)dst * 1024 + lane * 16) = v;
+}
+
+uint32_t total_frags_host(uint32_t in_dim, uint32_t W, uint32_t L, int backward, int with_last) {
+    const uint32_t MT = (W + 31) / 32, KS = W / 16;
+    if (!backward) return MT * (in_dim / 16) + (L - 1) * MT * KS + 1 * KS;
+    return MT * 1 + (L - 1) * MT * KS + (with_last ? ((in_dim + 31) / 32) * KS : 0);
+}
+
+// ---- weight gradients: dW[m][n] = sum_b G[b][m] X[b][n] ---------------------------------------------------------------------------
+constexpr int kDwRows = 64;                     // batch rows per LDS tile
+constexpr int kDwStride = (128 + 32) * 2;       // bytes per LDS row: 128 halfs + 64 B pad (4 rows x 32 B blocks of a transposed read land on disjoint banks)
+
+struct DwArgs {
+    const _Float16 *G;   // [B, ldg]
+    const _Float16 *X;   // [B, ldx]
+    float *partial;      // [nsplit][Mpad][Npad]
+    uint32_t B, ldg, ldx, M, N, Mpad, Npad, rows_per_split;
+};
+
+__device__ __forceinline__ half8 tr_frag(const unsigned char *tile, int s, int c0, uint32_t lane) {
+    // 32x32x16 operand with k = batch row 16s + 8h + j and row/col = feature c0 + (lane & 31), from a row-major [row][feature] image
+    const uint32_t g = lane >> 4, i = lane & 15u, q = i >> 2, p = i & 3u;
+    const uint32_t row = 16u * s + 8u * (g >> 1) + q;
+    const unsigned char *a = tile + row * kDwStride + (c0 + 16u * (g & 1u) + 4u * p) * 2u;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(a));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(a + 4 * kDwStride));
+    const half4 l4 = __builtin_bit_cast(half4, lo), h4 = __builtin_bit_cast(half4, hi);
+    return half8{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+}
+
+__global__ void __launch_bounds__(256) k_ffmlp_dw(DwArgs P) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_g[kDwRows * kDwStride];
+    __shared__ __attribute__((aligned(16))) unsigned char s_x[kDwRows * kDwStride];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t nbx = (P.N + 127) / 128;
+    const uint32_t mb = (blockIdx.y / nbx) * 128, nb = (blockIdx.y % nbx) * 128;   // origin of this block's <= 128 x 128 output
+    const uint32_t mcols = min(128u, P.Mpad - mb), ncols = min(128u, P.Npad - nb); // multiples of 32
+    const uint32_t wy = wave >> 1, wx = wave & 1u;
+    const uint32_t b_begin = blockIdx.x * P.rows_per_split;
+    const uint32_t b_end = min(P.B, b_begin + P.rows_per_split);
+
+    f32x16 acc[2][2];
+    #pragma unroll
+    for (int a = 0; a < 2; a++)
+        #pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const bool my_m[2] = {64 * wy < mcols, 64 * wy + 32 < mcols};
+    const bool my_n[2] = {64 * wx < ncols, 64 * wx + 32 < ncols};
+
+    // 64 rows x 16 chunks of 16 B per operand = 1024 chunks, 4 per thread
+    half8 rg[4], rx[4];
+    auto fetch = [&](uint32_t b0) {
+        #pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t idx = threadIdx.x + 256u * u, row = idx >> 4, ch = idx & 15u;
+            const uint32_t b = b0 + row;
+            const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            rg[u] = (b < b_end && ch * 8 < mcols && mb + ch * 8 < P.M) ? *reinterpret_cast<const half8 *>(P.G + (size_t)b * P.ldg + mb + ch * 8) : z;
+            rx[u] = (b < b_end && ch * 8 < ncols && nb + ch * 8 < P.N) ? *reinterpret_cast<const half8 *>(P.X + (size_t)b * P.ldx + nb + ch * 8) : z;
+        }
+    };
+    auto stash = [&]() {
+        #pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t idx = threadIdx.x + 256u * u, row = idx >> 4, ch = idx & 15u;
+            *reinterpret_cast<half8 *>(s_g + row * kDwStride + ch * 16) = rg[u];
+            *reinterpret_cast<half8 *>(s_x + row * kDwStride + ch * 16) = rx[u];
+        }
+    };
+
+    if (b_begin < b_end) fetch(b_begin);
+    for (uint32_t b0 = b_begin; b0 < b_end; b0 += kDwRows) {
+        __syncthreads();            // previous tile fully consumed
+        stash();
+        __syncthreads();
+        if (b0 + kDwRows < b_end) fetch(b0 + kDwRows);
+        #pragma unroll
+        for (int s = 0; s < kDwRows / 16; s++) {
+            half8 fa[2], fb[2];
+            #pragma unroll
+            for (int a = 0; a < 2; a++) fa[a] = tr_frag(s_g, s, 64 * wy + 32 * a, lane);
+            #pragma unroll
+            for (int b = 0; b < 2; b++) fb[b] = tr_frag(s_x, s, 64 * wx + 32 * b, lane);
+            #pragma unroll
+            for (int a = 0; a < 2; a++)
+                #pragma unroll
+                for (int b = 0; b < 2; b++)
+                    if (my_m[a] && my_n[b]) acc[a][b] = mfma(fa[a], fb[b], acc[a][b]);
+        }
+    }
+    const uint32_t n = lane & 31u, h = lane >> 5;
+    float *dst = P.partial + (size_t)blockIdx.x * P.Mpad * P.Npad;
+    #pragma unroll
+    for (int a = 0; a < 2; a++)
+        #pragma unroll
+        for (int b = 0; b < 2; b++) {
+            if (!(my_m[a] && my_n[b])) continue;
+            #pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t m = mb + 64 * wy + 32 * a + 8 * (i >> 2) + 4 * h + (i & 3);
+                dst[(size_t)m * P.Npad + nb + 64 * wx + 32 * b + n] = acc[a][b][i];
+            }
+        }
+}
+
+__global__ void k_ffmlp_dw_reduce(const float *partial, uint32_t nsplit, uint32_t M, uint32_t N, uint32_t Mpad, uint32_t Npad, _Float16 *out) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * N) return;
+    const uint32_t m = idx / N, n = idx % N;
+    float s = 0.0f;
+    for (uint32_t k = 0; k < nsplit; k++) s += partial[((size_t)k * Mpad + m) * Npad + n];
+    out[idx] = (_Float16)s;
+}
+
+uint32_t dw_splits(uint32_t B, uint32_t blocks) {
+    uint32_t ns = sdn_div_up(B, 1024u);
+    const uint32_t cap = 1024u / blocks;
+    if (ns > cap) ns = cap;
+    return ns ? ns : 1;
+}
+
+uint32_t dw_blocks(uint32_t M, uint32_t N) { return (((M + 31) / 32 * 32 + 127) / 128) * (((N + 31) / 32 * 32 + 127) / 128); }
+
+uint64_t dw_partial_bytes(uint32_t B, uint32_t M, uint32_t N) {
+    return (uint64_t)dw_splits(B, dw_blocks(M, N)) * ((M + 31) / 32 * 32) * ((N + 31) / 32 * 32) * sizeof(float);
+}
+
+bool dims_ok(uint32_t in_dim, uint32_t out_dim, uint32_t W, uint32_t L) {
+    const bool wok = W == 16 || W == 32 || W == 64 || W == 128 || W == 256;
+    return wok && in_dim >= 16 && in_dim % 16 == 0 && in_dim <= 512 && out_dim == 16 && L >= 2;
+}
+
+template <int MODE>
+int launch_fused(uint32_t W, const FfArgs &a, hipStream_t st) {
+    #define SDN_FF_LAUNCH(WIDTH, NT)                                                                                              \
+        hipLaunchKernelGGL((k_ffmlp<WIDTH, NT, MODE>), dim3(sdn_div_up(a.B, (uint32_t)(kWaves * 32 * NT))), dim3(64 * kWaves), 0, st, a)
+    switch (W) {
+        case 16: SDN_FF_LAUNCH(16, 2); break;
+        case 32: SDN_FF_LAUNCH(32, 2); break;
+        case 64: SDN_FF_LAUNCH(64, 2); break;
+        case 128: SDN_FF_LAUNCH(128, 2); break;
+        case 256: SDN_FF_LAUNCH(256, 1); break;
+        default: return SDN_E_UNSUPPORTED;
+    }
+    #undef SDN_FF_LAUNCH
+    return sdn_launch_status();
+}
+
+int pack(const void *weights, void *packed, uint32_t in_dim, uint32_t W, uint32_t L, int backward, int with_last, hipStream_t st) {
+    PackArgs p{(const _Float16 *)weights, (unsigned char *)packed, in_dim, W, L, backward, with_last};
+    const uint32_t nf = total_frags_host(in_dim, W, L, backward, with_last);
+    hipLaunchKernelGGL(k_ffmlp_pack, dim3(sdn_div_up(nf * 64u, 256u)), dim3(256), 0, st, p, nf);
+    return sdn_launch_status();
+}
+
+int forward_common(const void *inputs, const void *weights, uint32_t B, uint32_t in_dim, uint32_t out_dim, uint32_t W, uint32_t L,
+                   uint32_t act, uint32_t out_act, void *forward_buffer, void *outputs, void *scratch, hipStream_t st) {
+    if (B == 0) return 0;
+    if (!inputs || !weights || !outputs || !scratch) return SDN_E_BADARG;
+    if (!dims_ok(in_dim, out_dim, W, L) || act > ACT_NONE || out_act != ACT_NONE) return SDN_E_UNSUPPORTED;
+    if (((uintptr_t)scratch & 15u) || ((uintptr_t)inputs & 7u) || ((uintptr_t)outputs & 7u) || ((uintptr_t)forward_buffer & 7u)) return SDN_E_BADARG;
+    int rc = pack(weights, scratch, in_dim, W, L, 0, 1, st);
+    if (rc) return rc;
+    FfArgs a{(const _Float16 *)inputs, (const unsigned char *)scratch, (_Float16 *)forward_buffer, nullptr, (_Float16 *)outputs, B, in_dim, 16, L, act};
+    return forward_buffer ? launch_fused<1>(W, a, st) : launch_fused<0>(W, a, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+uint64_t sdn_ffmlp_scratch_bytes(uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers) {
+    if (!dims_ok(input_dim, output_dim, hidden_dim, num_layers)) return 0;
+    const uint64_t fw = total_frags_host(input_dim, hidden_dim, num_layers, 0, 1), bw = total_frags_host(input_dim, hidden_dim, num_layers, 1, 1);
+    const uint64_t packed = (fw > bw ? fw : bw) * 1024;
+    uint64_t partial = dw_partial_bytes(B, 16, hidden_dim);
+    const uint64_t p1 = dw_partial_bytes(B, hidden_dim, hidden_dim), p2 = dw_partial_bytes(B, hidden_dim, input_dim);
+    if (p1 > partial) partial = p1;
+    if (p2 > partial) partial = p2;
+    return packed + partial;
+}
+
+int sdn_ffmlp_forward(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
+                      uint32_t num_layers, uint32_t activation, uint32_t output_activation, void *forward_buffer, void *outputs,
+                      void *scratch, void *stream) {
+    if (B && !forward_buffer) return SDN_E_BADARG;
+    return forward_common(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, forward_buffer,
+                          outputs, scratch, (hipStream_t)stream);
+}
+
+int sdn_ffmlp_inference(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
+                        uint32_t num_layers, uint32_t activation, uint32_t output_activation, void *outputs, void *scratch, void *stream) {
+    return forward_common(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, nullptr, outputs,
+                          scratch, (hipStream_t)stream);
+}
+
+int sdn_ffmlp_backward(const void *grad, const void *inputs, const void *weights, const void *forward_buffer, uint32_t B, uint32_t input_dim,
+                       uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                       int calc_grad_inputs, void *backward_buffer, void *grad_inputs, void *grad_weights, void *scratch, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t W = hidden_dim, L = num_layers, in = input_dim;
+    if (B == 0) return 0;
+    if (!grad || !inputs || !weights || !forward_buffer || !backward_buffer || !grad_weights || !scratch) return SDN_E_BADARG;
+    if (calc_grad_inputs && !grad_inputs) return SDN_E_BADARG;
+    if (!dims_ok(in, output_dim, W, L) || activation > ACT_NONE || activation == ACT_SINE || output_activation != ACT_NONE) return SDN_E_UNSUPPORTED;
+    if ((uintptr_t)scratch & 15u) return SDN_E_BADARG;
+
+    // 1. pre-activation gradients of every hidden layer (+ grad_inputs): one fused launch
+    int rc = pack(weights, scratch, in, W, L, 1, calc_grad_inputs ? 1 : 0, st);
+    if (rc) return rc;
+    FfArgs a{(const _Float16 *)grad, (const unsigned char *)scratch, (_Float16 *)backward_buffer, (const _Float16 *)forward_buffer,
+             calc_grad_inputs ? (_Float16 *)grad_inputs : nullptr, B, 16, in, L, activation};
+    rc = launch_fused<2>(W, a, st);
+    if (rc) return rc;
+
+    // 2. weight gradients, layer by layer (split-K over the batch, deterministic two-pass reduction)
+    const uint64_t fw = total_frags_host(in, W, L, 0, 1), bw = total_frags_host(in, W, L, 1, 1);
+    float *partial = (float *)((unsigned char *)scratch + (fw > bw ? fw : bw) * 1024);
+    const _Float16 *fwd = (const _Float16 *)forward_buffer, *bwd = (const _Float16 *)backward_buffer;
+    _Float16 *gw = (_Float16 *)grad_weights;
+    auto dw = [&](const _Float16 *G, uint32_t ldg, uint32_t M, const _Float16 *X, uint32_t ldx, uint32_t N, _Float16 *out) -> int {
+        DwArgs d;
+        d.G = G; d.X = X; d.partial = partial; d.B = B; d.ldg = ldg; d.ldx = ldx; d.M = M; d.N = N;
+        d.Mpad = (M + 31) / 32 * 32; d.Npad = (N + 31) / 32 * 32;
+        const uint32_t blocks = dw_blocks(M, N);
+        const uint32_t ns = dw_splits(B, blocks);
+        d.rows_per_split = sdn_div_up(sdn_div_up(B, ns), (uint32_t)kDwRows) * kDwRows;
+        const uint32_t ns_used = sdn_div_up(B, d.rows_per_split);
+        hipLaunchKernelGGL(k_ffmlp_dw, dim3(ns_used, blocks), dim3(256), 0, st, d);
+        hipLaunchKernelGGL(k_ffmlp_dw_reduce, dim3(sdn_div_up(M * N, 256u)), dim3(256), 0, st, partial, ns_used, M, N, d.Mpad, d.Npad, out);
+        return sdn_launch_status();
+    };
+    const size_t BW = (size_t)B * W;
+    // output layer: dW_out [16, W] = grad^T X_L                                   (ffmlp.cu:800-811)
+    rc = dw((const _Float16 *)grad, 16, 16, fwd + (L - 1) * BW, W, W, gw + (size_t)W * in + (size_t)(L - 1) * W * W);
+    if (rc) return rc;
+    // hidden layers: dW_j [W, W] = G_j^T X_j, G_j = backward_buffer[L - 1 - j]   (ffmlp.cu:845-863)
+    for (uint32_t j = L - 1; j >= 1; j--) {
+        rc = dw(bwd + (size_t)(L - 1 - j) * BW, W, W, fwd + (size_t)(j - 1) * BW, W, W, gw + (size_t)W * in + (size_t)(j - 1) * W * W);
+        if (rc) return rc;
+    }
+    // input layer: dW_0 [W, in] = G_0^T inputs                                    (ffmlp.cu:866-876)
+    return dw(bwd + (size_t)(L - 1) * BW, W, W, (const _Float16 *)inputs, in, in, gw);
+}
+
+}  // extern "C"

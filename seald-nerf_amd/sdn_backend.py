@@ -45,6 +45,9 @@ PROTOTYPES = {
     "sdn_render_finish": [_vp, _f32, _vp, _vp, _vp],
     "sdn_render_frame_f16": [_vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     "sdn_field_forward_f16": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _f32, _u32, _f32, _f32, _i32, _vp, _vp, _vp],
+    "sdn_ffmlp_forward": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp],
+    "sdn_ffmlp_inference": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
+    "sdn_ffmlp_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp],
 }
 class SdnRenderCtx(ctypes.Structure):
     """Mirror of `SdnRenderCtx` in include/sdn_hip.h (field order and types must match)."""
@@ -65,6 +68,7 @@ PROTOTYPES_U32 = {
 PROTOTYPES_U64 = {
     "sdn_march_rays_train_scratch_bytes": [_u32],
     "sdn_compact_alive_scratch_bytes": [_u32],
+    "sdn_ffmlp_scratch_bytes": [_u32, _u32, _u32, _u32, _u32],
 }
 
 if not os.path.exists(LIB_PATH):
