@@ -23,280 +23,16 @@
 //     direct-to-LDS loads (global_load_lds_dwordx4), one barrier per stage.
 //   * weight gradients: split-K MFMA kernel, batch rows staged row-major in LDS and read column-wise with the gfx950
 //     transposing LDS read (ds_read_b64_tr_b16), fp32 partials per split + a deterministic reduction (no atomics).
-#include <math.h>
+#include "ffmlp_kernels.h"
 
-#include "sdn_common.h"
+namespace sdn_ff {
+// instantiated in ffmlp_act.hip: every activation other than ReLU (run-time dispatch inside the kernels)
+int launch_fused_generic(int mode, uint32_t W, const FfArgs &a, hipStream_t st);
+}  // namespace sdn_ff
 
 namespace {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kWaves = 4;
-constexpr int kStageFrags = 32;                 // 32 KiB per LDS buffer
-constexpr int kStageBytes = kStageFrags * 1024;
-constexpr float kAct = 10.0f;                   // utils.h:41 K_ACT
-
-enum { ACT_RELU = 0, ACT_EXP = 1, ACT_SINE = 2, ACT_SIGMOID = 3, ACT_SQUAREPLUS = 4, ACT_SOFTPLUS = 5, ACT_NONE = 6 };
-
-__device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-
-// utils.h:425-470 (forward) on the fp16-rounded layer output.  The transcendental ones use the hardware
-// v_exp_f32 / v_log_f32 / v_sin_f32 forms (relative error ~1e-6, far inside the fp16 rounding of the result;
-// sine is accurate to ~1e-5 absolute for |x| < 100 and degrades with |x| like any fp32 argument reduction by 2 pi).
-__device__ __forceinline__ _Float16 act_forward(uint32_t act, _Float16 v) {
-    const float x = (float)v;
-    switch (act) {
-        case ACT_RELU: return v > (_Float16)0 ? v : (_Float16)0;
-        case ACT_EXP: return (_Float16)__expf(x);
-        case ACT_SINE: return (_Float16)__sinf(x);
-        case ACT_SIGMOID: return (_Float16)__fdividef(1.0f, 1.0f + __expf(-x));
-        case ACT_SQUAREPLUS: { const float s = x * kAct; return (_Float16)(0.5f * (s + __fsqrt_rn(s * s + 4.0f)) / kAct); }
-        case ACT_SOFTPLUS: return (_Float16)(__logf(__expf(x * kAct) + 1.0f) / kAct);
-        default: return v;
-    }
-}
-
-// utils.h:538-583 (backward from the stored post-activation value `f`), half arithmetic for the product as there
-__device__ __forceinline__ _Float16 act_backward(uint32_t act, _Float16 g, _Float16 f) {
-    switch (act) {
-        case ACT_RELU: return f > (_Float16)0 ? g : (_Float16)0;
-        case ACT_EXP: return g * f;
-        case ACT_SIGMOID: return g * (_Float16)(f * ((_Float16)1.0f - f));
-        case ACT_SQUAREPLUS: { const float y = (float)f * kAct; return g * (_Float16)__fdividef(y * y, y * y + 1.0f); }
-        case ACT_SOFTPLUS: return g * (_Float16)(1.0f - __expf(-(float)f * kAct));
-        default: return g;   // none; sine is rejected on the host (needs pre-activations the buffers do not hold)
-    }
-}
-
-__device__ __forceinline__ void stage_load(const unsigned char *__restrict__ g, unsigned char *lds, int nfrags, uint32_t wave, uint32_t lane) {
-    for (int c = (int)wave; c < nfrags; c += kWaves) {
-        const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)c * 1024u);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off + lane * 16),
-                                         (__attribute__((address_space(3))) void *)(lds + off), 16, 0, 0);
-    }
-}
-
-// direct-to-LDS loads are pending LDS writes on the VM counter; hipcc does not reliably wait for them before a barrier
-__device__ __forceinline__ void stage_wait_and_sync() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-}
-
-struct Stager {
-    const unsigned char *g;   // next fragment to prefetch
-    unsigned char *lds;       // two kStageBytes buffers
-    int cur;                  // buffer of the stage being consumed
-    uint32_t wave, lane;
-    __device__ __forceinline__ void prefetch(int nfrags) {
-        stage_load(g, lds + (cur ^ 1) * kStageBytes, nfrags, wave, lane);
-        g += (size_t)nfrags * 1024;
-    }
-    // the stage prefetched last becomes current; start fetching the one after it (next_frags of it, 0 = none)
-    __device__ __forceinline__ void begin_stage(int next_frags) {
-        stage_wait_and_sync();
-        cur ^= 1;
-        if (next_frags) prefetch(next_frags);
-    }
-    __device__ __forceinline__ const unsigned char *buf() const { return lds + cur * kStageBytes; }
-};
-
-__device__ __forceinline__ half8 lds_frag(const unsigned char *buf, int blk, uint32_t lane) {
-    return *reinterpret_cast<const half8 *>(buf + (size_t)blk * 1024 + lane * 16);
-}
-
-__host__ __device__ inline int tiles_per_stage(int KS) { return KS >= kStageFrags ? 1 : kStageFrags / KS; }
-__host__ __device__ inline int first_stage_frags(int MT, int KS) { const int g = tiles_per_stage(KS); return (MT < g ? MT : g) * KS; }
-
-struct FfArgs {
-    const _Float16 *x;            // forward: inputs [B, K0]; backward: grad [B, 16]
-    const unsigned char *packed;  // fragments in consumption order
-    _Float16 *buf;                // forward (training): forward_buffer [L, B, W]; backward: backward_buffer [L, B, W]
-    const _Float16 *fwd;          // backward: forward_buffer
-    _Float16 *out;                // forward: outputs [B, 16]; backward: grad_inputs [B, Mlast] or nullptr
-    uint32_t B, K0, Mlast, L, act;
-};
-
-// MODE 0 inference, 1 training forward (stores the post-activations), 2 backward
-template <int WIDTH, int NT, int MODE>
-__global__ void __launch_bounds__(64 * kWaves, 2) k_ffmlp(FfArgs P) {
-    constexpr int KS = WIDTH / 16;               // k-steps of a hidden activation
-    constexpr int MT = (WIDTH + 31) / 32;        // M-tiles of a hidden layer
-    constexpr int GM = KS >= kStageFrags ? 1 : (kStageFrags / KS < MT ? kStageFrags / KS : MT);   // hidden M-tiles per stage
-    __shared__ __attribute__((aligned(16))) unsigned char s_w[2 * kStageBytes];
-
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t n = lane & 31u, h = lane >> 5;
-    const uint32_t p0 = (blockIdx.x * kWaves + wave) * (32u * NT) + n;   // point of n-tile 0
-    uint32_t pt[NT];
-    bool live[NT];
-    #pragma unroll
-    for (int t = 0; t < NT; t++) { live[t] = p0 + 32u * t < P.B; pt[t] = live[t] ? p0 + 32u * t : P.B - 1; }
-
-    const int KS0 = (int)P.K0 / 16;
-    const int MTL = ((int)P.Mlast + 31) / 32;
-    const bool has_last = P.out != nullptr;
-
-    Stager S{P.packed, s_w, 1, wave, lane};
-    S.prefetch(first_stage_frags(MT, KS0));     // stage 0 -> buffer 0
-
-    half8 fa[KS][NT], fb[KS][NT];
-
-    // hidden-layer epilogue: accumulator tile -> next layer's B fragments (+ buffers)
-    auto epilogue = [&](int k, int Mt, const f32x16 (&acc)[NT], half8 (&dst)[KS][NT]) __attribute__((always_inline)) {
-        #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            half8 f[2];
-            #pragma unroll
-            for (int s = 0; s < 2; s++) {
-                if (2 * Mt + s >= KS) continue;                       // hidden 16: rows 16..31 of the tile do not exist
-                #pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const uint32_t feat = 32u * Mt + 16u * s + 8u * q + 4u * h;
-                    half4 v;
-                    #pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = (_Float16)acc[t][8 * s + 4 * q + e];
-                    if (MODE == 2) {
-                        const size_t at = ((size_t)(P.L - 1 - k) * P.B + pt[t]) * WIDTH + feat;
-                        const half4 fw = *reinterpret_cast<const half4 *>(P.fwd + at);
-                        #pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] = act_backward(P.act, v[e], fw[e]);
-                    } else {
-                        #pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] = act_forward(P.act, v[e]);
-                    }
-                    if (MODE != 0 && live[t]) *reinterpret_cast<half4 *>(P.buf + ((size_t)k * P.B + pt[t]) * WIDTH + feat) = v;
-                    #pragma unroll
-                    for (int e = 0; e < 4; e++) f[s][4 * q + e] = v[e];
-                }
-                dst[2 * Mt + s][t] = f[s];
-            }
-        }
-    };
-
-    // ---- first layer: B operand from global memory (row length K0), M = WIDTH -------------------------------------------------
-    {
-        const int g0 = tiles_per_stage(KS0);
-        const int after = first_stage_frags(P.L > 1 ? MT : MTL, KS);       // first stage of the layer that follows
-        const bool preload = KS0 <= KS;
-        if (preload) {
-            #pragma unroll
-            for (int s = 0; s < KS; s++) {
-                if (s < KS0) {
-                    #pragma unroll
-                    for (int t = 0; t < NT; t++) {
-                        const _Float16 *row = P.x + (size_t)pt[t] * P.K0 + 16 * s + 4 * h;
-                        const half4 lo = *reinterpret_cast<const half4 *>(row), hi = *reinterpret_cast<const half4 *>(row + 8);
-                        fb[s][t] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    }
-                }
-            }
-        }
-        #pragma unroll
-        for (int Mt = 0; Mt < MT; Mt++) {
-            if (Mt % g0 == 0) {
-                const int left = MT - Mt - g0;
-                const bool more = P.L > 1 || has_last;
-                S.begin_stage(left > 0 ? (left < g0 ? left : g0) * KS0 : (more ? after : 0));
-            }
-            const unsigned char *base = S.buf() + (size_t)(Mt % g0) * KS0 * 1024;
-            f32x16 acc[NT];
-            #pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            if (preload) {
-                #pragma unroll
-                for (int s = 0; s < KS; s++) {
-                    if (s < KS0) {
-                        const half8 a = lds_frag(base, s, lane);
-                        #pragma unroll
-                        for (int t = 0; t < NT; t++) acc[t] = mfma(a, fb[s][t], acc[t]);
-                    }
-                }
-            } else {
-                for (int s = 0; s < KS0; s++) {
-                    const half8 a = lds_frag(base, s, lane);
-                    #pragma unroll
-                    for (int t = 0; t < NT; t++) {
-                        const _Float16 *row = P.x + (size_t)pt[t] * P.K0 + 16 * s + 4 * h;
-                        const half4 lo = *reinterpret_cast<const half4 *>(row), hi = *reinterpret_cast<const half4 *>(row + 8);
-                        acc[t] = mfma(a, half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, acc[t]);
-                    }
-                }
-            }
-            epilogue(0, Mt, acc, fa);
-        }
-    }
-
-    // ---- hidden layers 1 .. L-1: WIDTH x WIDTH, operands ping-pong between fa and fb ---------------------------------------------
-    auto hidden = [&](int k, const half8 (&src)[KS][NT], half8 (&dst)[KS][NT]) __attribute__((always_inline)) {
-        const int after = (k + 1 < (int)P.L) ? GM * KS : (has_last ? first_stage_frags(MTL, KS) : 0);
-        #pragma unroll
-        for (int Mt = 0; Mt < MT; Mt++) {
-            if (Mt % GM == 0) {
-                const int left = MT - Mt - GM;
-                S.begin_stage(left > 0 ? (left < GM ? left : GM) * KS : after);
-            }
-            const unsigned char *base = S.buf() + (size_t)(Mt % GM) * KS * 1024;
-            f32x16 acc[NT];
-            #pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            #pragma unroll
-            for (int s = 0; s < KS; s++) {
-                const half8 a = lds_frag(base, s, lane);
-                #pragma unroll
-                for (int t = 0; t < NT; t++) acc[t] = mfma(a, src[s][t], acc[t]);
-            }
-            epilogue(k, Mt, acc, dst);
-        }
-    };
-    // ---- last layer: M = Mlast rows written to global memory ---------------------------------------------------------------------
-    auto last = [&](const half8 (&src)[KS][NT]) __attribute__((always_inline)) {
-        const int gl = tiles_per_stage(KS);
-        for (int Mt = 0; Mt < MTL; Mt++) {
-            if (Mt % gl == 0) {
-                const int left = MTL - Mt - gl;
-                S.begin_stage(left > 0 ? (left < gl ? left : gl) * KS : 0);
-            }
-            const unsigned char *base = S.buf() + (size_t)(Mt % gl) * KS * 1024;
-            f32x16 acc[NT];
-            #pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            #pragma unroll
-            for (int s = 0; s < KS; s++) {
-                const half8 a = lds_frag(base, s, lane);
-                #pragma unroll
-                for (int t = 0; t < NT; t++) acc[t] = mfma(a, src[s][t], acc[t]);
-            }
-            #pragma unroll
-            for (int t = 0; t < NT; t++) {
-                #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t feat = 32u * Mt + 8u * q + 4u * h;
-                    if (feat < P.Mlast && live[t]) {
-                        half4 v;
-                        #pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] = (_Float16)acc[t][4 * q + e];
-                        *reinterpret_cast<half4 *>(P.out + (size_t)pt[t] * P.Mlast + feat) = v;
-                    }
-                }
-            }
-        }
-    };
-
-    int k = 1;
-    for (; k + 1 < (int)P.L; k += 2) {
-        hidden(k, fa, fb);
-        hidden(k + 1, fb, fa);
-    }
-    if (k < (int)P.L) {
-        hidden(k, fa, fb);
-        if (has_last) last(fb);
-    } else if (has_last) {
-        last(fa);
-    }
-}
+using namespace sdn_ff;
 
 // ---- weight packing ---------------------------------------------------------------------------------------------------------------
 struct PackArgs {
@@ -454,18 +190,24 @@ __global__ void __launch_bounds__(256) k_ffmlp_dw(DwArgs P) {
         }
 }
 
-__global__ void k_ffmlp_dw_reduce(const float *partial, uint32_t nsplit, uint32_t M, uint32_t N, uint32_t Mpad, uint32_t Npad, _Float16 *out) {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= M * N) return;
-    const uint32_t m = idx / N, n = idx % N;
+// deterministic second pass: element (m, n) = sum over the splits, 4 partial sums per element combined through LDS
+__global__ void __launch_bounds__(256) k_ffmlp_dw_reduce(const float *partial, uint32_t nsplit, uint32_t M, uint32_t N, uint32_t Mpad, uint32_t Npad, _Float16 *out) {
+    __shared__ float s_part[4][64];
+    const uint32_t x = threadIdx.x & 63u, y = threadIdx.x >> 6;
+    const uint32_t idx = blockIdx.x * 64u + x;
     float s = 0.0f;
-    for (uint32_t k = 0; k < nsplit; k++) s += partial[((size_t)k * Mpad + m) * Npad + n];
-    out[idx] = (_Float16)s;
+    if (idx < M * N) {
+        const uint32_t m = idx / N, n = idx % N;
+        for (uint32_t k = y; k < nsplit; k += 4) s += partial[((size_t)k * Mpad + m) * Npad + n];
+    }
+    s_part[y][x] = s;
+    __syncthreads();
+    if (y == 0 && idx < M * N) out[idx] = (_Float16)((s_part[0][x] + s_part[1][x]) + (s_part[2][x] + s_part[3][x]));
 }
 
 uint32_t dw_splits(uint32_t B, uint32_t blocks) {
     uint32_t ns = sdn_div_up(B, 1024u);
-    const uint32_t cap = 1024u / blocks;
+    const uint32_t cap = 512u / blocks;       // ~2 workgroups per CU in flight; the second pass reads ns partial tiles per element
     if (ns > cap) ns = cap;
     return ns ? ns : 1;
 }
@@ -481,20 +223,10 @@ bool dims_ok(uint32_t in_dim, uint32_t out_dim, uint32_t W, uint32_t L) {
     return wok && in_dim >= 16 && in_dim % 16 == 0 && in_dim <= 512 && out_dim == 16 && L >= 2;
 }
 
+// ReLU has its own instantiation (no dispatch in the epilogues); everything else goes through ffmlp_act.hip
 template <int MODE>
 int launch_fused(uint32_t W, const FfArgs &a, hipStream_t st) {
-    #define SDN_FF_LAUNCH(WIDTH, NT)                                                                                              \
-        hipLaunchKernelGGL((k_ffmlp<WIDTH, NT, MODE>), dim3(sdn_div_up(a.B, (uint32_t)(kWaves * 32 * NT))), dim3(64 * kWaves), 0, st, a)
-    switch (W) {
-        case 16: SDN_FF_LAUNCH(16, 2); break;
-        case 32: SDN_FF_LAUNCH(32, 2); break;
-        case 64: SDN_FF_LAUNCH(64, 2); break;
-        case 128: SDN_FF_LAUNCH(128, 2); break;
-        case 256: SDN_FF_LAUNCH(256, 1); break;
-        default: return SDN_E_UNSUPPORTED;
-    }
-    #undef SDN_FF_LAUNCH
-    return sdn_launch_status();
+    return a.act == ACT_RELU ? launch_fused_t<MODE, true>(W, a, st) : launch_fused_generic(MODE, W, a, st);
 }
 
 int pack(const void *weights, void *packed, uint32_t in_dim, uint32_t W, uint32_t L, int backward, int with_last, hipStream_t st) {
@@ -512,7 +244,8 @@ int forward_common(const void *inputs, const void *weights, uint32_t B, uint32_t
     if (((uintptr_t)scratch & 15u) || ((uintptr_t)inputs & 7u) || ((uintptr_t)outputs & 7u) || ((uintptr_t)forward_buffer & 7u)) return SDN_E_BADARG;
     int rc = pack(weights, scratch, in_dim, W, L, 0, 1, st);
     if (rc) return rc;
-    FfArgs a{(const _Float16 *)inputs, (const unsigned char *)scratch, (_Float16 *)forward_buffer, nullptr, (_Float16 *)outputs, B, in_dim, 16, L, act};
+    FfArgs a{(const _Float16 *)inputs, (const unsigned char *)scratch, (_Float16 *)forward_buffer, nullptr, (_Float16 *)outputs, B, in_dim, 16, L, act,
+             total_frags_host(in_dim, W, L, 0, 1)};
     return forward_buffer ? launch_fused<1>(W, a, st) : launch_fused<0>(W, a, st);
 }
 
@@ -560,7 +293,7 @@ int sdn_ffmlp_backward(const void *grad, const void *inputs, const void *weights
     int rc = pack(weights, scratch, in, W, L, 1, calc_grad_inputs ? 1 : 0, st);
     if (rc) return rc;
     FfArgs a{(const _Float16 *)grad, (const unsigned char *)scratch, (_Float16 *)backward_buffer, (const _Float16 *)forward_buffer,
-             calc_grad_inputs ? (_Float16 *)grad_inputs : nullptr, B, 16, in, L, activation};
+             calc_grad_inputs ? (_Float16 *)grad_inputs : nullptr, B, 16, in, L, activation, total_frags_host(in, W, L, 1, calc_grad_inputs ? 1 : 0)};
     rc = launch_fused<2>(W, a, st);
     if (rc) return rc;
 
@@ -578,7 +311,7 @@ int sdn_ffmlp_backward(const void *grad, const void *inputs, const void *weights
         d.rows_per_split = sdn_div_up(sdn_div_up(B, ns), (uint32_t)kDwRows) * kDwRows;
         const uint32_t ns_used = sdn_div_up(B, d.rows_per_split);
         hipLaunchKernelGGL(k_ffmlp_dw, dim3(ns_used, blocks), dim3(256), 0, st, d);
-        hipLaunchKernelGGL(k_ffmlp_dw_reduce, dim3(sdn_div_up(M * N, 256u)), dim3(256), 0, st, partial, ns_used, M, N, d.Mpad, d.Npad, out);
+        hipLaunchKernelGGL(k_ffmlp_dw_reduce, dim3(sdn_div_up(M * N, 64u)), dim3(256), 0, st, partial, ns_used, M, N, d.Mpad, d.Npad, out);
         return sdn_launch_status();
     };
     const size_t BW = (size_t)B * W;

@@ -31,9 +31,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=2 ** 21)
+    ap.add_argument("--only", type=int, default=-1, help="index of the single configuration to run")
     args = ap.parse_args()
     B = args.batch
-    for in_dim, out_dim, hidden, L in [(16, 16, 64, 2), (32, 16, 64, 4), (32, 16, 128, 8), (32, 16, 256, 4), (16, 16, 16, 2), (32, 16, 32, 3)]:
+    configs = [(16, 16, 64, 2), (32, 16, 64, 4), (32, 16, 128, 8), (32, 16, 256, 4), (16, 16, 16, 2), (32, 16, 32, 3)]
+    if args.only >= 0:
+        configs = configs[args.only:args.only + 1]
+    for in_dim, out_dim, hidden, L in configs:
         net = ffmlp.FFMLP(in_dim, out_dim, hidden, L).cuda()
         lin = torch.nn.Sequential()
         dims = [in_dim] + [hidden] * L + [out_dim]
