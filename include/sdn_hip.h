@@ -38,6 +38,7 @@ extern "C" {
 
 #define SDN_E_BADARG (-1)      /* null pointer / zero size where not allowed            */
 #define SDN_E_UNSUPPORTED (-2) /* D, C, degree ... outside what the reference supports */
+#define SDN_E_TIMEOUT (-3)     /* a frame driver waited 20 s for an iteration that never reported back */
 
 /* Library / build identification ("gfx950"), for load checks. */
 const char *sdn_version(void);
@@ -276,6 +277,19 @@ int sdn_render_step_f16_ev(const SdnRenderCtx *ctx, uint32_t bound_alive, void *
 int sdn_render_frame_f16(const SdnRenderCtx *ctx, float bg_color, float *image_out, float *depth_out, void *stream,
                          void *side_stream, void **ev_main, void **ev_copy, int32_t *host_snap, void **ev_field,
                          uint32_t max_field_events, uint32_t *iterations_out);
+/* Read-back memory for the frame drivers: 32 bytes per ray group of coherent, device-mapped host memory.  When `host_snap`
+ * comes from here the loop kernels publish every iteration's survivor count into it with one 64-bit system-scope store and
+ * the driver polls it (no event record / stream wait / copy per iteration); any other pinned memory selects the event +
+ * copy path described above.  Returns NULL on failure. */
+void *sdn_host_mailbox_alloc(uint32_t groups);
+int sdn_host_mailbox_free(void *mailbox);
+/* The same for `groups` (<= 16) disjoint groups of a frame's rays, each with its own context / output / stream / side
+ * stream, driven round-robin by the calling thread so that the groups' kernels overlap on the device.  ev_main / ev_copy:
+ * 4 events per group (group g uses [4g, 4g+4)); host_snap: 8 pinned ints per group; iterations_out: one per group or NULL.
+ * The caller orders the group streams after its own work and joins them afterwards. */
+int sdn_render_frame_groups_f16(const SdnRenderCtx *const *ctxs, uint32_t groups, float bg_color, float *const *image_outs,
+                                float *const *depth_outs, void *const *streams, void *const *side_streams, void **ev_main,
+                                void **ev_copy, int32_t *host_snap, uint32_t *iterations_out);
 /* image_out [N,3] = image + (1 - weights_sum) * bg; depth_out [N] = clamp(depth - nears, 0) / (fars - nears). */
 int sdn_render_finish(const SdnRenderCtx *ctx, float bg_color, float *image_out, float *depth_out, void *stream);
 

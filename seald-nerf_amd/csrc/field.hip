@@ -36,6 +36,10 @@
 #include "grid_common.h"
 #include "sh_eval.h"
 
+#ifndef SDN_ABL
+#define SDN_ABL 0   // timing-experiment switches (tools/field_microbench.py); 0 in every shipped build
+#endif
+
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -53,6 +57,10 @@ constexpr int kBlkC2 = kBlkC1 + 8;        // 1 Mt x 4 ks
 constexpr int kBlkTotal = kBlkC2 + 4;     // 240
 static_assert(kBlkTotal - kBlkD7 == 32, "the tail stage must be exactly one 32 KiB buffer");
 
+#ifndef SDN_GRID_BATCH
+#define SDN_GRID_BATCH 8
+#endif
+constexpr int kGridBatch = SDN_GRID_BATCH;   // grid levels (per lane-half) whose gathers are in flight together
 constexpr int kStageBytes = 32768;
 constexpr int kWaves = 8;                 // waves per workgroup, 32 points each; two workgroups per CU = 4 waves per SIMD
 constexpr int kPointsPerWG = 32 * kWaves;
@@ -188,7 +196,11 @@ __global__ void __launch_bounds__(64 * kWaves, 4) k_field_f16(FieldArgs P, Tiled
                     const int pr = q >> 1, f = pr / 3, dd = pr % 3;
                     // kernel_freq (freqencoder.cu:52-56): sin(x * 2^f + (col % 2) * pi/2), same float argument as encoders.hip
                     const float arg = scalbnf(xs[dd], f) * fscale + (float)(q & 1) * (3.141592653589793f / 2);
+#if SDN_ABL == 1
+                    v = arg;
+#else
                     v = fast_sin(arg);
+#endif
                 } else if (q == 30) {
                     v = h ? x2 : x0;
                 } else {
@@ -212,7 +224,11 @@ __global__ void __launch_bounds__(64 * kWaves, 4) k_field_f16(FieldArgs P, Tiled
     }
 
     // ---------------- deform layers 1..6 (128 -> 128, ReLU): stage l+1 uses buffer (l+1)&1 ----------------
+#if SDN_ABL == 4
+    for (int l = 5; l < 6; l++) {
+#else
     for (int l = 0; l < 6; l++) {
+#endif
         const unsigned char *cur = s_w[(l + 1) & 1];
         #pragma unroll
         for (int t = 0; t < 4; t++) acc_to_frags<true>(acc[t], bf[2 * t], bf[2 * t + 1]);
@@ -265,24 +281,30 @@ __global__ void __launch_bounds__(64 * kWaves, 4) k_field_f16(FieldArgs P, Tiled
 
     // ---------------- grid encode: lane-half h evaluates levels 8h .. 8h+7 ----------------
     half8 gf[2];
+#if SDN_ABL == 3
+    #pragma unroll
+    for (int j = 0; j < 8; j++) { gf[0][j] = (_Float16)u[j % 3]; gf[1][j] = (_Float16)u[(j + 1) % 3]; }
+    if (false)
+#endif
     {
         const bool oob = (u[0] < 0) | (u[0] > 1) | (u[1] < 0) | (u[1] > 1) | (u[2] < 0) | (u[2] > 1);
-        // two batches of 4 levels: the 32 row gathers of a batch are issued back to back (independent loads, L2 / Infinity
-        // Cache latency overlapped) before any of them is consumed
+        // The x and x+1 corners of a (y, z) corner pair are neighbouring table rows, so one 8-byte gather fetches both:
+        // 4 gathers per level instead of 8 (the gather address rate, not bytes, is what this phase is bound by).  The loads of
+        // kGridBatch levels are issued back to back (independent, L2 / Infinity Cache latency overlapped) before any is consumed.
         #pragma unroll
-        for (int lb = 0; lb < 2; lb++) {
-            float2 vals[4][8];
-            float pos[4][3];
+        for (int lb = 0; lb < 8 / kGridBatch; lb++) {
+            uint2 pairs[kGridBatch][4];
+            float pos[kGridBatch][3];
             #pragma unroll
-            for (int lq = 0; lq < 4; lq++) {
-                const int li = lb * 4 + lq;
+            for (int lq = 0; lq < kGridBatch; lq++) {
+                const int li = lb * kGridBatch + lq;
                 const uint32_t offset = h ? lv.offset[8 + li] : lv.offset[li];
                 const uint32_t s1 = h ? lv.s1[8 + li] : lv.s1[li];
                 const uint32_t s2 = h ? lv.s2[8 + li] : lv.s2[li];
                 const uint32_t hsize = h ? lv.hsize[8 + li] : lv.hsize[li];
                 const uint32_t mask = h ? lv.mask[8 + li] : lv.mask[li];
                 const float scale = h ? lv.scale[8 + li] : lv.scale[li];
-                const __half2 *__restrict__ tab = reinterpret_cast<const __half2 *>(P.table) + offset;
+                const uint32_t *__restrict__ tab = reinterpret_cast<const uint32_t *>(P.table) + offset;   // one row = one half2
                 uint32_t pg[3];
                 #pragma unroll
                 for (int d = 0; d < 3; d++) {
@@ -292,29 +314,42 @@ __global__ void __launch_bounds__(64 * kWaves, 4) k_field_f16(FieldArgs P, Tiled
                 }
                 const uint32_t base = oob ? 0u : pg[0] + pg[1] * s1 + pg[2] * s2;  // uint32 wrap-around as in get_grid_index
                 #pragma unroll
-                for (uint32_t idx = 0; idx < 8; idx++) {
-                    // `index % hashmap_size` of get_grid_index without a division and without a branch (a branch per corner
-                    // would serialise the gathers): capped levels have a power-of-two row count (AND); dense levels hold every
-                    // (res+1)^3 corner, so an in-range point never wraps -- the min() only guards memory safety.
-                    uint32_t row = base + (idx & 1u) + ((idx & 2u) ? s1 : 0u) + ((idx & 4u) ? s2 : 0u);
-                    row = min(row & mask, hsize - 1u);
-                    vals[lq][idx] = __half22float2(tab[row]);
+                for (uint32_t c = 0; c < 4; c++) {
+                    // `index % hashmap_size` of get_grid_index without a division: capped levels have a power-of-two row count
+                    // (AND); dense levels hold every (res+1)^3 corner, so an in-range point never wraps and x+1 is the next row.
+                    // On a capped level the x corner may be the last row, the x+1 corner then row 0: rare, patched below.
+                    const uint32_t row0 = (base + ((c & 1u) ? s1 : 0u) + ((c & 2u) ? s2 : 0u)) & mask;
+                    const uint32_t rl = min(row0, hsize - 2u);          // the pair (rl, rl + 1) is always inside the level
+                    uint2 v;
+#if SDN_ABL == 2
+                    v = make_uint2(rl, rl + 1u);
+#else
+                    __builtin_memcpy(&v, tab + rl, 8);                  // 4-byte aligned 8-byte gather
+                    if (row0 > rl) {                                     // row0 == hsize - 1: x corner = second row of the pair, x+1 corner wraps
+                        v.x = v.y;
+                        v.y = tab[(row0 + 1u) & mask];
+                    }
+#endif
+                    pairs[lq][c] = v;
                 }
             }
             #pragma unroll
-            for (int lq = 0; lq < 4; lq++) {
+            for (int lq = 0; lq < kGridBatch; lq++) {
                 float r0 = 0, r1 = 0;
                 #pragma unroll
                 for (uint32_t idx = 0; idx < 8; idx++) {  // kernel_grid: half += float * half, rounded to half each step
                     float w = 1;
                     #pragma unroll
                     for (uint32_t d = 0; d < 3; d++) w *= (idx & (1u << d)) ? pos[lq][d] : 1 - pos[lq][d];
-                    r0 = round_h(r0 + w * vals[lq][idx].x);
-                    r1 = round_h(r1 + w * vals[lq][idx].y);
+                    const uint32_t bits = (idx & 1u) ? pairs[lq][idx >> 1].y : pairs[lq][idx >> 1].x;
+                    const float2 val = __half22float2(__builtin_bit_cast(__half2, bits));
+                    r0 = round_h(r0 + w * val.x);
+                    r1 = round_h(r1 + w * val.y);
                 }
                 if (oob) { r0 = 0; r1 = 0; }
-                gf[lb][2 * lq] = (_Float16)r0;
-                gf[lb][2 * lq + 1] = (_Float16)r1;
+                const int li = lb * kGridBatch + lq;
+                gf[li >> 2][2 * (li & 3)] = (_Float16)r0;
+                gf[li >> 2][2 * (li & 3) + 1] = (_Float16)r1;
             }
         }
     }

@@ -625,6 +625,10 @@ __device__ __forceinline__ void live_append(uint32_t step, uint32_t n, uint32_t 
 }
 
 // Resumes the compositing of one ray over its n_step slots (raymarching.cu:845-904).  Returns true if the ray survives.
+// The per-ray state and -- in the n_step == 8 case the loop spends most of its iterations in -- all 8 slots of the ray
+// (8 sigmas, 24 colours, 16 deltas: twelve 16-byte loads) are fetched before the serial recurrence starts, so the ray pays one
+// memory round trip instead of one per sample (a lane is a ray here and there is at most one wave per SIMD to hide latency
+// behind); the arithmetic and its order, including the two early exits, are the reference's.
 __device__ __forceinline__ bool composite_ray(int index, uint32_t n_step, float T_thresh, const float *s, const float *c, const float *dl,
                                               float *__restrict__ rays_t, float *__restrict__ weights_sum, float *__restrict__ depth,
                                               float *__restrict__ image) {
@@ -632,17 +636,42 @@ __device__ __forceinline__ bool composite_ray(int index, uint32_t n_step, float 
     float weight_sum = weights_sum[index], d = depth[index];
     float r = image[(size_t)index * 3], g = image[(size_t)index * 3 + 1], b = image[(size_t)index * 3 + 2];
     uint32_t step = 0;
-    while (step < n_step) {
-        if (dl[0] == 0) break;
-        const float alpha = 1.0f - sdn_exp_cr(-s[0] * dl[0]);
-        const float T = 1 - weight_sum;
-        const float weight = alpha * T;
-        weight_sum += weight;
-        t += dl[1];
-        d += weight * t;
-        r += weight * c[0]; g += weight * c[1]; b += weight * c[2];
-        if (T < T_thresh) break;
-        s++; c += 3; dl += 2; step++;
+    if (n_step == 8) {
+        float sv[8], cv[24], dv[16];
+        #pragma unroll
+        for (int q = 0; q < 2; q++) *reinterpret_cast<float4 *>(sv + 4 * q) = *reinterpret_cast<const float4 *>(s + 4 * q);
+        #pragma unroll
+        for (int q = 0; q < 6; q++) *reinterpret_cast<float4 *>(cv + 4 * q) = *reinterpret_cast<const float4 *>(c + 4 * q);
+        #pragma unroll
+        for (int q = 0; q < 4; q++) *reinterpret_cast<float4 *>(dv + 4 * q) = *reinterpret_cast<const float4 *>(dl + 4 * q);
+        bool open = true;   // false once the reference's loop would have left through a break
+        #pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (open && dv[2 * k] == 0) open = false;
+            if (open) {
+                const float alpha = 1.0f - sdn_exp_cr(-sv[k] * dv[2 * k]);
+                const float T = 1 - weight_sum;
+                const float weight = alpha * T;
+                weight_sum += weight;
+                t += dv[2 * k + 1];
+                d += weight * t;
+                r += weight * cv[3 * k]; g += weight * cv[3 * k + 1]; b += weight * cv[3 * k + 2];
+                if (T < T_thresh) open = false; else step++;
+            }
+        }
+    } else {
+        while (step < n_step) {
+            if (dl[0] == 0) break;
+            const float alpha = 1.0f - sdn_exp_cr(-s[0] * dl[0]);
+            const float T = 1 - weight_sum;
+            const float weight = alpha * T;
+            weight_sum += weight;
+            t += dl[1];
+            d += weight * t;
+            r += weight * c[0]; g += weight * c[1]; b += weight * c[2];
+            if (T < T_thresh) break;
+            s++; c += 3; dl += 2; step++;
+        }
     }
     const bool survives = !(step < n_step);
     if (survives) rays_t[index] = t;
@@ -803,7 +832,7 @@ __global__ void __launch_bounds__(kScanBlock) k_compact_scatter(const int32_t *_
 __global__ void __launch_bounds__(256) k_loop_init(uint32_t N, uint32_t max_steps, const float *__restrict__ nears, int32_t *__restrict__ alive_a,
                                                    float *__restrict__ rays_t, float *__restrict__ weights_sum, float *__restrict__ depth,
                                                    float *__restrict__ image, int32_t *__restrict__ state, int32_t *__restrict__ live_counts,
-                                                   uint32_t n_counters) {
+                                                   uint32_t n_counters, unsigned long long mailbox, uint32_t frame_tag) {
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
     if (n < N) {
         alive_a[n] = (int32_t)n;
@@ -816,6 +845,24 @@ __global__ void __launch_bounds__(256) k_loop_init(uint32_t N, uint32_t max_step
         state[0] = (int32_t)N; state[1] = 1; state[2] = 0; state[3] = 0; state[4] = 0;
         state[5] = (int32_t)N; state[6] = (int32_t)max_steps; state[7] = 0;
         for (int k = 8; k < 16; k++) state[k] = 0;  // [8] frozen list length of the steady mode, [9] survivor accumulator
+        state[10] = (int32_t)(uint32_t)mailbox;      // [10],[11] host mailbox (device-visible pointer, 0 = none), [12] frame tag
+        state[11] = (int32_t)(uint32_t)(mailbox >> 32);
+        state[12] = (int32_t)frame_tag;
+    }
+}
+
+// Per-iteration snapshot {alive rays entering the next iteration, index of that iteration}: into the device ring `snap`
+// (4 deep, immutable once written: the host may copy it out while the next iteration runs) and, when the frame driver
+// registered a mailbox in coherent host memory, as ONE 64-bit system-scope store {tag : n_alive} the host polls for --
+// no event, no copy, no stream wait on the critical path.  tag = frame_tag << 16 | (call + 1).
+__device__ __forceinline__ void publish_snapshot(int32_t *__restrict__ state, int32_t *__restrict__ snap, int32_t call) {
+    snap[(call & 3) * 2] = state[0];
+    snap[(call & 3) * 2 + 1] = call + 1;
+    const unsigned long long mb = ((unsigned long long)(uint32_t)state[11] << 32) | (uint32_t)state[10];
+    if (mb) {
+        const unsigned long long tag = ((uint32_t)state[12] << 16) | (uint32_t)(call + 1);
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(mb) + (call & 3), (tag << 32) | (uint32_t)state[0], __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -841,8 +888,7 @@ __global__ void k_loop_advance(int32_t *__restrict__ state, const int32_t *__res
             state[1] = ns > 8 ? 8 : (ns < 1 ? 1 : ns);
         }
     }
-    snap[(call & 3) * 2] = state[0];
-    snap[(call & 3) * 2 + 1] = call + 1;
+    publish_snapshot(state, snap, call);
 }
 
 __device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t *lds4) {
@@ -913,8 +959,7 @@ __global__ void __launch_bounds__(256) k_scatter_advance(int32_t *__restrict__ a
                 state[1] = ns > 8 ? 8 : (ns < 1 ? 1 : ns);
             }
         }
-        snap[(call & 3) * 2] = state[0];
-        snap[(call & 3) * 2 + 1] = call + 1;
+        publish_snapshot(state, snap, call);
     }
 }
 
@@ -995,8 +1040,7 @@ __global__ void __launch_bounds__(256) k_composite_march(float T_thresh, int32_t
         if (state[2] >= state[6]) n_new = 0;
         state[0] = n_new;  // n_step stays 8: N / n_new >= 8 holds from here on
     }
-    snap[(call & 3) * 2] = state[0];
-    snap[(call & 3) * 2 + 1] = call + 1;
+    publish_snapshot(state, snap, call);
 }
 
 // image = image + (1 - weights_sum) * bg ; depth = clamp(depth - nears, 0) / (fars - nears)   (dnerf/renderer.py:378-379)
@@ -1018,10 +1062,10 @@ __global__ void __launch_bounds__(256) k_loop_finish(uint32_t N, const float *__
 namespace sdn_int {
 
 int loop_begin(uint32_t N, uint32_t max_steps, const float *nears, int32_t *alive_a, float *rays_t, float *weights_sum, float *depth,
-               float *image, int32_t *state, int32_t *live_counts, uint32_t n_counters, hipStream_t st) {
+               float *image, int32_t *state, int32_t *live_counts, uint32_t n_counters, void *mailbox, uint32_t frame_tag, hipStream_t st) {
     const uint32_t threads = N > n_counters ? N : n_counters;
     hipLaunchKernelGGL(k_loop_init, dim3(sdn_div_up(threads, 256u)), dim3(256), 0, st, N, max_steps, nears, alive_a, rays_t, weights_sum, depth,
-                       image, state, live_counts, n_counters);
+                       image, state, live_counts, n_counters, (unsigned long long)(uintptr_t)mailbox, frame_tag);
     return sdn_launch_status();
 }
 

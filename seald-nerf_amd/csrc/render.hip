@@ -7,8 +7,22 @@
 // iteration k runs; it only needs an UPPER BOUND of n_alive to size the grids (the survivor count it read back one
 // iteration earlier), and learns that the loop is over one iteration late (that iteration is a no-op).
 // The schedule -- n_step = clamp(N // n_alive, 1, 8), stop at max_steps -- and every sample are the reference's.
+#include <atomic>
+#include <chrono>
+#include <string.h>
+
 #include "sdn_common.h"
 #include "sdn_internal.h"
+
+namespace sdn_int {
+int render_begin(const SdnRenderCtx *c, void *mailbox, uint32_t frame_tag, hipStream_t st) {
+    int rc = loop_begin(c->N, c->max_steps, c->nears, c->alive_a, c->rays_t, c->weights_sum, c->depth, c->image, c->state, c->live_counts,
+                        c->n_counters, mailbox, frame_tag, st);
+    if (rc) return rc;
+    if (c->H == 128 && c->C == 1) rc = build_cull(c->bitfield, (uint32_t *)c->cull_bits, st);
+    return rc;
+}
+}  // namespace sdn_int
 
 extern "C" {
 
@@ -19,12 +33,7 @@ int sdn_render_begin(const SdnRenderCtx *c, void *stream) {
     if (!c || !c->rays_o || !c->rays_d || !c->nears || !c->fars || !c->bitfield || !c->alive_a || !c->alive_b || !c->rays_t ||
         !c->weights_sum || !c->depth || !c->image || !c->state || !c->live_counts || !c->cull_bits)
         return SDN_E_BADARG;
-    hipStream_t st = (hipStream_t)stream;
-    int rc = sdn_int::loop_begin(c->N, c->max_steps, c->nears, c->alive_a, c->rays_t, c->weights_sum, c->depth, c->image, c->state,
-                                 c->live_counts, c->n_counters, st);
-    if (rc) return rc;
-    if (c->H == 128 && c->C == 1) rc = sdn_int::build_cull(c->bitfield, (uint32_t *)c->cull_bits, st);
-    return rc;
+    return sdn_int::render_begin(c, nullptr, 0, (hipStream_t)stream);
 }
 
 int sdn_render_step_f16(const SdnRenderCtx *c, uint32_t bound_alive, void *stream) {
@@ -62,22 +71,50 @@ int sdn_render_step_f16_ev(const SdnRenderCtx *c, uint32_t bound_alive, void *ev
 //   ev_field: NULL or 2 * max_field_events hipEvent_t with timing enabled, recorded around the fused-field launches
 //   (pairs 2k, 2k+1 for iteration k; iterations beyond max_field_events are not timed);
 //   iterations_out: number of step calls enqueued (including the trailing no-op one).
-int sdn_render_frame_f16(const SdnRenderCtx *c, float bg_color, float *image_out, float *depth_out, void *stream, void *side_stream,
-                         void **ev_main, void **ev_copy, int32_t *host_snap, void **ev_field, uint32_t max_field_events,
-                         uint32_t *iterations_out) {
-    if (!c || !image_out || !depth_out || !side_stream || !ev_main || !ev_copy || !host_snap) return SDN_E_BADARG;
-    hipStream_t st = (hipStream_t)stream, side = (hipStream_t)side_stream;
-    int rc = sdn_render_begin(c, stream);
-    if (rc) return rc;
-    int32_t *snap_dev = c->trace + 2 * (size_t)c->n_counters;
-    const uint32_t *cull = (c->H == 128 && c->C == 1) ? (const uint32_t *)c->cull_bits : nullptr;
-    uint32_t bound = c->N, it = 0;
-    bool steady = false;  // see k_composite_march: two launches per iteration once n_alive <= N / 8
-    for (;;) {
+}  // extern "C"
+
+namespace {
+
+// One ray group's loop as a two-phase state machine, so that one host thread can drive several groups round-robin.
+struct FrameRun {
+    const SdnRenderCtx *c;
+    hipStream_t st, side;
+    void **ev_main, **ev_copy, **ev_field;
+    int32_t *host_snap;
+    uint32_t max_field_events;
+    uint32_t bound, it;
+    bool steady, done;   // steady: see k_composite_march -- two launches per iteration once n_alive <= N / 8
+    // Mailbox mode: host_snap is coherent (fine-grained) mapped host memory (sdn_host_mailbox_alloc), the kernels publish each
+    // iteration's {tag : n_alive} into it with one 64-bit system-scope store and the host polls -- the main stream then carries
+    // nothing but kernels (no event record / stream wait / copy / event wait per iteration).
+    void *mail_dev = nullptr;
+    uint32_t tag = 0;
+
+    int begin() {
+        bound = c->N; it = 0; steady = false; done = false;
+        mail_dev = nullptr;
+        unsigned int flags = 0;
+        void *dptr = nullptr;
+        if (hipHostGetFlags(&flags, host_snap) == hipSuccess && (flags & hipHostMallocCoherent) &&
+            hipHostGetDevicePointer(&dptr, host_snap, 0) == hipSuccess && dptr) {
+            static std::atomic<uint32_t> frame_seq{0};
+            tag = (frame_seq.fetch_add(1) % 0x7FFFu) + 1u;   // 1 .. 32767: stale publications of an earlier frame never match
+            mail_dev = dptr;
+        } else {
+            (void)hipGetLastError();
+        }
+        return sdn_int::render_begin(c, mail_dev, tag, st);
+    }
+    const uint32_t *cull() const { return (c->H == 128 && c->C == 1) ? (const uint32_t *)c->cull_bits : nullptr; }
+
+    // enqueue iteration `it` and the asynchronous read-back of its survivor count
+    int enqueue() {
+        int32_t *snap_dev = c->trace + 2 * (size_t)c->n_counters;
         void *e0 = (ev_field && it < max_field_events) ? ev_field[2 * it] : nullptr;
         void *e1 = (ev_field && it < max_field_events) ? ev_field[2 * it + 1] : nullptr;
+        int rc;
         if (!steady) {
-            rc = sdn_render_step_f16_ev(c, bound, e0, e1, stream);
+            rc = sdn_render_step_f16_ev(c, bound, e0, e1, st);
         } else {
             uint64_t m_bound = (uint64_t)bound * 8u;
             if (m_bound > c->N) m_bound = c->N;
@@ -89,40 +126,133 @@ int sdn_render_frame_f16(const SdnRenderCtx *c, float bg_color, float *image_out
             if (!rc)
                 rc = sdn_int::loop_composite_march(bound, c->T_thresh, c->alive_a, c->alive_b, c->rays_t, c->rays_o, c->rays_d, c->bound,
                                                    c->dt_gamma, c->max_steps, c->C, c->H, c->bitfield, c->fars, c->sigmas, c->rgbs, c->xyzs,
-                                                   c->dirs, c->deltas, c->weights_sum, c->depth, c->image, cull, c->live_idx,
+                                                   c->dirs, c->deltas, c->weights_sum, c->depth, c->image, cull(), c->live_idx,
                                                    (uint32_t *)c->live_counts, c->state, c->n_out, c->trace, snap_dev, st);
         }
         if (rc) return rc;
+        if (mail_dev) return 0;
         const uint32_t slot = it & 3u;
         hipError_t e = hipEventRecord((hipEvent_t)ev_main[slot], st);
         if (e == hipSuccess) e = hipStreamWaitEvent(side, (hipEvent_t)ev_main[slot], 0);
         if (e == hipSuccess) e = hipMemcpyAsync(host_snap + 2 * slot, snap_dev + 2 * slot, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, side);
         if (e == hipSuccess) e = hipEventRecord((hipEvent_t)ev_copy[slot], side);
-        if (e != hipSuccess) return (int)e;
+        return (int)e;
+    }
+
+    // wait for the survivor count of iteration it-1 (iteration `it` is already enqueued), then advance
+    int settle() {
         if (it >= 1) {
             const uint32_t prev = (it - 1) & 3u;
-            e = hipEventSynchronize((hipEvent_t)ev_copy[prev]);
-            if (e != hipSuccess) return (int)e;
-            const int32_t n_prev = host_snap[2 * prev];  // alive rays entering iteration `it` (already enqueued)
-            if (n_prev <= 0) break;
+            int32_t n_prev;
+            if (mail_dev) {
+                const uint64_t want = ((uint64_t)tag << 16) | it;     // iteration it-1 publishes call + 1 == it
+                const uint64_t *word = reinterpret_cast<const uint64_t *>(host_snap) + prev;
+                uint64_t v;
+                uint32_t spins = 0;
+                auto t0 = std::chrono::steady_clock::now();
+                while (((v = __atomic_load_n(word, __ATOMIC_ACQUIRE)) >> 32) != want) {
+                    if ((++spins & 0xFFFFu) == 0) {
+                        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return SDN_E_TIMEOUT;
+                        hipError_t q = hipStreamQuery(st);             // a faulted kernel never publishes: surface the error
+                        if (q != hipSuccess && q != hipErrorNotReady) return (int)q;
+                    }
+                }
+                n_prev = (int32_t)(uint32_t)v;
+            } else {
+                hipError_t e = hipEventSynchronize((hipEvent_t)ev_copy[prev]);
+                if (e != hipSuccess) return (int)e;
+                n_prev = host_snap[2 * prev];
+            }
+            // n_prev: alive rays entering iteration `it`
+            if (n_prev <= 0) { done = true; return 0; }
             if (!steady) {
                 bound = (uint32_t)n_prev;
                 if ((uint64_t)n_prev * 8u <= c->N) {
-                    // iteration `it` (enqueued above, normal mode) ends with a compacted list; freeze it and march iteration it+1
-                    rc = sdn_int::loop_steady_begin(bound, c->alive_a, c->alive_b, c->rays_t, c->rays_o, c->rays_d, c->bound, c->dt_gamma,
-                                                    c->max_steps, c->C, c->H, c->bitfield, c->fars, c->xyzs, c->dirs, c->deltas, cull,
-                                                    c->live_idx, (uint32_t *)c->live_counts, c->state, st);
+                    // iteration `it` (enqueued, normal mode) ends with a compacted list; freeze it and march iteration it+1
+                    int rc = sdn_int::loop_steady_begin(bound, c->alive_a, c->alive_b, c->rays_t, c->rays_o, c->rays_d, c->bound, c->dt_gamma,
+                                                        c->max_steps, c->C, c->H, c->bitfield, c->fars, c->xyzs, c->dirs, c->deltas, cull(),
+                                                        c->live_idx, (uint32_t *)c->live_counts, c->state, st);
                     if (rc) return rc;
                     steady = true;
                 }
             }
         }
         it++;
-        if (it > c->max_steps + 1) break;
+        if (it > c->max_steps + 1) done = true;
+        return 0;
     }
-    if (iterations_out) *iterations_out = it + 1;
+};
+
+}  // namespace
+
+extern "C" {
+
+int sdn_render_frame_f16(const SdnRenderCtx *c, float bg_color, float *image_out, float *depth_out, void *stream, void *side_stream,
+                         void **ev_main, void **ev_copy, int32_t *host_snap, void **ev_field, uint32_t max_field_events,
+                         uint32_t *iterations_out) {
+    if (!c || !image_out || !depth_out || !side_stream || !ev_main || !ev_copy || !host_snap) return SDN_E_BADARG;
+    FrameRun r{c, (hipStream_t)stream, (hipStream_t)side_stream, ev_main, ev_copy, ev_field, host_snap, max_field_events, 0, 0, false, false};
+    int rc = r.begin();
+    while (!rc && !r.done) {
+        rc = r.enqueue();
+        if (!rc) rc = r.settle();
+    }
+    if (rc) return rc;
+    if (iterations_out) *iterations_out = r.it + 1;
     return sdn_render_finish(c, bg_color, image_out, depth_out, stream);
 }
+
+// The same loop for G disjoint groups of a frame's rays, each with its own context, stream and read-back ring, driven
+// round-robin by this one host thread: every group's next iteration is enqueued before any read-back is waited for, so the
+// latency-bound kernels of one group (marching chains, the small compositing / bookkeeping launches, launch gaps) run
+// under the throughput-bound field kernel of another, and two half-size field kernels that share the CUs run out of phase
+// instead of in lock-step.  Per-ray results do not depend on the grouping.  Arrays are indexed by group;
+// ev_main / ev_copy hold 4 events per group (group g uses [4g, 4g+4)), host_snap 8 ints per group.
+int sdn_render_frame_groups_f16(const SdnRenderCtx *const *ctxs, uint32_t groups, float bg_color, float *const *image_outs,
+                                float *const *depth_outs, void *const *streams, void *const *side_streams, void **ev_main, void **ev_copy,
+                                int32_t *host_snap, uint32_t *iterations_out) {
+    constexpr uint32_t kMaxGroups = 16;
+    if (!ctxs || groups == 0 || groups > kMaxGroups || !image_outs || !depth_outs || !streams || !side_streams || !ev_main || !ev_copy ||
+        !host_snap)
+        return SDN_E_BADARG;
+    FrameRun runs[kMaxGroups];
+    for (uint32_t g = 0; g < groups; g++) {
+        if (!ctxs[g] || !image_outs[g] || !depth_outs[g] || !side_streams[g]) return SDN_E_BADARG;
+        runs[g] = FrameRun{ctxs[g], (hipStream_t)streams[g], (hipStream_t)side_streams[g], ev_main + 4 * g, ev_copy + 4 * g, nullptr,
+                           host_snap + 8 * g, 0, 0, 0, false, false};
+        int rc = runs[g].begin();
+        if (rc) return rc;
+    }
+    for (uint32_t active = groups; active;) {
+        for (uint32_t g = 0; g < groups; g++)
+            if (!runs[g].done) { int rc = runs[g].enqueue(); if (rc) return rc; }
+        for (uint32_t g = 0; g < groups; g++) {
+            if (runs[g].done) continue;
+            int rc = runs[g].settle();
+            if (rc) return rc;
+            if (runs[g].done) {
+                active--;
+                rc = sdn_render_finish(runs[g].c, bg_color, image_outs[g], depth_outs[g], streams[g]);
+                if (rc) return rc;
+                if (iterations_out) iterations_out[g] = runs[g].it + 1;
+            }
+        }
+    }
+    return 0;
+}
+
+// 32 bytes (4 snapshot slots) per ray group of coherent, device-mapped host memory for the frame drivers' read-back.
+void *sdn_host_mailbox_alloc(uint32_t groups) {
+    void *p = nullptr;
+    if (groups == 0 || hipHostMalloc(&p, 32u * groups, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    memset(p, 0, 32u * groups);
+    return p;
+}
+
+int sdn_host_mailbox_free(void *p) { return p ? (int)hipHostFree(p) : 0; }
 
 int sdn_render_finish(const SdnRenderCtx *c, float bg_color, float *image_out, float *depth_out, void *stream) {
     if (!c || !image_out || !depth_out) return SDN_E_BADARG;

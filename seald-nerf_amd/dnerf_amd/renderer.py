@@ -429,7 +429,8 @@ class DeviceLoop:
                         cull_bits=torch.empty(int(lib.sdn_cull_grid_bytes()), dtype=torch.uint8, device=device))
         self.image_out, self.depth_out = z(N, 3), z(N)
         self.snap = self.buf["trace"][2 * n_counters: 2 * n_counters + 8].view(4, 2)  # device ring written by the advance
-        self.host_state = torch.zeros(self.RING, 2, dtype=i32).pin_memory()
+        from sdn_backend import HostMailbox
+        self.host_state = HostMailbox(1)   # the loop kernels publish each iteration's survivor count here; the driver polls it
         self.events = [torch.cuda.Event() for _ in range(self.RING)]
         self.copy_events = [torch.cuda.Event() for _ in range(self.RING)]
         self.side = torch.cuda.Stream(device=device)
@@ -462,21 +463,24 @@ class DeviceLoop:
             self._timing_queue.append((arr, recs))
         torch.cuda.synchronize()
 
-    @torch.no_grad()
-    def render(self, rays_o, rays_d, time, bg_color=1.0, want_stats=True):
+    def bind(self, rays_o, rays_d, time):
+        """Points the context at this frame's rays / time slice (launches near_far_from_aabb on the current stream)."""
         import ctypes
-        from sdn_backend import lib, check, ptr, stream
-        import sdn_backend
+        from sdn_backend import ptr
         c, model = self.ctx, self.model
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         assert rays_o.shape[0] == self.N
         nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, model.aabb_infer, model.min_near)
-        bitfield = model.density_bitfield[model.time_slice(time)]
+        # the time slice of the occupancy grid is a per-timestep constant like the field's time bias: resolved once per distinct
+        # `time` tensor state (the reference indexes with a device scalar every frame, dnerf/renderer.py:285, a host sync)
+        key = (time.data_ptr(), time._version, model.density_bitfield.data_ptr())
+        if getattr(self, "_slice_key", None) != key:
+            self._slice_key, self._slice = key, model.density_bitfield[model.time_slice(time)]
+        bitfield = self._slice
         c.rays_o, c.rays_d, c.nears, c.fars, c.bitfield = ptr(rays_o), ptr(rays_d), ptr(nears), ptr(fars), ptr(bitfield)
         c.field_bias0, c.zero_deform = self.field.bias0.data_ptr(), int(self.field.zero_deform)
-        st = stream()
-        cref = ctypes.byref(c)
+        self._frame_refs = (rays_o, rays_d, nears, fars, bitfield)  # keep the tensors alive while the frame is in flight
         cur = torch.cuda.current_stream()
         if self._handles is None:  # materialise raw hipEvent_t / hipStream_t handles once
             for e in self.events + self.copy_events:
@@ -485,16 +489,9 @@ class DeviceLoop:
             self._ev_copy = (ctypes.c_void_p * self.RING)(*[e.cuda_event for e in self.copy_events])
             self._iters = ctypes.c_uint32(0)
             self._handles = True
-        ev_field, n_ev, recs = None, 0, None
-        if sdn_backend.timers is not None and self._timing_queue:  # bench: time the fused-field launches in place
-            ev_field, recs = self._timing_queue.pop()
-            n_ev = self.MAX_TIMED
-        self.side.wait_stream(cur)
-        check(lib.sdn_render_frame_f16(cref, float(bg_color), ptr(self.image_out), ptr(self.depth_out), st, self.side.cuda_stream,
-                                       self._ev_main, self._ev_copy, self.host_state.data_ptr(), ev_field, n_ev,
-                                       ctypes.byref(self._iters)), "render_frame_f16")
-        if recs is not None:  # keep the pairs of the iterations that ran
-            sdn_backend.timers.records.setdefault("field_forward_f16", []).extend(recs[: min(n_ev, int(self._iters.value))])
+        return nears, fars
+
+    def collect(self, nears, fars, want_stats):
         out = {"image": self.image_out, "depth": self.depth_out, "weights_sum": self.buf["weights_sum"], "nears": nears, "fars": fars}
         if want_stats:
             iters = int(self.buf["state"][3].item())
@@ -503,18 +500,39 @@ class DeviceLoop:
             out["n_samples"] = int(self.buf["live_counts"][:iters].sum().item())
         return out
 
+    @torch.no_grad()
+    def render(self, rays_o, rays_d, time, bg_color=1.0, want_stats=True):
+        import ctypes
+        from sdn_backend import lib, check, ptr, stream
+        import sdn_backend
+        nears, fars = self.bind(rays_o, rays_d, time)
+        cur = torch.cuda.current_stream()
+        ev_field, n_ev, recs = None, 0, None
+        if sdn_backend.timers is not None and self._timing_queue:  # bench: time the fused-field launches in place
+            ev_field, recs = self._timing_queue.pop()
+            n_ev = self.MAX_TIMED
+        self.side.wait_stream(cur)
+        check(lib.sdn_render_frame_f16(ctypes.byref(self.ctx), float(bg_color), ptr(self.image_out), ptr(self.depth_out), stream(),
+                                       self.side.cuda_stream, self._ev_main, self._ev_copy, self.host_state.data_ptr(), ev_field, n_ev,
+                                       ctypes.byref(self._iters)), "render_frame_f16")
+        if recs is not None:  # keep the pairs of the iterations that ran
+            sdn_backend.timers.records.setdefault("field_forward_f16", []).extend(recs[: min(n_ev, int(self._iters.value))])
+        return self.collect(nears, fars, want_stats)
+
 
 class GroupedDeviceLoop:
-    """G independent device-driven loops over disjoint, interleaved subsets of the frame's rays, each on its own HIP stream
-    and driven by its own host thread (the native frame driver releases the GIL), so that the latency-bound phases of one
-    group (the marcher's dependent probe chains, launch / read-back gaps) overlap with the throughput-bound field kernel of
-    another.  Exact by construction: per-ray results do not depend on which rays share a launch; only the
+    """G independent device-driven loops over disjoint, interleaved subsets of the frame's rays, each on its own HIP stream,
+    all driven round-robin by ONE host thread inside `sdn_render_frame_groups_f16`, so that the latency-bound phases of one
+    group (the marcher's dependent probe chains, the small bookkeeping launches, launch / read-back gaps) run under the
+    throughput-bound field kernel of another, and the half-size field kernels that share the CUs run out of phase.
+    Exact by construction: per-ray results do not depend on which rays share a launch; only the
     per-group n_step schedule -- hence the number of samples marched past a ray's termination -- can differ from the
     one-group schedule when N_g // n_alive_g falls on the other side of an integer than N // n_alive."""
 
     def __init__(self, model, field, rays_o, rays_d, groups, W, device, **kw):
-        from concurrent.futures import ThreadPoolExecutor
+        import ctypes
         from .dist import shard_rays
+        from sdn_backend import SdnRenderCtx
         N = rays_o.shape[0]
         self.N, self.G, self.device = N, groups, device
         self.idx, self.rays, self.loops, self.streams = [], [], [], []
@@ -527,35 +545,48 @@ class GroupedDeviceLoop:
             self.streams.append(torch.cuda.Stream(device=device))
         self.image = torch.empty(N, 3, dtype=torch.float32, device=device)
         self.depth = torch.empty(N, dtype=torch.float32, device=device)
-        self.pool = ThreadPoolExecutor(max_workers=groups)
+        from sdn_backend import HostMailbox
+        self.host_state = HostMailbox(groups)
+        self._ctxs = (ctypes.POINTER(SdnRenderCtx) * groups)(*[ctypes.pointer(lp.ctx) for lp in self.loops])
+        self._iters = (ctypes.c_uint32 * groups)()
+        self._arrays = None
 
     def prepare_timing(self, frames):
-        for lp in self.loops:
-            lp.prepare_timing(frames)
-
-    def _one(self, g, time, bg_color, want_stats, timers):
-        import sdn_backend
-        torch.cuda.set_device(self.device)
-        with torch.cuda.stream(self.streams[g]):
-            sdn_backend.timers = timers  # module-global, set identically by every worker
-            out = self.loops[g].render(self.rays[g][0], self.rays[g][1], time, bg_color=bg_color, want_stats=want_stats)
-            self.image[self.idx[g]] = out["image"]
-            self.depth[self.idx[g]] = out["depth"]
-        return out
+        """The grouped driver does not time individual launches (its kernels overlap; a per-launch duration is not a rate)."""
 
     @torch.no_grad()
     def render(self, time, bg_color=1.0, want_stats=True):
-        import sdn_backend
+        import ctypes
+        from sdn_backend import lib, check
         cur = torch.cuda.current_stream()
-        for st in self.streams:
-            st.wait_stream(cur)
-        timers = sdn_backend.timers
-        futs = [self.pool.submit(self._one, g, time, bg_color, want_stats, timers) for g in range(self.G)]
-        outs = [f.result() for f in futs]
-        for st in self.streams:
-            cur.wait_stream(st)
+        bound = []
+        for g, lp in enumerate(self.loops):
+            self.streams[g].wait_stream(cur)
+            with torch.cuda.stream(self.streams[g]):
+                bound.append(lp.bind(self.rays[g][0], self.rays[g][1], time))
+                lp.side.wait_stream(self.streams[g])
+        if self._arrays is None:
+            vp = ctypes.c_void_p
+            G = self.G
+            self._arrays = dict(
+                images=(vp * G)(*[lp.image_out.data_ptr() for lp in self.loops]),
+                depths=(vp * G)(*[lp.depth_out.data_ptr() for lp in self.loops]),
+                streams=(vp * G)(*[s.cuda_stream for s in self.streams]),
+                sides=(vp * G)(*[lp.side.cuda_stream for lp in self.loops]),
+                ev_main=(vp * (4 * G))(*[e.cuda_event for lp in self.loops for e in lp.events]),
+                ev_copy=(vp * (4 * G))(*[e.cuda_event for lp in self.loops for e in lp.copy_events]))
+        a = self._arrays
+        check(lib.sdn_render_frame_groups_f16(self._ctxs, self.G, float(bg_color), a["images"], a["depths"], a["streams"], a["sides"],
+                                              a["ev_main"], a["ev_copy"], self.host_state.data_ptr(), self._iters), "render_frame_groups_f16")
+        outs = []
+        for g, lp in enumerate(self.loops):
+            with torch.cuda.stream(self.streams[g]):
+                self.image[self.idx[g]] = lp.image_out
+                self.depth[self.idx[g]] = lp.depth_out
+            cur.wait_stream(self.streams[g])
         res = {"image": self.image, "depth": self.depth}
         if want_stats:
+            outs = [lp.collect(bound[g][0], bound[g][1], True) for g, lp in enumerate(self.loops)]
             res["n_samples"] = sum(o["n_samples"] for o in outs)
             res["trace"] = max((o["trace"] for o in outs), key=len)
             res["group_traces"] = [o["trace"] for o in outs]

@@ -44,6 +44,8 @@ PROTOTYPES = {
     "sdn_render_step_f16_ev": [_vp, _u32, _vp, _vp, _vp],
     "sdn_render_finish": [_vp, _f32, _vp, _vp, _vp],
     "sdn_render_frame_f16": [_vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    "sdn_render_frame_groups_f16": [_vp, _u32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sdn_host_mailbox_free": [_vp],
     "sdn_field_forward_f16": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _f32, _u32, _f32, _f32, _i32, _vp, _vp, _vp],
     "sdn_ffmlp_forward": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp],
     "sdn_ffmlp_inference": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
@@ -78,6 +80,8 @@ if not os.path.exists(LIB_PATH):
 
 lib = ctypes.CDLL(LIB_PATH)
 lib.sdn_version.restype = ctypes.c_char_p
+lib.sdn_host_mailbox_alloc.restype = ctypes.c_void_p
+lib.sdn_host_mailbox_alloc.argtypes = [ctypes.c_uint32]
 for _name, _args in PROTOTYPES.items():
     _fn = getattr(lib, _name)
     _fn.argtypes = _args
@@ -98,8 +102,28 @@ class SdnError(RuntimeError):
 
 def check(rc, what):
     if rc != 0:
-        kind = {-1: "bad argument", -2: "unsupported configuration"}.get(rc, f"hipError_t {rc}")
+        kind = {-1: "bad argument", -2: "unsupported configuration", -3: "timed out waiting for the device"}.get(rc, f"hipError_t {rc}")
         raise SdnError(f"{what} failed: {kind}")
+
+
+class HostMailbox:
+    """Coherent, device-mapped host memory for the frame drivers' read-back (sdn_host_mailbox_alloc): 32 bytes per ray group."""
+
+    def __init__(self, groups=1):
+        self.ptr = lib.sdn_host_mailbox_alloc(int(groups))
+        if not self.ptr:
+            raise SdnError("sdn_host_mailbox_alloc failed")
+
+    def data_ptr(self):
+        return self.ptr
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                lib.sdn_host_mailbox_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
 
 
 def require_device():

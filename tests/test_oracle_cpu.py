@@ -240,7 +240,8 @@ def test_c_abi_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     import sdn_backend
-    declared = set(sdn_backend.PROTOTYPES) | set(sdn_backend.PROTOTYPES_U64) | set(sdn_backend.PROTOTYPES_U32) | {"sdn_version"}
+    declared = (set(sdn_backend.PROTOTYPES) | set(sdn_backend.PROTOTYPES_U64) | set(sdn_backend.PROTOTYPES_U32)
+                | {"sdn_version", "sdn_host_mailbox_alloc"})
     assert set(names) == declared, sorted(set(names) ^ declared)
 
 
