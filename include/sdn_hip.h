@@ -256,6 +256,11 @@ typedef struct SdnRenderCtx {
     uint32_t N, M_cap, n_counters, max_steps, C, H;
     float bound, dt_gamma, T_thresh, density_scale;
     int32_t zero_deform;
+    /* optional: when aabb is non-NULL the frame drivers compute nears / fars themselves (near_far_from_aabb with this box and
+     * min_near) into the caller's `nears` / `fars` buffers, on the frame's stream, before the loop starts */
+    const float *aabb;
+    float min_near;
+    int32_t reserved_;
 } SdnRenderCtx;
 
 /* Resets per-ray state (alive = 0..N-1, rays_t = nears, accumulators = 0), the loop record and the counters, and builds

@@ -16,6 +16,10 @@
 
 namespace sdn_int {
 int render_begin(const SdnRenderCtx *c, void *mailbox, uint32_t frame_tag, hipStream_t st) {
+    if (c->aabb) {  // nears / fars of this frame's rays, on the frame's stream (one Python round trip less per frame)
+        int rc0 = sdn_near_far_from_aabb(c->rays_o, c->rays_d, c->aabb, c->N, c->min_near, (float *)c->nears, (float *)c->fars, st);
+        if (rc0) return rc0;
+    }
     int rc = loop_begin(c->N, c->max_steps, c->nears, c->alive_a, c->rays_t, c->weights_sum, c->depth, c->image, c->state, c->live_counts,
                         c->n_counters, mailbox, frame_tag, st);
     if (rc) return rc;
@@ -29,10 +33,13 @@ extern "C" {
 int sdn_render_finish(const SdnRenderCtx *c, float bg_color, float *image_out, float *depth_out, void *stream);
 int sdn_render_step_f16_ev(const SdnRenderCtx *c, uint32_t bound_alive, void *ev_field_begin, void *ev_field_end, void *stream);
 
+static bool ctx_ok(const SdnRenderCtx *c) {
+    return c && c->rays_o && c->rays_d && c->nears && c->fars && c->bitfield && c->alive_a && c->alive_b && c->rays_t && c->weights_sum &&
+           c->depth && c->image && c->state && c->live_counts && c->cull_bits;
+}
+
 int sdn_render_begin(const SdnRenderCtx *c, void *stream) {
-    if (!c || !c->rays_o || !c->rays_d || !c->nears || !c->fars || !c->bitfield || !c->alive_a || !c->alive_b || !c->rays_t ||
-        !c->weights_sum || !c->depth || !c->image || !c->state || !c->live_counts || !c->cull_bits)
-        return SDN_E_BADARG;
+    if (!ctx_ok(c)) return SDN_E_BADARG;
     return sdn_int::render_begin(c, nullptr, 0, (hipStream_t)stream);
 }
 
@@ -91,6 +98,7 @@ struct FrameRun {
     uint32_t tag = 0;
 
     int begin() {
+        if (!ctx_ok(c)) return SDN_E_BADARG;
         bound = c->N; it = 0; steady = false; done = false;
         mail_dev = nullptr;
         unsigned int flags = 0;

@@ -425,7 +425,7 @@ class DeviceLoop:
                         xyzs=z(M, 3), dirs=z(M, 3), deltas=z(M, 2), sigmas=z(M), rgbs=z(M, 3), live_idx=z(M, dt=i32),
                         live_counts=torch.zeros(n_counters, dtype=i32, device=device), state=torch.zeros(16, dtype=i32, device=device),
                         trace=torch.zeros(2 * n_counters + 16, dtype=i32, device=device), n_out=torch.zeros(1, dtype=i32, device=device),
-                        block_totals=z((N + 255) // 256 + 1, dt=i32),
+                        block_totals=z((N + 255) // 256 + 1, dt=i32), nears=z(N), fars=z(N),
                         cull_bits=torch.empty(int(lib.sdn_cull_grid_bytes()), dtype=torch.uint8, device=device))
         self.image_out, self.depth_out = z(N, 3), z(N)
         self.snap = self.buf["trace"][2 * n_counters: 2 * n_counters + 8].view(4, 2)  # device ring written by the advance
@@ -471,14 +471,15 @@ class DeviceLoop:
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         assert rays_o.shape[0] == self.N
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, model.aabb_infer, model.min_near)
+        nears, fars = self.buf["nears"], self.buf["fars"]  # filled by the native driver (ctx.aabb / ctx.min_near)
+        c.aabb, c.min_near = ptr(model.aabb_infer, torch.float32, "aabb_infer"), float(model.min_near)
         # the time slice of the occupancy grid is a per-timestep constant like the field's time bias: resolved once per distinct
         # `time` tensor state (the reference indexes with a device scalar every frame, dnerf/renderer.py:285, a host sync)
         key = (time.data_ptr(), time._version, model.density_bitfield.data_ptr())
         if getattr(self, "_slice_key", None) != key:
             self._slice_key, self._slice = key, model.density_bitfield[model.time_slice(time)]
         bitfield = self._slice
-        c.rays_o, c.rays_d, c.nears, c.fars, c.bitfield = ptr(rays_o), ptr(rays_d), ptr(nears), ptr(fars), ptr(bitfield)
+        c.rays_o, c.rays_d, c.bitfield = ptr(rays_o, torch.float32, "rays_o"), ptr(rays_d, torch.float32, "rays_d"), ptr(bitfield)
         c.field_bias0, c.zero_deform = self.field.bias0.data_ptr(), int(self.field.zero_deform)
         self._frame_refs = (rays_o, rays_d, nears, fars, bitfield)  # keep the tensors alive while the frame is in flight
         cur = torch.cuda.current_stream()
