@@ -96,7 +96,7 @@ struct MarcherT {
     const uint8_t *__restrict__ grid;
     // FAST only: LDS copy of the fine bits of the cull grid's bounding box (one 64-bit word = one 4x4x4 voxel block)
     const unsigned long long *fine = nullptr;
-    int fx0 = 0, fy0 = 0, fz0 = 0, fnx = 0, fny = 0;
+    int fx0 = 0, fy0 = 0, fz0 = 0, fnx = 0, fny = 0, fnz = 0;
 
     __device__ __forceinline__ void init(const float *o, const float *d, float bound_, float dt_gamma_,
                                          uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid_) {
@@ -131,17 +131,19 @@ struct MarcherT {
             const int ny = (int)clampf_((y + 1) * halfH, 0.0f, Hm1);
             const int nz = (int)clampf_((z + 1) * halfH, 0.0f, Hm1);
             bool occ = false;
-            // an unmarked cull cell holds no occupied voxel: the fine bit (a dependent L2 load) is only fetched near the object
-            if (!cull_bits || cull_marked(cull_bits, nx >> 2, ny >> 2, nz >> 2)) {
-                if (fine) {
-                    // marked cells lie inside the cached box by construction; bit = Morton code of the low two bits per axis
-                    const int slot = (((nz >> 2) - fz0) * fny + ((ny >> 2) - fy0)) * fnx + ((nx >> 2) - fx0);
+            if (fine) {
+                // The LDS image holds the fine bits of every 4x4x4 block inside the bounding box of the marked cull cells, and
+                // every occupied voxel lies in a marked cell: one LDS read answers the probe inside the box (a block of an unmarked
+                // cell reads as zero), three register compares answer it outside.  bit = Morton code of the low two bits per axis.
+                const int bx = (nx >> 2) - fx0, by = (ny >> 2) - fy0, bz = (nz >> 2) - fz0;
+                if ((uint32_t)bx < (uint32_t)fnx && (uint32_t)by < (uint32_t)fny && (uint32_t)bz < (uint32_t)fnz) {
                     const uint32_t b = m2((uint32_t)nx & 3u) | (m2((uint32_t)ny & 3u) << 1) | (m2((uint32_t)nz & 3u) << 2);
-                    occ = (fine[slot] >> b) & 1ull;
-                } else {
-                    const uint32_t index = morton3D_8bit((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
-                    occ = grid[index >> 3] & (1u << (index & 7u));
+                    occ = (fine[(bz * fny + by) * fnx + bx] >> b) & 1ull;
                 }
+            } else if (!cull_bits || cull_marked(cull_bits, nx >> 2, ny >> 2, nz >> 2)) {
+                // an unmarked cull cell holds no occupied voxel: the fine bit (a dependent L2 load) is only fetched near the object
+                const uint32_t index = morton3D_8bit((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+                occ = grid[index >> 3] & (1u << (index & 7u));
             }
             if (occ) return true;
             const float tx = ((((float)nx + ex) * twoRH - 1) - x) * rdx;
@@ -228,22 +230,44 @@ __global__ void k_cull_meta_init(uint32_t *__restrict__ cull_bits) {
 // cannot produce a sample).  Otherwise t_end receives a parameter beyond which no marked cell is met any more: the
 // marcher may stop there -- the reference would only step through empty voxels from there to `far`.
 __device__ __forceinline__ bool ray_may_hit(const uint32_t *cull_bits, float ox, float oy, float oz, float dx, float dy, float dz,
-                                            float t, float far, float &t_end) {
+                                            float t, float far, float &t_end, int bx0, int by0, int bz0, int bnx, int bny, int bnz) {
     const float len = sqrtf(dx * dx + dy * dy + dz * dz);
     const float ds = (2.0f / kCullRes) / fmaxf(len, 1e-12f);  // parameter step = one cull cell along the ray
-    float s = t;
-    bool hit = false;
     t_end = far;
+    if (bnx <= 0 || bny <= 0 || bnz <= 0) return false;       // nothing is marked: nothing is occupied
+    // Marked cells only exist inside their bounding box: scan just the part of [t, far] that can be inside it (slab test,
+    // widened by one scan step against rounding), not the whole chord of the unit cube.
+    const float cw = 2.0f / kCullRes;
+    float s0 = t, s1 = far;
+    {
+        const float lo[3] = {(float)bx0 * cw - 1.0f, (float)by0 * cw - 1.0f, (float)bz0 * cw - 1.0f};
+        const float hi[3] = {(float)(bx0 + bnx) * cw - 1.0f, (float)(by0 + bny) * cw - 1.0f, (float)(bz0 + bnz) * cw - 1.0f};
+        const float o[3] = {ox, oy, oz}, d[3] = {dx, dy, dz};
+        #pragma unroll
+        for (int a = 0; a < 3; a++) {
+            if (d[a] != 0.0f) {
+                const float r = 1.0f / d[a];
+                const float ta = (lo[a] - o[a]) * r, tb = (hi[a] - o[a]) * r;
+                s0 = fmaxf(s0, fminf(ta, tb) - ds);
+                s1 = fminf(s1, fmaxf(ta, tb) + ds);
+            } else if (o[a] < lo[a] - cw || o[a] > hi[a] + cw) {
+                return false;                                  // parallel to the slab and outside it
+            }
+        }
+    }
+    if (!(s0 <= s1)) return false;
+    float s = s0;
+    bool hit = false;
     // bounded: a unit-cube diagonal is 2*sqrt(3) / (2/32) = 56 cells; anything longer (degenerate direction, huge far)
     // falls through to "may hit, no early end" and takes the ordinary marcher
     for (int it = 0; it < 96; it++, s += ds) {
-        const float ss = fminf(s, far);
+        const float ss = fminf(s, s1);
         const float x = clampf_(ox + ss * dx, -1.0f, 1.0f), y = clampf_(oy + ss * dy, -1.0f, 1.0f), z = clampf_(oz + ss * dz, -1.0f, 1.0f);
         const int cx = (int)fminf((x + 1) * (0.5f * kCullRes), (float)(kCullRes - 1));
         const int cy = (int)fminf((y + 1) * (0.5f * kCullRes), (float)(kCullRes - 1));
         const int cz = (int)fminf((z + 1) * (0.5f * kCullRes), (float)(kCullRes - 1));
         if (cull_marked(cull_bits, cx, cy, cz)) { hit = true; t_end = ss + ds; }
-        if (s >= far) return hit;
+        if (s >= s1) return hit;
     }
     t_end = far;
     return true;
@@ -542,7 +566,7 @@ __global__ void __launch_bounds__(256) k_composite_train_bwd(const float *__rest
 struct OccCache {
     const uint32_t *s_cull = nullptr;            // 32^3 mark bits
     const unsigned long long *fine = nullptr;    // fine bits of the marked bounding box (one word = 4x4x4 voxels)
-    int fx0 = 0, fy0 = 0, fz0 = 0, fnx = 0, fny = 0;
+    int fx0 = 0, fy0 = 0, fz0 = 0, fnx = 0, fny = 0, fnz = 0;   // bounding box of the marked cull cells (origin, extent)
 };
 
 // Cooperative load by a 256-thread workgroup; contains a barrier, so every thread of the workgroup must call it.
@@ -556,6 +580,7 @@ __device__ __forceinline__ void occ_cache_load(const uint32_t *__restrict__ cull
             oc.fx0 = meta[0]; oc.fy0 = meta[1]; oc.fz0 = meta[2];
             oc.fnx = meta[3] - oc.fx0 + 1; oc.fny = meta[4] - oc.fy0 + 1;
             const int fnz = meta[5] - oc.fz0 + 1;
+            oc.fnz = fnz;
             if (oc.fnx > 0 && oc.fny > 0 && fnz > 0 && (uint32_t)(oc.fnx * oc.fny * fnz) <= kFineCacheCells) {
                 const unsigned long long *__restrict__ blocks = reinterpret_cast<const unsigned long long *>(grid);
                 const int cells = oc.fnx * oc.fny * fnz;
@@ -576,12 +601,13 @@ __device__ __forceinline__ void occ_cache_load(const uint32_t *__restrict__ cull
 template <bool FAST>
 __device__ __forceinline__ uint32_t march_ray(MarcherT<FAST> &m, const OccCache &oc, float t, float far, uint32_t n_step, float *px, float *pd,
                                               float *pl) {
-    m.fine = oc.fine; m.fx0 = oc.fx0; m.fy0 = oc.fy0; m.fz0 = oc.fz0; m.fnx = oc.fnx; m.fny = oc.fny;
+    m.fine = oc.fine; m.fx0 = oc.fx0; m.fy0 = oc.fy0; m.fz0 = oc.fz0; m.fnx = oc.fnx; m.fny = oc.fny; m.fnz = oc.fnz;
     uint32_t step = 0;
     float last_t = t, x, y, z, dt;
     bool go = t < far;
     float t_end = far;
-    if (FAST && oc.s_cull && go) go = ray_may_hit(oc.s_cull, m.ox, m.oy, m.oz, m.dx, m.dy, m.dz, t, far, t_end);
+    if (FAST && oc.s_cull && go)
+        go = ray_may_hit(oc.s_cull, m.ox, m.oy, m.oz, m.dx, m.dy, m.dz, t, far, t_end, oc.fx0, oc.fy0, oc.fz0, oc.fnx, oc.fny, oc.fnz);
     if (go) {
         while (t < far && t < t_end && step < n_step) {
             if (m.probe(t, x, y, z, dt, oc.s_cull)) {
