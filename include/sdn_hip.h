@@ -261,6 +261,9 @@ typedef struct SdnRenderCtx {
     const float *aabb;
     float min_near;
     int32_t reserved_;
+    /* optional [N] scratch: per-ray cache of the cull-grid scan (the parameter beyond which a ray meets no marked cell), so
+     * that only a ray's first march of a frame scans; NULL = scan in every iteration */
+    float *rays_tend;
 } SdnRenderCtx;
 
 /* Resets per-ray state (alive = 0..N-1, rays_t = nears, accumulators = 0), the loop record and the counters, and builds

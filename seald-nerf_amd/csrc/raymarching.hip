@@ -598,16 +598,32 @@ __device__ __forceinline__ void occ_cache_load(const uint32_t *__restrict__ cull
 
 // Marches one ray from parameter t for up to n_step samples into its slots (the loop of raymarching.cu:750-804), zero-fills
 // the unused slots and returns the number of samples written.
+// tend (may be null): this ray's cached cull result.  The bound t_end found by ray_may_hit -- beyond it the ray meets no
+// marked cell -- is a property of the ray, not of where the scan started, so the device loop computes it on a ray's first
+// march and later iterations only compare (kTendUnset: not computed yet; kTendDead: the ray cannot produce a sample).
+constexpr float kTendUnset = -2.0f, kTendDead = -1.0f;
+// device loop: the cache's base pointer travels in the loop record (state[13], state[14]; 0 = no cache)
+__device__ __forceinline__ float *state_tend(const int32_t *__restrict__ state) {
+    return reinterpret_cast<float *>(((unsigned long long)(uint32_t)state[14] << 32) | (uint32_t)state[13]);
+}
 template <bool FAST>
 __device__ __forceinline__ uint32_t march_ray(MarcherT<FAST> &m, const OccCache &oc, float t, float far, uint32_t n_step, float *px, float *pd,
-                                              float *pl) {
+                                              float *pl, float *tend = nullptr) {
     m.fine = oc.fine; m.fx0 = oc.fx0; m.fy0 = oc.fy0; m.fz0 = oc.fz0; m.fnx = oc.fnx; m.fny = oc.fny; m.fnz = oc.fnz;
     uint32_t step = 0;
     float last_t = t, x, y, z, dt;
     bool go = t < far;
     float t_end = far;
-    if (FAST && oc.s_cull && go)
-        go = ray_may_hit(oc.s_cull, m.ox, m.oy, m.oz, m.dx, m.dy, m.dz, t, far, t_end, oc.fx0, oc.fy0, oc.fz0, oc.fnx, oc.fny, oc.fnz);
+    if (FAST && oc.s_cull && go) {
+        const float cached = tend ? *tend : kTendUnset;
+        if (cached != kTendUnset) {
+            t_end = cached;                 // kTendDead (< every t) ends the ray here
+            go = t < t_end;
+        } else {
+            go = ray_may_hit(oc.s_cull, m.ox, m.oy, m.oz, m.dx, m.dy, m.dz, t, far, t_end, oc.fx0, oc.fy0, oc.fz0, oc.fnx, oc.fny, oc.fnz);
+            if (tend) *tend = go ? t_end : kTendDead;
+        }
+    }
     if (go) {
         while (t < far && t < t_end && step < n_step) {
             if (m.probe(t, x, y, z, dt, oc.s_cull)) {
@@ -743,8 +759,10 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
         m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid);
         float t = rays_t[index];
         t += m.step_size(t) * (noises ? noises[n] : 0.0f);
+        float *tend = state ? state_tend(state) : nullptr;
+        if (tend) tend += index;
         step = march_ray<FAST>(m, oc, t, fars[index], n_step, xyzs + (size_t)n * n_step * 3, dirs + (size_t)n * n_step * 3,
-                               deltas + (size_t)n * n_step * 2);
+                               deltas + (size_t)n * n_step * 2, tend);
     } else {
         const uint32_t slot = n_alive * n_step + (n - n_alive);  // spare lanes of the last blocks clear the alignment tail
         if (slot < M_pad) {
@@ -858,9 +876,11 @@ __global__ void __launch_bounds__(kScanBlock) k_compact_scatter(const int32_t *_
 __global__ void __launch_bounds__(256) k_loop_init(uint32_t N, uint32_t max_steps, const float *__restrict__ nears, int32_t *__restrict__ alive_a,
                                                    float *__restrict__ rays_t, float *__restrict__ weights_sum, float *__restrict__ depth,
                                                    float *__restrict__ image, int32_t *__restrict__ state, int32_t *__restrict__ live_counts,
-                                                   uint32_t n_counters, unsigned long long mailbox, uint32_t frame_tag) {
+                                                   uint32_t n_counters, unsigned long long mailbox, uint32_t frame_tag,
+                                                   float *__restrict__ rays_tend) {
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
     if (n < N) {
+        if (rays_tend) rays_tend[n] = kTendUnset;
         alive_a[n] = (int32_t)n;
         rays_t[n] = nears[n];
         weights_sum[n] = 0; depth[n] = 0;
@@ -874,8 +894,12 @@ __global__ void __launch_bounds__(256) k_loop_init(uint32_t N, uint32_t max_step
         state[10] = (int32_t)(uint32_t)mailbox;      // [10],[11] host mailbox (device-visible pointer, 0 = none), [12] frame tag
         state[11] = (int32_t)(uint32_t)(mailbox >> 32);
         state[12] = (int32_t)frame_tag;
+        const unsigned long long tp = (unsigned long long)(uintptr_t)rays_tend;   // [13],[14] per-ray t_end cache (0 = none)
+        state[13] = (int32_t)(uint32_t)tp;
+        state[14] = (int32_t)(uint32_t)(tp >> 32);
     }
 }
+
 
 // Per-iteration snapshot {alive rays entering the next iteration, index of that iteration}: into the device ring `snap`
 // (4 deep, immutable once written: the host may copy it out while the next iteration runs) and, when the frame driver
@@ -1035,7 +1059,9 @@ __global__ void __launch_bounds__(256) k_composite_march(float T_thresh, int32_t
             } else if (march_next) {
                 MarcherT<FAST> m;
                 m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid);
-                emitted = march_ray<FAST>(m, oc, rays_t[index], fars[index], n_step, px, pd, pl);
+                float *tend = state_tend(state);
+                if (tend) tend += index;
+                emitted = march_ray<FAST>(m, oc, rays_t[index], fars[index], n_step, px, pd, pl, tend);
             }
         }
         live_append(emitted, n, n_step, live_idx, live_counts + it + 1);
@@ -1088,10 +1114,11 @@ __global__ void __launch_bounds__(256) k_loop_finish(uint32_t N, const float *__
 namespace sdn_int {
 
 int loop_begin(uint32_t N, uint32_t max_steps, const float *nears, int32_t *alive_a, float *rays_t, float *weights_sum, float *depth,
-               float *image, int32_t *state, int32_t *live_counts, uint32_t n_counters, void *mailbox, uint32_t frame_tag, hipStream_t st) {
+               float *image, int32_t *state, int32_t *live_counts, uint32_t n_counters, void *mailbox, uint32_t frame_tag, float *rays_tend,
+               hipStream_t st) {
     const uint32_t threads = N > n_counters ? N : n_counters;
     hipLaunchKernelGGL(k_loop_init, dim3(sdn_div_up(threads, 256u)), dim3(256), 0, st, N, max_steps, nears, alive_a, rays_t, weights_sum, depth,
-                       image, state, live_counts, n_counters, (unsigned long long)(uintptr_t)mailbox, frame_tag);
+                       image, state, live_counts, n_counters, (unsigned long long)(uintptr_t)mailbox, frame_tag, rays_tend);
     return sdn_launch_status();
 }
 

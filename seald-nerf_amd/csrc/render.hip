@@ -21,7 +21,7 @@ int render_begin(const SdnRenderCtx *c, void *mailbox, uint32_t frame_tag, hipSt
         if (rc0) return rc0;
     }
     int rc = loop_begin(c->N, c->max_steps, c->nears, c->alive_a, c->rays_t, c->weights_sum, c->depth, c->image, c->state, c->live_counts,
-                        c->n_counters, mailbox, frame_tag, st);
+                        c->n_counters, mailbox, frame_tag, c->rays_tend, st);
     if (rc) return rc;
     if (c->H == 128 && c->C == 1) rc = build_cull(c->bitfield, (uint32_t *)c->cull_bits, st);
     return rc;

@@ -425,7 +425,7 @@ class DeviceLoop:
                         xyzs=z(M, 3), dirs=z(M, 3), deltas=z(M, 2), sigmas=z(M), rgbs=z(M, 3), live_idx=z(M, dt=i32),
                         live_counts=torch.zeros(n_counters, dtype=i32, device=device), state=torch.zeros(16, dtype=i32, device=device),
                         trace=torch.zeros(2 * n_counters + 16, dtype=i32, device=device), n_out=torch.zeros(1, dtype=i32, device=device),
-                        block_totals=z((N + 255) // 256 + 1, dt=i32), nears=z(N), fars=z(N),
+                        block_totals=z((N + 255) // 256 + 1, dt=i32), nears=z(N), fars=z(N), rays_tend=z(N),
                         cull_bits=torch.empty(int(lib.sdn_cull_grid_bytes()), dtype=torch.uint8, device=device))
         self.image_out, self.depth_out = z(N, 3), z(N)
         self.snap = self.buf["trace"][2 * n_counters: 2 * n_counters + 8].view(4, 2)  # device ring written by the advance

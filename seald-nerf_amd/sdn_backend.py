@@ -60,7 +60,7 @@ class SdnRenderCtx(ctypes.Structure):
                 + [("grid_offsets", ctypes.c_int32 * 17), ("grid_S", _f32), ("grid_H", _u32)]
                 + [(n, _u32) for n in ("N", "M_cap", "n_counters", "max_steps", "C", "H")]
                 + [(n, _f32) for n in ("bound", "dt_gamma", "T_thresh", "density_scale")]
-                + [("zero_deform", ctypes.c_int32), ("aabb", _vp), ("min_near", _f32), ("reserved_", ctypes.c_int32)])
+                + [("zero_deform", ctypes.c_int32), ("aabb", _vp), ("min_near", _f32), ("reserved_", ctypes.c_int32), ("rays_tend", _vp)])
 
 
 PROTOTYPES_U32 = {
