@@ -57,10 +57,6 @@ constexpr int kBlkC2 = kBlkC1 + 8;        // 1 Mt x 4 ks
 constexpr int kBlkTotal = kBlkC2 + 4;     // 240
 static_assert(kBlkTotal - kBlkD7 == 32, "the tail stage must be exactly one 32 KiB buffer");
 
-#ifndef SDN_GRID_BATCH
-#define SDN_GRID_BATCH 8
-#endif
-constexpr int kGridBatch = SDN_GRID_BATCH;   // grid levels (per lane-half) whose gathers are in flight together
 constexpr int kStageBytes = 32768;
 constexpr int kWaves = 8;                 // waves per workgroup, 32 points each; two workgroups per CU = 4 waves per SIMD
 constexpr int kPointsPerWG = 32 * kWaves;
@@ -123,6 +119,30 @@ __device__ __forceinline__ void acc_to_frags(const f32x16 &acc, half8 &f0, half8
 
 __device__ __forceinline__ float round_h(float v) { return (float)(_Float16)v; }
 
+// fp32 multiply / add with one operand taken straight from the low / high half of a packed fp16 pair (v_fma_mix_f32):
+//   mix_mul_*(w, h2) = w * float(h2.half)        as fma(w, half, -0)  -- identical to the rounded product for every input
+//   mix_add_*(t, h2) = float(h2.half) + t        as fma(1, half, t)
+__device__ __forceinline__ float mix_mul_lo(float w, uint32_t h2) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(h2), "s"(-0.0f));
+    return r;
+}
+__device__ __forceinline__ float mix_mul_hi(float w, uint32_t h2) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(h2), "s"(-0.0f));
+    return r;
+}
+__device__ __forceinline__ float mix_add_lo(float t, uint32_t h2) {
+    float r;
+    asm("v_fma_mix_f32 %0, 1.0, %1, %2 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(h2), "v"(t));
+    return r;
+}
+__device__ __forceinline__ float mix_add_hi(float t, uint32_t h2) {
+    float r;
+    asm("v_fma_mix_f32 %0, 1.0, %1, %2 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(h2), "v"(t));
+    return r;
+}
+
 // sin(a) for |a| < ~1e4 to ~1e-7 absolute: 3-term Cody-Waite reduction by pi (explicit FMAs: this file is built with
 // -ffp-contract=off) + odd degree-9 minimax polynomial on [-pi/2, pi/2].  The standalone freq_encode kernel uses OCML
 // sinf (<= 1 ulp); the two agree to ~1e-7, far below the fp16 rounding the features get as MFMA operands.
@@ -162,11 +182,33 @@ __device__ __forceinline__ half8 lds_frag(const unsigned char *buf, int blk, uin
     return *reinterpret_cast<const half8 *>(buf + (size_t)blk * 1024 + lane * 16);
 }
 
-__global__ void __launch_bounds__(64 * kWaves, 4) k_field_f16(FieldArgs P, TiledLevels lv) {
+// OCC = waves per SIMD the kernel is compiled for, LA = LDS fragment reads kept in flight ahead of the MFMAs of a hidden layer.
+//   <4, 2>: the throughput variant (128 VGPRs, two workgroups per CU) for launches that fill the chip;
+//   <2, 8>: the latency variant for launches of at most one workgroup per CU (the tail iterations of a frame, every iteration
+//           of a ray-sharded frame): with two waves per SIMD nothing hides an LDS round trip per MFMA, so a whole k-step of
+//           fragments is read ahead (256-VGPR budget).
+template <int OCC, int LA>
+__global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, TiledLevels lv) {
+    constexpr int kGridBatch = OCC >= 4 ? 4 : 8;   // grid levels (per lane-half) whose gathers are in flight together (register budget)
     __shared__ __attribute__((aligned(16))) unsigned char s_w[2][kStageBytes];
+    __shared__ uint4 s_lv[16][2];   // per grid level: {offset, s1, s2, hsize}, {mask, scale, -, -}
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 16) {         // visible to everyone after the first stage barrier below
+        const uint32_t l = threadIdx.x;
+        s_lv[l][0] = make_uint4(lv.offset[l], lv.s1[l], lv.s2[l], lv.hsize[l]);
+        s_lv[l][1] = make_uint4(lv.mask[l], __float_as_uint(lv.scale[l]), 0u, 0u);
+    }
     const uint32_t count = P.state ? P.live_count[P.state[3]] : (P.live_idx ? *P.live_count : P.M);
     if (blockIdx.x * (uint32_t)kPointsPerWG >= count) return;  // workgroup-uniform: nothing to do, no barrier touched
+#if SDN_ABL == 9
+    unsigned long long ts[12];
+    int nts = 0;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+    #define SDN_TS() ts[nts++] = __builtin_readcyclecounter()
+#else
+    #define SDN_TS()
+#endif
+    SDN_TS();
     const uint32_t n = lane & 31u, h = lane >> 5;
     const uint32_t i = blockIdx.x * (uint32_t)kPointsPerWG + wave * 32u + n;
     const bool valid = i < count;
@@ -216,13 +258,22 @@ __global__ void __launch_bounds__(64 * kWaves, 4) k_field_f16(FieldArgs P, Tiled
         #pragma unroll
         for (int r = 0; r < 16; r++) acc[mt][r] = P.bias0[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h];
     }
+    SDN_TS();   // 1: features done
+    // Wave priority follows the phase.  All vector instructions of a SIMD share one issue port and the arbiter prefers the oldest
+    // wave, so a co-resident workgroup that is in its VALU-only grid phase starves a younger one's MFMAs completely (measured:
+    // the second workgroup of a CU made no progress until the first had retired -- two tiles took 28 + 23 us, not ~35).  An MFMA
+    // needs the port for 8 of its 32 cycles: with the matrix phases at higher priority the other workgroup's VALU work
+    // fills the remaining 24 and the two phases overlap.
+    __builtin_amdgcn_s_setprio(2);
     stage_wait_and_sync();  // D0 and D1 are resident
+    SDN_TS();   // 2: first stages landed
     #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
         #pragma unroll
         for (int mt = 0; mt < 4; mt++) acc[mt] = mfma(lds_frag(s_w[0], mt * 4 + ks, lane), bf[ks], acc[mt]);
     }
 
+    SDN_TS();   // 3: layer 0 issued
     // ---------------- deform layers 1..6 (128 -> 128, ReLU): stage l+1 uses buffer (l+1)&1 ----------------
 #if SDN_ABL == 4
     for (int l = 5; l < 6; l++) {
@@ -237,24 +288,37 @@ __global__ void __launch_bounds__(64 * kWaves, 4) k_field_f16(FieldArgs P, Tiled
         stage_load(P.weights + (size_t)(l < 5 ? kBlkD1 + (l + 1) * 32 : kBlkD7) * 1024, s_w[l & 1], kStageBytes, wave, lane);
         // (a software-pipelined variant -- fragments of k-step ks+1 read while the MFMAs of ks run -- needs 32 more VGPRs,
         // i.e. 3 waves per SIMD instead of 4, and measured 20 % slower: latency is hidden by occupancy here)
+        // look-ahead: the LDS reads of fragments i+1 .. i+LA are in flight while MFMA i issues
+        half8 ring[LA];
         #pragma unroll
-        for (int ks = 0; ks < 8; ks++) {
-            #pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
-                const half8 a = lds_frag(cur, mt * 8 + ks, lane);
-                if (ks == 0) {
-                    f32x16 z;
-                    #pragma unroll
-                    for (int r = 0; r < 16; r++) z[r] = 0.0f;
-                    acc[mt] = mfma(a, bf[0], z);
-                } else {
-                    acc[mt] = mfma(a, bf[ks], acc[mt]);
-                }
+        for (int j = 0; j < LA; j++) ring[j] = lds_frag(cur, (j & 3) * 8 + (j >> 2), lane);
+        #pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const int ks = i >> 2, mt = i & 3;
+            const half8 a = ring[i % LA];
+            if (i + LA < 32) ring[i % LA] = lds_frag(cur, ((i + LA) & 3) * 8 + ((i + LA) >> 2), lane);
+            if (ks == 0) {
+                f32x16 z;
+                #pragma unroll
+                for (int r = 0; r < 16; r++) z[r] = 0.0f;
+                acc[mt] = mfma(a, bf[0], z);
+            } else {
+                acc[mt] = mfma(a, bf[ks], acc[mt]);
             }
         }
+        // pin the interleaving the look-ahead needs (left alone, the scheduler sinks every read to just before its MFMA to save
+        // registers, and each MFMA then waits out a full LDS round trip): LA reads, then MFMA / read alternating
+        __builtin_amdgcn_sched_group_barrier(0x100, LA, 0);
+        #pragma unroll
+        for (int i = 0; i < 32 - LA; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, LA, 0);
     }
     #pragma unroll
     for (int t = 0; t < 4; t++) acc_to_frags<true>(acc[t], bf[2 * t], bf[2 * t + 1]);
+    SDN_TS();   // 4: hidden layers issued
     stage_wait_and_sync();  // tail stage (D7 | S0 | S1 | C0 | C1 | C2) resident in buffer 1
     const unsigned char *tail = s_w[1];
     constexpr int tD7 = 0, tS0 = kBlkS0 - kBlkD7, tS1 = kBlkS1 - kBlkD7, tC0 = kBlkC0 - kBlkD7, tC1 = kBlkC1 - kBlkD7, tC2 = kBlkC2 - kBlkD7;
@@ -279,8 +343,11 @@ __global__ void __launch_bounds__(64 * kWaves, 4) k_field_f16(FieldArgs P, Tiled
         }
     }
 
+    SDN_TS();   // 5: deform output
+    __builtin_amdgcn_s_setprio(0);
     // ---------------- grid encode: lane-half h evaluates levels 8h .. 8h+7 ----------------
     half8 gf[2];
+    uint32_t gfw[2][4];   // the same 2 x 8 halfs as packed pairs
 #if SDN_ABL == 3
     #pragma unroll
     for (int j = 0; j < 8; j++) { gf[0][j] = (_Float16)u[j % 3]; gf[1][j] = (_Float16)u[(j + 1) % 3]; }
@@ -295,65 +362,100 @@ __global__ void __launch_bounds__(64 * kWaves, 4) k_field_f16(FieldArgs P, Tiled
         for (int lb = 0; lb < 8 / kGridBatch; lb++) {
             uint2 pairs[kGridBatch][4];
             float pos[kGridBatch][3];
-            #pragma unroll
-            for (int lq = 0; lq < kGridBatch; lq++) {
+            const unsigned char *__restrict__ table_bytes = reinterpret_cast<const unsigned char *>(P.table);
+            uint32_t wrapbits = 0;   // bit 4 lq + c: that gather's x corner is the last row of a capped level (x+1 wraps to row 0)
+            // (tab, row0, mask) of corner pair c of level lq -- also recomputed by the rare wrap patch below instead of being kept
+            auto corner = [&](int lq, uint32_t c, uint32_t &tab, uint32_t &row0, uint32_t &mask, uint32_t &hsize, float (&ps)[3]) {
                 const int li = lb * kGridBatch + lq;
-                const uint32_t offset = h ? lv.offset[8 + li] : lv.offset[li];
-                const uint32_t s1 = h ? lv.s1[8 + li] : lv.s1[li];
-                const uint32_t s2 = h ? lv.s2[8 + li] : lv.s2[li];
-                const uint32_t hsize = h ? lv.hsize[8 + li] : lv.hsize[li];
-                const uint32_t mask = h ? lv.mask[8 + li] : lv.mask[li];
-                const float scale = h ? lv.scale[8 + li] : lv.scale[li];
-                const uint32_t *__restrict__ tab = reinterpret_cast<const uint32_t *>(P.table) + offset;   // one row = one half2
+                // the level's constants come from the LDS copy made at kernel start: two 16-byte reads per level instead of six
+                // per-lane selects between kernarg values (which the compiler turns into six per-lane global loads)
+                const uint4 k0 = s_lv[8 * h + li][0], k1 = s_lv[8 * h + li][1];
+                const uint32_t offset = k0.x, s1 = k0.y, s2 = k0.z;
+                hsize = k0.w;
+                mask = k1.x;
+                const float scale = __uint_as_float(k1.y);
+                tab = offset;   // first row of the level; one row = one half2, addressed as uniform base + 32-bit byte offset
                 uint32_t pg[3];
                 #pragma unroll
                 for (int d = 0; d < 3; d++) {
-                    pos[lq][d] = u[d] * scale + 0.5f;
-                    pg[d] = (uint32_t)floorf(pos[lq][d]);
-                    pos[lq][d] -= (float)pg[d];
+                    ps[d] = u[d] * scale + 0.5f;
+                    pg[d] = (uint32_t)floorf(ps[d]);
+                    ps[d] -= (float)pg[d];
                 }
                 const uint32_t base = oob ? 0u : pg[0] + pg[1] * s1 + pg[2] * s2;  // uint32 wrap-around as in get_grid_index
-                #pragma unroll
-                for (uint32_t c = 0; c < 4; c++) {
-                    // `index % hashmap_size` of get_grid_index without a division: capped levels have a power-of-two row count
-                    // (AND); dense levels hold every (res+1)^3 corner, so an in-range point never wraps and x+1 is the next row.
-                    // On a capped level the x corner may be the last row, the x+1 corner then row 0: rare, patched below.
-                    const uint32_t row0 = (base + ((c & 1u) ? s1 : 0u) + ((c & 2u) ? s2 : 0u)) & mask;
-                    const uint32_t rl = min(row0, hsize - 2u);          // the pair (rl, rl + 1) is always inside the level
-                    uint2 v;
-#if SDN_ABL == 2
-                    v = make_uint2(rl, rl + 1u);
-#else
-                    __builtin_memcpy(&v, tab + rl, 8);                  // 4-byte aligned 8-byte gather
-                    if (row0 > rl) {                                     // row0 == hsize - 1: x corner = second row of the pair, x+1 corner wraps
-                        v.x = v.y;
-                        v.y = tab[(row0 + 1u) & mask];
-                    }
-#endif
-                    pairs[lq][c] = v;
-                }
-            }
+                // `index % hashmap_size` of get_grid_index without a division: capped levels have a power-of-two row count
+                // (AND); dense levels hold every (res+1)^3 corner, so an in-range point never wraps and x+1 is the next row.
+                row0 = (base + ((c & 1u) ? s1 : 0u) + ((c & 2u) ? s2 : 0u)) & mask;
+            };
             #pragma unroll
             for (int lq = 0; lq < kGridBatch; lq++) {
-                float r0 = 0, r1 = 0;
                 #pragma unroll
-                for (uint32_t idx = 0; idx < 8; idx++) {  // kernel_grid: half += float * half, rounded to half each step
+                for (uint32_t c = 0; c < 4; c++) {
+                    uint32_t tab, row0, mask, hsize;
+                    corner(lq, c, tab, row0, mask, hsize, pos[lq]);
+                    const uint32_t rl = min(row0, hsize - 2u);          // the pair (rl, rl + 1) is always inside the level
+#if SDN_ABL == 2
+                    pairs[lq][c] = make_uint2(rl, rl + 1u);
+#else
+                    __builtin_memcpy(&pairs[lq][c], table_bytes + ((tab + rl) << 2), 8);   // 4-byte aligned 8-byte gather
+#endif
+                    if (row0 > rl) wrapbits |= 1u << (4 * lq + (int)c);
+                }
+            }
+#if SDN_ABL != 2
+            // On a capped level the x corner may be the LAST row: it is then the second row of the pair that was fetched and the
+            // x+1 corner is row 0.  Patched after every gather of the batch has been issued (a branch per gather would make each
+            // wait for its own data); practically never taken (1 row in 2^19).
+            if (__builtin_expect(wrapbits != 0u, 0)) {
+                #pragma unroll
+                for (int lq = 0; lq < kGridBatch; lq++) {
+                    #pragma unroll
+                    for (uint32_t c = 0; c < 4; c++) {
+                        if ((wrapbits >> (4 * lq + (int)c)) & 1u) {
+                            const int li = lb * kGridBatch + lq;   // wrapped: row0 == mask, so the x+1 corner is row 0 of the level
+                            const uint32_t offset = s_lv[8 * h + li][0].x;
+                            pairs[lq][c].x = pairs[lq][c].y;
+                            pairs[lq][c].y = *reinterpret_cast<const uint32_t *>(table_bytes + (offset << 2));
+                        }
+                    }
+                }
+            }
+#endif
+            #pragma unroll
+            for (int lq = 0; lq < kGridBatch; lq++) {
+                // kernel_grid: half += float * half, rounded to half after every corner.  The running pair (r0, r1) stays packed in fp16;
+                // v_fma_mix_f32 reads fp16 halves as fp32 operands, so  t = w * val  is fma(w, val, -0)  and  r + t  is fma(1, r, t):
+                // the same two individually rounded fp32 operations as before without the three conversions around them
+                // (5 instead of 9 VALU instructions per corner; the whole phase is VALU-issue bound).
+                uint32_t acc2 = 0u;
+                #pragma unroll
+                for (uint32_t idx = 0; idx < 8; idx++) {
                     float w = 1;
                     #pragma unroll
                     for (uint32_t d = 0; d < 3; d++) w *= (idx & (1u << d)) ? pos[lq][d] : 1 - pos[lq][d];
                     const uint32_t bits = (idx & 1u) ? pairs[lq][idx >> 1].y : pairs[lq][idx >> 1].x;
-                    const float2 val = __half22float2(__builtin_bit_cast(__half2, bits));
-                    r0 = round_h(r0 + w * val.x);
-                    r1 = round_h(r1 + w * val.y);
+                    const float s0 = mix_add_lo(mix_mul_lo(w, bits), acc2), s1 = mix_add_hi(mix_mul_hi(w, bits), acc2);
+                    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+                    acc2 = __builtin_bit_cast(uint32_t, (half2v){(_Float16)s0, (_Float16)s1});
                 }
-                if (oob) { r0 = 0; r1 = 0; }
+                if (oob) acc2 = 0u;
                 const int li = lb * kGridBatch + lq;
-                gf[li >> 2][2 * (li & 3)] = (_Float16)r0;
-                gf[li >> 2][2 * (li & 3) + 1] = (_Float16)r1;
+                gfw[li >> 2][li & 3] = acc2;
             }
+            // keep the batches apart: hoisting the next batch's index math and gathers above this batch's interpolation doubles the
+            // live registers (spills under the 128-VGPR cap of the throughput variant)
+            if (lb + 1 < 8 / kGridBatch) __builtin_amdgcn_sched_barrier(0);
         }
     }
 
+#if SDN_ABL != 3
+    #pragma unroll
+    for (int q = 0; q < 2; q++) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        gf[q] = __builtin_bit_cast(half8, (u32x4){gfw[q][0], gfw[q][1], gfw[q][2], gfw[q][3]});
+    }
+#endif
+    SDN_TS();   // 6: grid features
     // ---------------- sigma net: 32 -> 64 (ReLU) -> 16 ----------------
     f32x16 s0[2];
     #pragma unroll
@@ -374,6 +476,7 @@ __global__ void __launch_bounds__(64 * kWaves, 4) k_field_f16(FieldArgs P, Tiled
     // h[0] (lane-half 0, register 0) is the density logit; trunc_exp = exp in fp32 of the fp16 value
     const float sigma = P.density_scale * expf(round_h(hv[0]));
 
+    SDN_TS();   // 7: sigma
     // ---------------- colour net: [SH(16) ++ geo_feat(15)] -> 64 -> 64 -> 3 ----------------
     half8 cf[2], dummy;
     acc_to_frags<false>(hv, cf[0], dummy);  // registers 0..7 of every lane = h[0..15]; column of h[0] is zero in the packed weights
@@ -418,6 +521,18 @@ __global__ void __launch_bounds__(64 * kWaves, 4) k_field_f16(FieldArgs P, Tiled
     #pragma unroll
     for (int ks = 0; ks < 4; ks++) co = mfma(lds_frag(tail, tC2 + ks, lane), c2f[ks], co);
 
+    SDN_TS();   // 8: colour net issued
+#if SDN_ABL == 9
+    if (co[0] == 12345.678f) ts[0] = 0;   // keep the accumulator (and with it the MFMAs before the last stamp) alive
+    if (threadIdx.x == 0) {   // per workgroup: {start, end} in 10 ns ticks relative to a common origin, shader cycles; block 0 also its phase stamps
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+        float *o = P.rgbs + 64 + 4 * (size_t)blockIdx.x;
+        o[0] = (float)(long long)(rt0 & 0xFFFFFFull); o[1] = (float)(long long)(rt1 & 0xFFFFFFull); o[2] = (float)(long long)(ts[nts - 1] - ts[0]);
+        if (blockIdx.x == 0) for (int k = 0; k < nts; k++) P.rgbs[k] = (float)(long long)(ts[k] - ts[0]);
+        if (blockIdx.x == 300) for (int k = 0; k < nts; k++) P.rgbs[16 + k] = (float)(long long)(ts[k] - ts[0]);
+    }
+    return;
+#endif
     if (h == 0 && valid) {
         P.sigmas[p] = sigma;
         #pragma unroll
@@ -469,7 +584,17 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
     a.xyzs = xyzs; a.dirs = dirs; a.live_idx = live_idx; a.live_count = live_count; a.state = state; a.M = M;
     a.weights = (const unsigned char *)weights; a.bias0 = bias0; a.table = (const __half *)table;
     a.sigmas = sigmas; a.rgbs = rgbs; a.bound = bound; a.density_scale = density_scale; a.zero_deform = zero_deform;
-    hipLaunchKernelGGL(k_field_f16, dim3(sdn_div_up(M, (uint32_t)kPointsPerWG)), dim3(64 * kWaves), 0, st, a, lv);
+    const uint32_t wgs = sdn_div_up(M, (uint32_t)kPointsPerWG);
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    if (wgs <= (uint32_t)cus)
+        hipLaunchKernelGGL((k_field_f16<2, 8>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+    else
+        hipLaunchKernelGGL((k_field_f16<4, 2>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
     return sdn_launch_status();
 }
 
