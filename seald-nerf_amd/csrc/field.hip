@@ -576,7 +576,7 @@ namespace sdn_int {
 // launch used by both the C entry point and the device-driven render loop (render.hip)
 int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count, const int32_t *state,
                       uint32_t M, const void *weights, const float *bias0, const void *table, const int32_t *offsets_host, float S,
-                      uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, hipStream_t st) {
+                      uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, uint32_t expect_points, hipStream_t st) {
     TiledLevels lv;
     int rc = fill_tiled_levels(lv, offsets_host, S, H);
     if (rc) return rc;
@@ -591,7 +591,9 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
     }
-    if (wgs <= (uint32_t)cus)
+    // expect_points (0 = unknown): the caller's estimate of the live points when M is only a loose bound of them
+    const uint32_t busy = expect_points ? sdn_div_up(expect_points < M ? expect_points : M, (uint32_t)kPointsPerWG) : wgs;
+    if (busy <= (uint32_t)cus)
         hipLaunchKernelGGL((k_field_f16<2, 8>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
     else
         hipLaunchKernelGGL((k_field_f16<4, 2>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
@@ -614,7 +616,7 @@ int sdn_field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *
     if ((live_idx == nullptr) != (live_count == nullptr)) return SDN_E_BADARG;
     if (((uintptr_t)weights & 15u) != 0 || ((uintptr_t)table & 3u) != 0) return SDN_E_BADARG;
     return sdn_int::field_forward_f16(xyzs, dirs, live_idx, live_count, nullptr, M, weights, bias0, table, offsets_host, S, H, bound,
-                                      density_scale, zero_deform, sigmas, rgbs, (hipStream_t)stream);
+                                      density_scale, zero_deform, sigmas, rgbs, 0u, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -62,7 +62,7 @@ int sdn_render_step_f16_ev(const SdnRenderCtx *c, uint32_t bound_alive, void *ev
     if (ev_field_begin) (void)hipEventRecord((hipEvent_t)ev_field_begin, st);
     rc = sdn_int::field_forward_f16(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, (uint32_t)m_bound,
                                     c->field_weights, c->field_bias0, c->grid_table, c->grid_offsets, c->grid_S, c->grid_H, c->bound,
-                                    c->density_scale, c->zero_deform, c->sigmas, c->rgbs, st);
+                                    c->density_scale, c->zero_deform, c->sigmas, c->rgbs, 0u, st);
     if (ev_field_end) (void)hipEventRecord((hipEvent_t)ev_field_end, st);
     if (rc) return rc;
     return sdn_int::loop_composite_compact(bound_alive, c->T_thresh, c->alive_a, c->alive_b, c->rays_t, c->sigmas, c->rgbs, c->deltas,
@@ -96,10 +96,11 @@ struct FrameRun {
     // nothing but kernels (no event record / stream wait / copy / event wait per iteration).
     void *mail_dev = nullptr;
     uint32_t tag = 0;
+    uint32_t last_alive = 0;   // alive rays entering the newest iteration whose count has been read back (a bound for later ones)
 
     int begin() {
         if (!ctx_ok(c)) return SDN_E_BADARG;
-        bound = c->N; it = 0; steady = false; done = false;
+        bound = c->N; it = 0; steady = false; done = false; last_alive = c->N;
         mail_dev = nullptr;
         unsigned int flags = 0;
         void *dptr = nullptr;
@@ -129,7 +130,7 @@ struct FrameRun {
             if (e0) (void)hipEventRecord((hipEvent_t)e0, st);
             rc = sdn_int::field_forward_f16(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, (uint32_t)m_bound,
                                             c->field_weights, c->field_bias0, c->grid_table, c->grid_offsets, c->grid_S, c->grid_H, c->bound,
-                                            c->density_scale, c->zero_deform, c->sigmas, c->rgbs, st);
+                                            c->density_scale, c->zero_deform, c->sigmas, c->rgbs, last_alive * 8u, st);
             if (e1) (void)hipEventRecord((hipEvent_t)e1, st);
             if (!rc)
                 rc = sdn_int::loop_composite_march(bound, c->T_thresh, c->alive_a, c->alive_b, c->rays_t, c->rays_o, c->rays_d, c->bound,
@@ -173,6 +174,7 @@ struct FrameRun {
             }
             // n_prev: alive rays entering iteration `it`
             if (n_prev <= 0) { done = true; return 0; }
+            last_alive = (uint32_t)n_prev;
             if (!steady) {
                 bound = (uint32_t)n_prev;
                 if ((uint64_t)n_prev * 8u <= c->N) {

@@ -29,6 +29,6 @@ int render_begin(const SdnRenderCtx *c, void *mailbox, uint32_t frame_tag, hipSt
 int build_cull(const uint8_t *bitfield, uint32_t *cull_bits, hipStream_t st);
 int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count, const int32_t *state,
                       uint32_t M, const void *weights, const float *bias0, const void *table, const int32_t *offsets_host, float S,
-                      uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, hipStream_t st);
+                      uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, uint32_t expect_points, hipStream_t st);
 
 }  // namespace sdn_int
