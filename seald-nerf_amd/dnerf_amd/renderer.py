@@ -413,7 +413,7 @@ class DeviceLoop:
     RING = 4
     MAX_TIMED = 24  # iterations whose fused-field launch can be timed in place (the headline frame has 11 + 1)
 
-    def __init__(self, model, field, N, device, max_steps=1024, T_thresh=1e-2, dt_gamma=0.0):
+    def __init__(self, model, field, N, device, max_steps=1024, T_thresh=1e-2, dt_gamma=0.0, mailbox=True):
         import ctypes
         from sdn_backend import lib, SdnRenderCtx
         f32, i32 = torch.float32, torch.int32
@@ -430,7 +430,9 @@ class DeviceLoop:
         self.image_out, self.depth_out = z(N, 3), z(N)
         self.snap = self.buf["trace"][2 * n_counters: 2 * n_counters + 8].view(4, 2)  # device ring written by the advance
         from sdn_backend import HostMailbox
-        self.host_state = HostMailbox(1)   # the loop kernels publish each iteration's survivor count here; the driver polls it
+        # mailbox=True: coherent mapped host memory the loop kernels publish each iteration's survivor count into (the driver polls
+        # it); False: ordinary pinned memory, which selects the driver's event + side-stream copy read-back
+        self.host_state = HostMailbox(1) if mailbox else torch.zeros(self.RING, 2, dtype=i32).pin_memory()
         self.events = [torch.cuda.Event() for _ in range(self.RING)]
         self.copy_events = [torch.cuda.Event() for _ in range(self.RING)]
         self.side = torch.cuda.Stream(device=device)

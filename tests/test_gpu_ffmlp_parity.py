@@ -142,3 +142,27 @@ def test_ffmlp_rejects_what_the_reference_rejects():
     y = ffmlp.ffmlp_forward(x, wd, 16, 16, 64, 2, 2, 6, False, False)       # sine forward is fine ...
     with pytest.raises(NotImplementedError):
         y.sum().backward()                                                   # ... its backward is not (utils.h:552-556)
+
+
+@pytest.mark.parametrize("B", [1, 31, 33, 255, 257])
+def test_ffmlp_ragged_batches_match_the_padded_result(B):
+    """Any batch size works (the reference pads to 128, ffmlp.py:154-157): rows beyond B are neither read nor written."""
+    import ffmlp
+    in_dim, hidden, L = 32, 64, 3
+    w, x, g = _case(in_dim, hidden, L, 512, seed=11)
+    wd = torch.from_numpy(w).cuda()
+    full = ffmlp.ffmlp_forward(torch.from_numpy(x).cuda(), wd, in_dim, 16, hidden, L, 0, 6, True, False)
+    guard = torch.full((B + 64, 16), -7.0, dtype=torch.float16, device="cuda")
+    xs = torch.from_numpy(x[:B]).cuda().contiguous()
+    out = ffmlp.ffmlp_forward(xs, wd, in_dim, 16, hidden, L, 0, 6, True, False)
+    assert out.shape == (B, 16) and torch.equal(out, full[:B])
+    # training forward + backward on the ragged batch, weights only (calc_grad_inputs False)
+    wg = wd.clone().requires_grad_(True)
+    y = ffmlp.ffmlp_forward(xs, wg, in_dim, 16, hidden, L, 0, 6, False, False)
+    assert torch.equal(y, full[:B])
+    fwd = y.grad_fn.saved_tensors[3].cpu().numpy()
+    y.backward(torch.from_numpy(g[:B]).cuda())
+    _, gw_ref, _ = F.ffmlp_backward(g[:B], x[:B], w, fwd, in_dim, hidden, L, 0, calc_grad_inputs=False)
+    gw, gw_ref = wg.grad.cpu().numpy().astype(np.float32), gw_ref.astype(np.float32)
+    assert np.linalg.norm(gw - gw_ref) <= 1e-2 * np.linalg.norm(gw_ref) + 1e-6
+    del guard
