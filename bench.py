@@ -41,6 +41,11 @@ def parse():
     ap.add_argument("--loop", default="auto", choices=["auto", "host", "device"], help="loop driver: per-iteration host sync, or device-driven")
     ap.add_argument("--time-every", type=int, default=4, help="record the per-launch HIP events of the tracked kernels on every K-th timed step "
                     "(each event record costs ~5 us of queue time between two dependent launches; K = 1 instruments every step)")
+    ap.add_argument("--pipeline", type=int, default=1, metavar="DIV",
+                    help="device loop: render the timed steps as a stream of frames through --contexts loop contexts; the next frame "
+                         "starts when a context is free and the newest frame in flight is down to rays / DIV alive (1 = at once; "
+                         "0 = strictly one frame at a time)")
+    ap.add_argument("--contexts", type=int, default=3, help="--pipeline: loop contexts (frames in flight)")
     ap.add_argument("--groups", type=int, default=1, help="device loop only: render the frame as G interleaved ray groups on G streams")
     ap.add_argument("--mode", default="render", choices=["render", "train"],
                     help="render: the headline 800x800 inference frame; train: one dnerf training step on 4096 rays (BASELINE config 3)")
@@ -85,6 +90,9 @@ def train_mode(args):
         step()
     n_points = int(model.step_counter[(model.local_step - 1) % 16, 0].item())
     timers = sdn_backend.KernelTimers()
+    import gc
+    gc.collect()
+    gc.disable()   # no cyclic-collector pass inside the timed region (see main())
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -93,6 +101,7 @@ def train_mode(args):
     sdn_backend.timers = None
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
     summ = timers.summary()
     print(json.dumps({"metric": "dnerf training step, 4096 rays (march_rays_train + field + composite_rays_train fwd/bwd + grid backward + Adam)",
                       "value": args.steps / dt, "unit": "steps/s", "points_per_s": n_points * args.steps / dt, "rays_per_s": n_rays * args.steps / dt,
@@ -162,6 +171,62 @@ def main():
         else:
             dloop = DeviceLoop(sc.model, field, n_local, dev)
 
+    ploop = None
+    if args.pipeline > 0 and dloop is not None and args.groups == 1:
+        from dnerf_amd.renderer import PipelinedDeviceLoop
+        ploop = PipelinedDeviceLoop(sc.model, field, n_local, dev, overlap_div=args.pipeline, contexts=args.contexts)
+
+    def make_timing(frames):
+        """Event pairs (created outside the timed region) for the field launches of `frames` instrumented frames."""
+        import ctypes
+        cur = torch.cuda.current_stream()
+        out = []
+        for _ in range(frames):
+            recs = []
+            for _ in range(DeviceLoop.MAX_TIMED):
+                s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_.record(cur); e_.record(cur)
+                recs.append((s_, e_, 0))
+            arr = (ctypes.c_void_p * (2 * DeviceLoop.MAX_TIMED))(*[h for r in recs for h in (r[0].cuda_event, r[1].cuda_event)])
+            out.append((arr, recs))
+        torch.cuda.synchronize()
+        return out
+
+    def stream_of_frames(k, every=0):
+        """k frames through the pipelined driver; every > 0: the field launches of every `every`-th frame are timed in place."""
+        # instrumented frames: the first and the last of the stream are rendered with nothing else in flight -- the pipeline is
+        # empty / draining there anyway -- and their launch durations are the kernel's own (the roofline figure); every `every`-th
+        # frame in between is instrumented while it overlaps like all the others (what a launch takes while it shares the device)
+        marked = sorted(set(range(0, k, every)) | {k - 1}) if every else []
+        timing = make_timing(len(marked))
+        per_frame, it = [None] * k, iter(timing)
+        exclusive = [False] * k
+        for f in marked:
+            per_frame[f] = next(it)
+            exclusive[f] = f in (0, k - 1)
+        outputs = None
+        if world > 1:  # every frame keeps its own shard output until it has been gathered
+            outputs = [(torch.empty(n_local, 3, dtype=torch.float32, device=dev), torch.empty(n_local, dtype=torch.float32, device=dev))
+                       for _ in range(k)]
+        barrier()
+        t0 = time.perf_counter()
+        outs, iters = ploop.render_frames([rays_o] * k, [rays_d] * k, sc.time, outputs=outputs,
+                                          timing=[p[0] if p else None for p in per_frame] if every else None,
+                                          exclusive=exclusive if every else None)
+        if world > 1:
+            for img, dep in outs:
+                gather(img, dep)  # one RCCL all-gather per frame + local un-permute, issued behind the renders
+        t1 = time.perf_counter()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if os.environ.get("SDN_DRIVER_STATS"):
+            print(f"[bench] render_frames {1e3 * (t1 - t0):.2f} ms, final sync {1e3 * (time.perf_counter() - t1):.2f} ms", file=sys.stderr)
+        for f, p in enumerate(per_frame):
+            if p:
+                key = "field_forward_f16" if exclusive[f] else "field_forward_f16_overlapped"
+                timers.records.setdefault(key, []).extend(p[1][: min(DeviceLoop.MAX_TIMED, iters[f])])
+        return elapsed, outs
+
     def step(count=False, timed=False):
         sdn_backend.timers = timers if timed else None  # HIP events around the tracked launches, timed steps only
         if dloop is not None and args.groups > 1:
@@ -188,14 +253,25 @@ def main():
 
     every = max(1, args.time_every)
     n_instrumented = len(range(0, args.steps, every))
-    if dloop is not None:
-        dloop.prepare_timing(n_instrumented)  # event pairs for the in-place timing of the fused-field launches, created up front
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(timed=(i % every == 0))
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # A generation-2 pass of CPython's cyclic collector costs tens of milliseconds with torch + numpy loaded and fires on allocation
+    # counts, i.e. inside the timed region for some argument combinations and not for others (seen: 20 frames in 14 ms of driver
+    # time reported as 50-78 ms).  Collect now and keep the collector off while the clock runs, as `timeit` does.
+    import gc
+    gc.collect()
+    gc.disable()
+    if ploop is not None:
+        stream_of_frames(max(args.contexts, args.warmup))           # warm every context
+        elapsed, _ = stream_of_frames(args.steps, every)
+    else:
+        if dloop is not None:
+            dloop.prepare_timing(n_instrumented)  # event pairs for the in-place timing of the fused-field launches, created up front
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(timed=(i % every == 0))
+        barrier()
+        elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         cdev = "cpu" if rehearse else dev
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -219,12 +295,23 @@ def main():
                                f"{'-O (fp16 field network, fp16 grid table)' if fp16 else 'fp32'}, 1 timestep (t=0.5), "
                                f"T_thresh 1e-2, max_steps 1024, dt_gamma 0",
                    "rays": n_total, "sampled_points_per_frame": n_samples, "loop_iterations": n_iters,
-                   "field": field_kind, "loop": loop_kind, "ray_groups": args.groups, "parallelism": (f"ray-tiles x{world}" + (" (ONE-GPU REHEARSAL, numbers invalid)" if rehearse else "")) if world > 1 else "single GPU"},
+                   "field": field_kind, "loop": loop_kind, "ray_groups": args.groups,
+                   "frames_in_flight": ("%d (the next frame starts when the newest one is down to rays/%d alive)" % (args.contexts, args.pipeline)) if ploop is not None else 1, "parallelism": (f"ray-tiles x{world}" + (" (ONE-GPU REHEARSAL, numbers invalid)" if rehearse else "")) if world > 1 else "single GPU"},
     }
     if rank == 0:
-        result["roofline"], result["kernel_times"] = roofline(timers, fp16, n_samples_local, n_iters, n_instrumented)
+        if ploop is not None:
+            marked = sorted(set(range(0, args.steps, every)) | {args.steps - 1})
+            n_instrumented, n_excl = len(marked), len({0, args.steps - 1})
+        else:
+            n_excl = n_instrumented
+        result["roofline"], result["kernel_times"] = roofline(timers, fp16, n_samples_local, n_iters, n_excl, n_instrumented - n_excl)
         if result["roofline"]:
-            result["roofline"]["instrumented_steps"] = f"{n_instrumented} of {args.steps} timed steps (every {every}th)"
+            result["roofline"]["instrumented_steps"] = (
+                f"{n_instrumented} of {args.steps} timed steps (every {every}th" + (", plus the last" if ploop is not None else "") + ")"
+                + (f"; {n_excl} of them (the first and the last) rendered with nothing else in flight -- their launches give achieved / frac -- and "
+                   f"{n_instrumented - n_excl} overlapped like the uninstrumented steps (the `overlapped` entry)" if ploop is not None else ""))
+            # field FLOPs of the whole timed region over its wall time: a lower bound of the kernel's rate that no overlap can inflate
+            result["roofline"]["whole_job_mfma_frac"] = FIELD_FLOP_PER_POINT * n_samples * args.steps / elapsed / 1e12 / MFMA_F16_PEAK_TFLOPS
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sc, args.cpu_baseline_side)
         print(json.dumps(result))
@@ -232,7 +319,7 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline(timers, fp16, n_samples, n_iters, steps):
+def roofline(timers, fp16, n_samples, n_iters, steps, steps_overlapped=0):
     """Roofline entry of the dominant TRACKED kernel: achieved = algorithmic bytes (or flops) per launch / average launch
     duration, both from the HIP events recorded around the launches inside the timed region.  The fused field kernel
     evaluates only the live samples of each iteration (device-side list), so its units per launch are the frame's sampled
@@ -246,6 +333,7 @@ def roofline(timers, fp16, n_samples, n_iters, steps):
         f = summ["field_forward_f16"]
         f["units"] = int(n_samples * steps)
         f["avg_units"] = f["units"] / f["launches"]
+    over = summ.pop("field_forward_f16_overlapped", None)
     name = max(summ, key=lambda k: summ[k]["total_ms"])
     s = summ[name]
     if name.startswith("grid_encode_fwd"):
@@ -264,6 +352,13 @@ def roofline(timers, fp16, n_samples, n_iters, steps):
             f = json.load(open(pmc))["field_forward_f16"]
             roof["traffic"] = (f["fetch_bytes_per_frame_raw"] + f["write_bytes_per_frame"]) * steps / s["launches"]
             roof["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/r01_field_pmc_summary.json)"
+        if over and steps_overlapped:  # the same launches while other frames' kernels share the device: durations are not the kernel's own
+            units = n_samples * steps_overlapped / over["launches"]
+            ach = FIELD_FLOP_PER_POINT * units / (over["avg_ms"] * 1e-3) / 1e12
+            roof["overlapped"] = {"avg_launch_ms": over["avg_ms"], "launches": over["launches"], "achieved": ach,
+                                  "frac": ach / MFMA_F16_PEAK_TFLOPS,
+                                  "note": "frames in flight share the CUs: this is the figure rocprofv3 --stats of the default command averages towards"}
+            summ["field_forward_f16_overlapped"] = over
     return roof, summ
 
 

@@ -285,6 +285,19 @@ int sdn_render_step_f16_ev(const SdnRenderCtx *ctx, uint32_t bound_alive, void *
 int sdn_render_frame_f16(const SdnRenderCtx *ctx, float bg_color, float *image_out, float *depth_out, void *stream,
                          void *side_stream, void **ev_main, void **ev_copy, int32_t *host_snap, void **ev_field,
                          uint32_t max_field_events, uint32_t *iterations_out);
+/* A stream of n_frames frames through n_ctx (<= 8) contexts used in turn (ctxs, streams, side_streams [n_ctx]; host_snap 8 ints
+ * and ev_main / ev_copy 4 events per context): the next frame starts as soon as a context is free and the alive rays of the
+ * newest frame in flight are <= N / overlap_div (1 = at once), so the latency-bound parts of one frame run under the
+ * throughput-bound kernels of another.  Per-frame pointers come from rays_o / rays_d / image_outs / depth_outs [n_frames]; the
+ * contexts supply everything else (aabb must be set: the driver computes nears / fars per frame).  ev_field_frames: NULL, or per
+ * frame a pointer (may be NULL) to 2 * max_field_events timing events for that frame's field launches.  exclusive_frames: NULL or
+ * [n_frames] flags; a flagged frame runs with nothing else in flight (to time its kernels undisturbed).  Every frame is
+ * bit-identical to sdn_render_frame_f16's; iterations_out [n_frames] or NULL. */
+int sdn_render_frames_pipelined_f16(const SdnRenderCtx *const *ctxs, uint32_t n_ctx, uint32_t n_frames, const float *const *rays_o,
+                                    const float *const *rays_d, float *const *image_outs, float *const *depth_outs, float bg_color,
+                                    uint32_t overlap_div, void *const *streams, void *const *side_streams, void **ev_main,
+                                    void **ev_copy, int32_t *host_snap, void *const *ev_field_frames, uint32_t max_field_events,
+                                    const uint8_t *exclusive_frames, uint32_t *iterations_out);
 /* Read-back memory for the frame drivers: 32 bytes per ray group of coherent, device-mapped host memory.  When `host_snap`
  * comes from here the loop kernels publish every iteration's survivor count into it with one 64-bit system-scope store and
  * the driver polls it (no event record / stream wait / copy per iteration); any other pinned memory selects the event +

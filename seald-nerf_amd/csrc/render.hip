@@ -9,6 +9,8 @@
 // The schedule -- n_step = clamp(N // n_alive, 1, 8), stop at max_steps -- and every sample are the reference's.
 #include <atomic>
 #include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "sdn_common.h"
@@ -248,6 +250,104 @@ int sdn_render_frame_groups_f16(const SdnRenderCtx *const *ctxs, uint32_t groups
             }
         }
     }
+    return 0;
+}
+
+// A stream of frames (camera path / time steps) through n_ctx loop contexts used in turn, each on its own stream: the next frame
+// begins as soon as a context is free and the alive rays of the newest frame in flight have dropped to N / overlap_div
+// (1 = at once), so that the latency-bound parts of one frame -- marching chains, the tail iterations with a few thousand
+// rays, launch gaps -- run under the throughput-bound field kernels of another.  Frames are independent (separate state, samples and outputs per context): every
+// frame is bit-identical to the one `sdn_render_frame_f16` renders; only throughput changes.  ctxs[n_ctx] carry everything but the
+// per-frame pointers, which come from rays_o / rays_d / image_outs / depth_outs [n_frames] (entries may repeat); host_snap: 8 ints
+// per context; ev_main / ev_copy: 4 events per context (event + copy read-back only); ev_field_frames: NULL or [n_frames] pointers
+// (NULL entries allowed) to 2 * max_field_events timing events recorded around that frame's field launches; exclusive_frames: NULL or
+// [n_frames] flags -- a flagged frame starts only when no other frame is in flight and nothing starts until it is done.
+int sdn_render_frames_pipelined_f16(const SdnRenderCtx *const *ctxs, uint32_t n_ctx, uint32_t n_frames, const float *const *rays_o,
+                                    const float *const *rays_d, float *const *image_outs, float *const *depth_outs, float bg_color,
+                                    uint32_t overlap_div, void *const *streams, void *const *side_streams, void **ev_main, void **ev_copy,
+                                    int32_t *host_snap, void *const *ev_field_frames, uint32_t max_field_events, const uint8_t *exclusive_frames,
+                                    uint32_t *iterations_out) {
+    constexpr uint32_t kMaxCtx = 8;
+    if (!ctxs || n_ctx == 0 || n_ctx > kMaxCtx || !rays_o || !rays_d || !image_outs || !depth_outs || !streams || !side_streams ||
+        !ev_main || !ev_copy || !host_snap)
+        return SDN_E_BADARG;
+    for (uint32_t s = 0; s < n_ctx; s++)
+        if (!ctxs[s] || !ctxs[s]->aabb || !side_streams[s]) return SDN_E_BADARG;
+    if (n_frames == 0) return 0;
+    if (overlap_div == 0) overlap_div = 1;
+    SdnRenderCtx local[kMaxCtx];
+    FrameRun runs[kMaxCtx];
+    int frame_of[kMaxCtx];             // frame a context is rendering, -1 = free
+    for (uint32_t s = 0; s < n_ctx; s++) { local[s] = *ctxs[s]; frame_of[s] = -1; }
+    uint32_t next = 0, finished = 0;
+    auto start = [&](uint32_t slot) -> int {
+        if (!rays_o[next] || !rays_d[next] || !image_outs[next] || !depth_outs[next]) return SDN_E_BADARG;
+        local[slot].rays_o = rays_o[next];
+        local[slot].rays_d = rays_d[next];
+        void **evf = ev_field_frames ? (void **)ev_field_frames[next] : nullptr;   // timing events of this frame's field launches, or none
+        runs[slot] = FrameRun{&local[slot], (hipStream_t)streams[slot], (hipStream_t)side_streams[slot], ev_main + 4 * slot, ev_copy + 4 * slot,
+                              evf, host_snap + 8 * slot, evf ? max_field_events : 0u, 0, 0, false, false};
+        frame_of[slot] = (int)next++;
+        return runs[slot].begin();
+    };
+    int rc = start(0);
+    if (rc) return rc;
+    const bool stats = getenv("SDN_DRIVER_STATS") != nullptr;   // host-side time split of the driver loop, to stderr
+    double t_enq = 0, t_set = 0, t_max_enq = 0, t_max_set = 0;
+    uint32_t n_loops = 0;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    while (finished < n_frames) {
+        n_loops++;
+        // contexts in frame order, oldest first: its kernels are the ones the stream of frames is waiting for
+        uint32_t order[kMaxCtx], n_act = 0;
+        for (uint32_t s = 0; s < n_ctx; s++)
+            if (frame_of[s] >= 0) order[n_act++] = s;
+        for (uint32_t a = 1; a < n_act; a++)
+            for (uint32_t b = a; b > 0 && frame_of[order[b]] < frame_of[order[b - 1]]; b--) { const uint32_t t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+        const double t0 = stats ? now() : 0;
+        for (uint32_t a = 0; a < n_act; a++) { rc = runs[order[a]].enqueue(); if (rc) return rc; }
+        const double t1 = stats ? now() : 0;
+        uint32_t newest_alive = 0;
+        bool any_active = false;
+        for (uint32_t a = 0; a < n_act; a++) {
+            const uint32_t s = order[a];
+            rc = runs[s].settle();
+            if (rc) return rc;
+            if (runs[s].done) {
+                const int f = frame_of[s];
+                rc = sdn_render_finish(&local[s], bg_color, image_outs[f], depth_outs[f], streams[s]);
+                if (rc) return rc;
+                if (iterations_out) iterations_out[f] = runs[s].it + 1;
+                frame_of[s] = -1;
+                finished++;
+            } else {
+                any_active = true;
+                newest_alive = runs[s].last_alive;     // order is oldest first: the last one kept is the newest frame's
+            }
+        }
+        if (stats) {
+            const double t2 = now();
+            t_enq += t1 - t0; t_set += t2 - t1;
+            if (t1 - t0 > t_max_enq) t_max_enq = t1 - t0;
+            if (t2 - t1 > t_max_set) t_max_set = t2 - t1;
+        }
+        if (next < n_frames) {
+            const uint32_t slot = next % n_ctx;
+            bool ok = !any_active || (uint64_t)newest_alive * overlap_div <= local[slot].N;
+            if (exclusive_frames && any_active) {
+                // an exclusive frame has the device to itself (used to time its kernels undisturbed): it starts only when nothing
+                // else is in flight, and nothing starts while it is
+                bool excl_in_flight = false;
+                for (uint32_t c = 0; c < n_ctx; c++)
+                    if (frame_of[c] >= 0 && exclusive_frames[frame_of[c]]) excl_in_flight = true;
+                if (exclusive_frames[next] || excl_in_flight) ok = false;
+            }
+            if (frame_of[slot] < 0 && ok) { rc = start(slot); if (rc) return rc; }
+        }
+    }
+    if (stats)
+        fprintf(stderr, "[sdn driver] frames %u contexts %u loops %u  enqueue %.0f us (max %.0f)  settle/wait %.0f us (max %.0f)  mailbox %d\n", n_frames,
+                n_ctx, n_loops, t_enq, t_max_enq, t_set, t_max_set, runs[0].mail_dev != nullptr);
     return 0;
 }
 

@@ -594,3 +594,78 @@ class GroupedDeviceLoop:
             res["trace"] = max((o["trace"] for o in outs), key=len)
             res["group_traces"] = [o["trace"] for o in outs]
         return res
+
+
+class PipelinedDeviceLoop:
+    """A stream of frames (camera path / time steps of one model) through `contexts` `DeviceLoop` contexts used in turn, each on its
+    own HIP stream, all driven by one host thread in `sdn_render_frames_pipelined_f16`: the next frame starts as soon as a
+    context is free and the newest frame in flight is down to N / overlap_div alive rays (1 = at once), so the latency-bound
+    parts of one frame (marching chains, tail iterations, launch gaps) run under the throughput-bound field kernels of another.
+    Every frame is the one `DeviceLoop.render` produces, bit for bit; what changes is frames per second."""
+
+    def __init__(self, model, field, N, device, overlap_div=1, contexts=2, **kw):
+        import ctypes
+        from sdn_backend import SdnRenderCtx, HostMailbox
+        self.N, self.device, self.overlap_div, self.K = N, device, int(overlap_div), int(contexts)
+        self.loops = [DeviceLoop(model, field, N, device, **kw) for _ in range(self.K)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(self.K)]
+        self.host_state = HostMailbox(self.K)
+        self._ctxs = (ctypes.POINTER(SdnRenderCtx) * self.K)(*[ctypes.pointer(lp.ctx) for lp in self.loops])
+        self._fixed = None
+
+    @torch.no_grad()
+    def render_frames(self, rays_o, rays_d, time, bg_color=1.0, outputs=None, timing=None, exclusive=None):
+        """rays_o / rays_d: lists of [N,3] tensors, one per frame (entries may repeat).  outputs: optional list of (image [N,3],
+        depth [N]) tensors per frame; by default frame f lands in the output buffers of context f % contexts.  timing: optional list
+        (per frame, None allowed) of ctypes arrays of 2 * DeviceLoop.MAX_TIMED hipEvent_t for that frame's field launches.
+        exclusive: optional list of bools per frame; a flagged frame is rendered with nothing else in flight.
+        Returns the list of (image, depth) per frame and the per-frame iteration counts."""
+        import ctypes
+        import time as _t
+        _tin = _t.perf_counter()
+        from sdn_backend import lib, check, ptr
+        n = len(rays_o)
+        assert n == len(rays_d) and n >= 1
+        cur = torch.cuda.current_stream()
+        ro = [r.contiguous().view(-1, 3) for r in rays_o]
+        rd = [r.contiguous().view(-1, 3) for r in rays_d]
+        for s, lp in enumerate(self.loops):
+            self.streams[s].wait_stream(cur)
+            with torch.cuda.stream(self.streams[s]):
+                lp.bind(ro[min(s, n - 1)], rd[min(s, n - 1)], time)     # time slice, aabb, field constants; rays are set per frame
+                lp.side.wait_stream(self.streams[s])
+        if outputs is None:
+            outputs = [(self.loops[f % self.K].image_out, self.loops[f % self.K].depth_out) for f in range(n)]
+        vp = ctypes.c_void_p
+        if self._fixed is None:
+            K = self.K
+            self._fixed = dict(streams=(vp * K)(*[s.cuda_stream for s in self.streams]),
+                               sides=(vp * K)(*[lp.side.cuda_stream for lp in self.loops]),
+                               ev_main=(vp * (4 * K))(*[e.cuda_event for lp in self.loops for e in lp.events]),
+                               ev_copy=(vp * (4 * K))(*[e.cuda_event for lp in self.loops for e in lp.copy_events]))
+        fx = self._fixed
+        a_ro = (vp * n)(*[ptr(t, torch.float32, "rays_o") for t in ro])
+        a_rd = (vp * n)(*[ptr(t, torch.float32, "rays_d") for t in rd])
+        a_img = (vp * n)(*[ptr(o[0], torch.float32, "image_out") for o in outputs])
+        a_dep = (vp * n)(*[ptr(o[1], torch.float32, "depth_out") for o in outputs])
+        iters = (ctypes.c_uint32 * n)()
+        a_ev, n_ev = None, 0
+        if timing is not None:
+            a_ev = (vp * n)(*[ctypes.cast(t, vp).value if t is not None else None for t in timing])
+            n_ev = DeviceLoop.MAX_TIMED
+        import os, time as _t
+        _dbg = os.environ.get("SDN_DRIVER_STATS")
+        _t0 = _t.perf_counter()
+        check(lib.sdn_render_frames_pipelined_f16(self._ctxs, self.K, n, a_ro, a_rd, a_img, a_dep, float(bg_color), self.overlap_div, fx["streams"],
+                                                  fx["sides"], fx["ev_main"], fx["ev_copy"], self.host_state.data_ptr(), a_ev, n_ev,
+                                                  (ctypes.c_uint8 * n)(*[1 if e else 0 for e in exclusive]) if exclusive is not None else None, iters),
+              "render_frames_pipelined_f16")
+        _t1 = _t.perf_counter()
+        for s in self.streams:
+            cur.wait_stream(s)
+        if _dbg:
+            import sys
+            print(f"[sdn py] entry->call {1e3 * (_t0 - _tin):.2f} ms, driver call {1e3 * (_t1 - _t0):.2f} ms, wait_stream {1e3 * (_t.perf_counter() - _t1):.2f} ms",
+                  file=sys.stderr)
+        return outputs, [int(v) for v in iters]
+
