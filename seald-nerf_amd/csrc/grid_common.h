@@ -42,7 +42,11 @@ __device__ __forceinline__ uint32_t grid_index(uint32_t gridtype, bool align_cor
         }
     }
     if (gridtype == 0 && stride > hashmap_size) index = fast_hash<D>(pos_grid);
-    return (index % hashmap_size) * C;
+    // `index % hashmap_size` without the 30-instruction software division in the common cases (hashmap_size is uniform over the
+    // workgroup): a power-of-two row count is an AND; a dense level holds every corner, so its index is already in range
+    if ((hashmap_size & (hashmap_size - 1u)) == 0u) index &= hashmap_size - 1u;
+    else if (index >= hashmap_size) index %= hashmap_size;
+    return index * C;
 }
 
 inline int fill_levels(LevelParams &lp, const int32_t *offsets_host, uint32_t L, float S, uint32_t H) {

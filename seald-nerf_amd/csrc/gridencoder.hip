@@ -90,22 +90,65 @@ __global__ void __launch_bounds__(256) k_grid_fwd(const float *__restrict__ inpu
         }
     }
 
-    // issue all 2^D row gathers first (independent loads), then blend in the reference's corner order
+    // issue all row gathers first (independent loads), then blend in the reference's corner order
     float vals[1u << D][C];
     float ws[1u << D];
     #pragma unroll
     for (uint32_t idx = 0; idx < (1u << D); idx++) {
         float w = 1;
-        uint32_t pgl[D];
         #pragma unroll
-        for (uint32_t d = 0; d < D; d++) {
-            if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
-            else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
-        }
+        for (uint32_t d = 0; d < D; d++) w *= (idx & (1u << d)) ? pos[d] : 1 - pos[d];
         ws[idx] = w;
-        const uint32_t index = grid_index<D, C>(gridtype, align_corners, hashmap_size, resolution, pgl);
+    }
+    // A level whose index is linear in the coordinates (every tiled level, every hash level that fits its table) keeps the x and
+    // x+1 corners in neighbouring rows: ONE gather of 2 C elements fetches both (the gather address rate, not bytes, bounds this
+    // kernel).  Workgroup-uniform choice; the rare wrap (x corner in the last row of a capped level) is patched after all gathers
+    // of the lane have been issued.
+    uint32_t full_stride = 1;
+    #pragma unroll
+    for (uint32_t d = 0; d < D; d++)
+        if (full_stride <= hashmap_size) full_stride *= align_corners ? resolution : (resolution + 1);
+    // (a row must be a whole number of dwords: the 2-row gather is then at least dword aligned)
+    const bool linear = (C * sizeof(T)) % 4 == 0 && !(gridtype == 0 && full_stride > hashmap_size) && hashmap_size >= 2;
+    if (linear) {
+        constexpr uint32_t NP = 1u << (D - 1);
+        T raw[NP][2 * C];
+        uint32_t wrapped = 0;
         #pragma unroll
-        for (uint32_t ch = 0; ch < C; ch++) vals[idx][ch] = Num<T>::ld(grid + index + ch);
+        for (uint32_t pi = 0; pi < NP; pi++) {
+            uint32_t pgl[D];
+            pgl[0] = pos_grid[0];
+            #pragma unroll
+            for (uint32_t d = 1; d < D; d++) pgl[d] = pos_grid[d] + ((pi >> (d - 1)) & 1u);
+            const uint32_t row0 = grid_index<D, 1>(gridtype, align_corners, hashmap_size, resolution, pgl);
+            const uint32_t rl = min(row0, hashmap_size - 2u);
+            __builtin_memcpy(raw[pi], grid + (size_t)rl * C, 2 * C * sizeof(T));
+            if (row0 > rl) wrapped |= 1u << pi;
+        }
+        if (__builtin_expect(wrapped != 0u, 0)) {
+            #pragma unroll
+            for (uint32_t pi = 0; pi < NP; pi++) {
+                if ((wrapped >> pi) & 1u) {   // x corner = last row (second half of what was fetched), x+1 corner = row 0
+                    #pragma unroll
+                    for (uint32_t ch = 0; ch < C; ch++) { raw[pi][ch] = raw[pi][C + ch]; raw[pi][C + ch] = grid[ch]; }
+                }
+            }
+        }
+        #pragma unroll
+        for (uint32_t idx = 0; idx < (1u << D); idx++) {
+            #pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) vals[idx][ch] = Num<T>::ld(&raw[idx >> 1][(idx & 1u) * C + ch]);
+        }
+    } else {
+        #pragma unroll
+        for (uint32_t idx = 0; idx < (1u << D); idx++) {
+            uint32_t pgl[D];
+            #pragma unroll
+            for (uint32_t d = 0; d < D; d++) pgl[d] = pos_grid[d] + ((idx >> d) & 1u);
+            const uint32_t index = grid_index<D, C>(gridtype, align_corners, hashmap_size, resolution, pgl);
+            #pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) vals[idx][ch] = Num<T>::ld(grid + index + ch);
+        }
     }
     float results[C];
     #pragma unroll
