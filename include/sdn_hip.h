@@ -56,6 +56,12 @@ int sdn_near_far_from_aabb(const float *rays_o, const float *rays_d, const float
 int sdn_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords,
                      void *stream);
 
+/* Caller-side helper ("next" row): the rays of a whole H x W frame from a camera-to-world pose [4,4] (row-major, device memory)
+ * and pinhole intrinsics -- nerf/utils.py:54-137 `get_rays` with N = -1: pixel centres + 0.5, directions normalised.
+ * rays_o, rays_d [H*W, 3]. */
+int sdn_get_rays(const float *pose, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, float *rays_o,
+                 float *rays_d, void *stream);
+
 /* raymarching.h:9-10  morton3D / morton3D_invert;  coords [N,3] int32, indices [N] int32 */
 int sdn_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, void *stream);
 int sdn_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, void *stream);

@@ -1,0 +1,83 @@
+"""Caller-side helpers of the rendering path ("next" rows of the scope table): ray generation and checkpoint loading.
+
+`get_rays` mirrors nerf/utils.py:54-137 of the reference (same arguments, same result dict).  The full-frame case (N = -1) runs as
+one HIP kernel (`sdn_get_rays`); the sampled cases (random pixels, patches, error-map importance sampling) are index bookkeeping
+in torch followed by the same per-pixel arithmetic.
+"""
+import torch
+
+from sdn_backend import lib as _lib, check as _check, ptr as _ptr, stream as _stream
+
+
+def _meshgrid(*args):
+    return torch.meshgrid(*args, indexing="ij")
+
+
+@torch.no_grad()
+def get_rays(poses, intrinsics, H, W, N=-1, error_map=None, patch_size=1):
+    """poses [B,4,4] cam2world, intrinsics (fx, fy, cx, cy) -> {'rays_o','rays_d': [B,N,3] (+ 'inds', 'inds_coarse')}."""
+    device = poses.device
+    B = poses.shape[0]
+    fx, fy, cx, cy = [float(v) for v in intrinsics]
+    results = {}
+    if N <= 0 and poses.is_cuda:
+        rays_o = torch.empty(B, H * W, 3, dtype=torch.float32, device=device)
+        rays_d = torch.empty(B, H * W, 3, dtype=torch.float32, device=device)
+        p = poses.detach().to(torch.float32).contiguous()
+        for b in range(B):
+            _check(_lib.sdn_get_rays(_ptr(p[b]), fx, fy, cx, cy, int(H), int(W), _ptr(rays_o[b]), _ptr(rays_d[b]), _stream()), "get_rays")
+        results["rays_o"], results["rays_d"] = rays_o, rays_d
+        return results
+
+    i, j = _meshgrid(torch.linspace(0, W - 1, W, device=device), torch.linspace(0, H - 1, H, device=device))
+    i = i.t().reshape([1, H * W]).expand([B, H * W]) + 0.5
+    j = j.t().reshape([1, H * W]).expand([B, H * W]) + 0.5
+    if N > 0:
+        N = min(N, H * W)
+        if patch_size > 1:  # nerf/utils.py:82-100
+            num_patch = N // (patch_size ** 2)
+            inds_x = torch.randint(0, H - patch_size, size=[num_patch], device=device)
+            inds_y = torch.randint(0, W - patch_size, size=[num_patch], device=device)
+            inds = torch.stack([inds_x, inds_y], dim=-1)
+            pi, pj = _meshgrid(torch.arange(patch_size, device=device), torch.arange(patch_size, device=device))
+            offsets = torch.stack([pi.reshape(-1), pj.reshape(-1)], dim=-1)
+            inds = (inds.unsqueeze(1) + offsets.unsqueeze(0)).view(-1, 2)
+            inds = (inds[:, 0] * W + inds[:, 1]).expand([B, N])
+        elif error_map is None:  # :102-104
+            inds = torch.randint(0, H * W, size=[N], device=device).expand([B, N])
+        else:  # :105-118
+            inds_coarse = torch.multinomial(error_map.to(device), N, replacement=False)
+            inds_x, inds_y = inds_coarse // 128, inds_coarse % 128
+            sx, sy = H / 128, W / 128
+            inds_x = (inds_x * sx + torch.rand(B, N, device=device) * sx).long().clamp(max=H - 1)
+            inds_y = (inds_y * sy + torch.rand(B, N, device=device) * sy).long().clamp(max=W - 1)
+            inds = inds_x * W + inds_y
+            results["inds_coarse"] = inds_coarse
+        i = torch.gather(i, -1, inds)
+        j = torch.gather(j, -1, inds)
+        results["inds"] = inds
+    zs = torch.ones_like(i)
+    xs = (i - cx) / fx * zs
+    ys = (j - cy) / fy * zs
+    directions = torch.stack((xs, ys, zs), dim=-1)
+    directions = directions / torch.norm(directions, dim=-1, keepdim=True)
+    rays_d = directions @ poses[:, :3, :3].transpose(-1, -2)
+    rays_o = poses[..., :3, 3][..., None, :].expand_as(rays_d)
+    results["rays_o"], results["rays_d"] = rays_o, rays_d
+    return results
+
+
+def load_reference_checkpoint(model, path, map_location="cpu"):
+    """Loads a checkpoint written by the reference's trainer (nerf/utils.py:1095-1154: a dict whose 'model' entry is the state
+    dict; bare state dicts are accepted too) into a `dnerf_amd.network.NeRFNetwork`.  Parameter and buffer names are the
+    reference's (`encoder.embeddings`, `deform_net.N.weight`, `density_bitfield`, ...), so this is a plain name match; the file is
+    read with `weights_only=True` (nothing in it is executed).  Returns (missing_keys, unexpected_keys) like load_state_dict."""
+    blob = torch.load(path, map_location=map_location, weights_only=True)
+    state = blob["model"] if isinstance(blob, dict) and "model" in blob else blob
+    result = model.load_state_dict(state, strict=False)
+    if isinstance(blob, dict):
+        if "mean_count" in blob and hasattr(model, "mean_count"):
+            model.mean_count = blob["mean_count"]
+        if "mean_density" in blob and hasattr(model, "mean_density"):
+            model.mean_density = blob["mean_density"]
+    return result.missing_keys, result.unexpected_keys

@@ -22,6 +22,7 @@ _vp, _u32, _f32, _i32, _u64 = _c.c_void_p, _c.c_uint32, _c.c_float, _c.c_int, _c
 PROTOTYPES = {
     "sdn_near_far_from_aabb": [_vp, _vp, _vp, _u32, _f32, _vp, _vp, _vp],
     "sdn_sph_from_ray": [_vp, _vp, _f32, _u32, _vp, _vp],
+    "sdn_get_rays": [_vp, _f32, _f32, _f32, _f32, _u32, _u32, _vp, _vp, _vp],
     "sdn_morton3D": [_vp, _u32, _vp, _vp],
     "sdn_morton3D_invert": [_vp, _u32, _vp, _vp],
     "sdn_packbits": [_vp, _u32, _f32, _vp, _vp],
