@@ -47,7 +47,7 @@ def parse():
                          "0 = strictly one frame at a time)")
     ap.add_argument("--contexts", type=int, default=3, help="--pipeline: loop contexts (frames in flight)")
     ap.add_argument("--groups", type=int, default=1, help="device loop only: render the frame as G interleaved ray groups on G streams")
-    ap.add_argument("--mode", default="render", choices=["render", "train"],
+    ap.add_argument("--mode", default="render", choices=["render", "train", "seald"],
                     help="render: the headline 800x800 inference frame; train: one dnerf training step on 4096 rays (BASELINE config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-side", type=int, default=96, help="side of the CPU-baseline sample image")
@@ -110,10 +110,54 @@ def train_mode(args):
                                                       "mean_count": model.mean_count}, "kernel_times": summ}))
 
 
+def seald_mode(args):
+    """BASELINE config 4: the SealD-NeRF teacher's edit render -- the jumpingjacks-like frame with the figure's head copied
+    0.35 to the side and hue-shifted by a bounding-box seal mapper -- through the reference-shaped loop (`SealDNeRFTeacher`, op by
+    op) and through the native loop with the fused field (`render_frame(..., mapper=)`).  One JSON line."""
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    from dnerf_amd.bench_scene import build_scene
+    from dnerf_amd.renderer import render_frame, FrameWorkspace
+    from dnerf_amd import fused, seal_mapper as SM
+    sc = build_scene(H=args.size, W=args.size, device=dev, seed=0)
+    half, centre = 0.12, (0.0, 0.47, 0.0)
+    raw = [[centre[0] + sx * half, centre[1] + sy * half, centre[2] + sz * half] for sz in (-1, 1) for sy in (-1, 1) for sx in (-1, 1)]
+    T = np.eye(4); T[0, 3] = 0.35
+    mapper = SM.get_seal_mapper({"type": "bbox", "raw": raw, "transform": T.tolist(), "scale": [1.0, 1.0, 1.0], "boundType": "to",
+                                 "hsv": [0.3, 0.0, 0.0]})
+    SM.fill_bitfield(sc.model.density_bitfield, mapper.map_data["force_fill_bound"].cpu().numpy(), sc.model.grid_size, sc.model.bound)
+    field = fused.FusedField(sc.model, sc.time, fp16=True, max_points=sc.rays_o.shape[0] + 128)
+    ws = FrameWorkspace(sc.rays_o.shape[0], dev)
+
+    def step(count=False):
+        return render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=True, T_thresh=1e-4, workspace=ws, field=field,
+                            count_samples=count, mapper=mapper)
+    first = step(count=True)
+    for _ in range(args.warmup):
+        step()
+    import gc
+    gc.collect(); gc.disable()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    print(json.dumps({"metric": "SealD-NeRF teacher edit render (bbox seal mapper), 800x800 jumpingjacks-like frame", "value": first["n_samples"] * args.steps / dt,
+                      "unit": "sampled-points/s", "rays_per_s": sc.rays_o.shape[0] * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "n_gpus": 1,
+                      "steps": args.steps, "warmup": args.warmup, "dtype": "f16", "data": "synthetic",
+                      "config": {"workload": "BASELINE config 4", "rays": int(sc.rays_o.shape[0]), "sampled_points_per_frame": first["n_samples"],
+                                 "loop_iterations": len(first["trace"]), "T_thresh": 1e-4, "mapper": "SealBBoxMapper (torch on device) between the HIP marcher and the fused field",
+                                 "loop": "host"}}))
+
+
 def main():
     args = parse()
     if args.mode == "train":
         return train_mode(args)
+    if args.mode == "seald":
+        return seald_mode(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

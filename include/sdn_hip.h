@@ -304,6 +304,21 @@ int sdn_render_frames_pipelined_f16(const SdnRenderCtx *const *ctxs, uint32_t n_
                                     uint32_t overlap_div, void *const *streams, void *const *side_streams, void **ev_main,
                                     void **ev_copy, int32_t *host_snap, void *const *ev_field_frames, uint32_t max_field_events,
                                     const uint8_t *exclusive_frames, uint32_t *iterations_out);
+/* ---------------------------------------------------------------------------
+ * SealD-NeRF bounding-box seal mapper on the sample stream  (reference: SealNeRF/seal_utils.py:132-153 map_mask, :245-286
+ * SealBBoxMapper.map_to_origin, :638-693 moller_trumbore / points_in_mesh, :747-758 modify_hsv; torch boolean-mask code there)
+ * ------------------------------------------------------------------------- */
+/* In place on xyzs / dirs [M,3] (device): a sample that is non-zero in every coordinate, strictly inside one of the n_bounds (<= 4)
+ * axis-aligned bounds [n_bounds][lo xyz, hi xyz] and inside the mesh (hit by the ray along test_dir AND the opposite ray) is
+ * taken back to its origin -- tinv [3x4] applied to (p, 1), then (.. - center) * scale + center -- and its direction rotated by
+ * rinv [3x3]; mask [M] u8 receives 1 for mapped samples.  tris [n_tris][12] (device) = v0, E1, E2, N = E1 x E2 per triangle;
+ * bounds, test_dir, tinv, rinv, scale, center are host arrays (copied by value). */
+int sdn_seal_bbox_map(float *xyzs, float *dirs, uint32_t M, const float *bounds, uint32_t n_bounds, const float *tris,
+                      uint32_t n_tris, const float *test_dir, const float *tinv, const float *rinv, const float *scale,
+                      const float *center, uint8_t *mask, void *stream);
+/* rgbs [M,3] of the masked samples: rgb -> hsv, + (dh, ds, dv), -> rgb (color_utils.py:31-63), in place. */
+int sdn_seal_modify_hsv(float *rgbs, const uint8_t *mask, uint32_t M, float dh, float ds, float dv, void *stream);
+
 /* Read-back memory for the frame drivers: 32 bytes per ray group of coherent, device-mapped host memory.  When `host_snap`
  * comes from here the loop kernels publish every iteration's survivor count into it with one 64-bit system-scope store and
  * the driver polls it (no event record / stream wait / copy per iteration); any other pinned memory selects the event +

@@ -312,7 +312,7 @@ class FrameWorkspace:
 
 @torch.no_grad()
 def render_frame(model, rays_o, rays_d, time, fp16=False, dt_gamma=0.0, max_steps=1024, T_thresh=1e-2, bg_color=1.0,
-                 workspace=None, field=None, count_samples=True, use_cull=True):
+                 workspace=None, field=None, count_samples=True, use_cull=True, mapper=None):
     """One inference frame: rays [N,3] -> {'image' [N,3], 'depth' [N], 'weights_sum' [N], 'n_samples', 'trace'}.
 
     Same schedule as dnerf/renderer.py:340-381 (n_step = clamp(N // n_alive, 1, 8), stop at max_steps),
@@ -325,6 +325,10 @@ def render_frame(model, rays_o, rays_d, time, fp16=False, dt_gamma=0.0, max_step
     evaluated on those only (the reference evaluates every padded slot, including the ~94 % empty ones of the first
     iteration); rays whose remaining segment provably cannot produce a sample are retired by the marcher's exact
     cull-grid test instead of stepping through the empty volume voxel by voxel.
+
+    `mapper`: an optional SealD seal mapper (`dnerf_amd.seal_mapper`), hooked exactly where `SealDNeRF/renderer.py:245-267` hooks
+    it -- sample positions / directions are mapped back to their origin before the field is evaluated, colours of the mapped
+    samples are re-mapped after it -- so an edited scene renders through the fused field as well.
     """
     from sdn_backend import lib, check, ptr, stream
     device = rays_o.device
@@ -365,10 +369,22 @@ def render_frame(model, rays_o, rays_d, time, fp16=False, dt_gamma=0.0, max_step
                                     ptr(live_count), st), "march_rays_ex")
         if n_samples is not None:  # ops path: live samples = slots with a non-zero step (bookkeeping, off in the timed loop)
             n_samples += (deltas[:M0, 0] > 0).sum()
+        q_xyzs, q_dirs, mapped = xyzs, dirs, None
+        native_map = mapper is not None and hasattr(mapper, "map_to_origin_") and mapper._native_ok(xyzs, dirs)
+        if native_map:      # in place on the sample buffers (the marcher rewrites them every iteration)
+            mapper.map_data_conversion(xyzs)
+            mapped = mapper.map_to_origin_(xyzs, dirs)
+        elif mapper is not None:
+            q_xyzs, q_dirs, mapped = mapper.map_to_origin(xyzs, dirs)
+            q_xyzs, q_dirs = q_xyzs.contiguous(), q_dirs.contiguous()
         if use_list:
-            sigmas, rgbs = evaluate(xyzs, dirs, ws.live_idx, live_count)
+            sigmas, rgbs = evaluate(q_xyzs, q_dirs, ws.live_idx, live_count)
         else:
-            sigmas, rgbs = evaluate(xyzs, dirs)
+            sigmas, rgbs = evaluate(q_xyzs, q_dirs)
+        if native_map:
+            mapper.map_color_(rgbs, mapped)
+        elif mapped is not None and bool(mapped.any()):
+            rgbs[mapped] = mapper.map_color(q_xyzs[mapped], q_dirs[mapped], rgbs[mapped]).to(rgbs.dtype)
         check(lib.sdn_composite_rays(n_alive, n_step, float(T_thresh), ptr(alive), ptr(ws.rays_t), ptr(sigmas), ptr(rgbs), ptr(deltas),
                                      ptr(ws.weights_sum), ptr(ws.depth), ptr(ws.image), st), "composite_rays")
         check(lib.sdn_compact_alive(ptr(alive), n_alive, ptr(ws.alive[1 - cur]), ptr(ws.count), ptr(ws.scratch), st), "compact_alive")

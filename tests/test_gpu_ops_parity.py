@@ -497,3 +497,49 @@ def test_load_reference_checkpoint_roundtrip(tmp_path):
     assert not missing and not unexpected and b.mean_count == 123
     for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
         assert ka == kb and torch.equal(va, vb)
+
+
+def test_seal_bbox_kernels_match_the_torch_restatement():
+    """csrc/seal.hip against dnerf_amd/seal_mapper's torch restatement of SealNeRF/seal_utils.py (run on the CPU): identical
+    masks except within rounding of a face (excluded by an analytic margin), mapped coordinates / directions to 2e-6, colours
+    to 2e-6; empty (all-zero) slots are never mapped."""
+    from dnerf_amd import seal_mapper as SM
+    rng = np.random.default_rng(5)
+
+    def rot(axis, deg):
+        a = np.asarray(axis, np.float64) / np.linalg.norm(axis); t = np.deg2rad(deg)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        return np.eye(3) + np.sin(t) * K + (1 - np.cos(t)) * K @ K
+    R0, c0, half = rot([0, 0, 1], 20.0), np.array([-0.2, 0.0, 0.1]), np.array([0.15, 0.1, 0.2])
+    corners = (np.array([[sx, sy, sz] for sz in (-1, 1) for sy in (-1, 1) for sx in (-1, 1)], np.float64) * half) @ R0.T + c0
+    T = np.eye(4); T[:3, :3] = rot([0, 1, 0], 30.0); T[:3, 3] = [0.45, 0.05, -0.1]
+    scale = np.array([1.5, 1.0, 0.8])
+    for bound_type in ("to", "both"):
+        cfg = {"type": "bbox", "raw": corners.tolist(), "transform": T.tolist(), "scale": scale.tolist(), "boundType": bound_type,
+               "hsv": [0.15, -0.05, 0.02]}
+        cpu, gpu = SM.get_seal_mapper(cfg), SM.get_seal_mapper(cfg)
+        p = rng.uniform(-0.8, 0.8, (50000, 3)).astype(np.float32)
+        p[:100] = 0.0                                                  # empty slots
+        d = rng.standard_normal((50000, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        cp, cd, cm = cpu.map_to_origin(torch.from_numpy(p), torch.from_numpy(d))
+        gp, gd, gm = gpu.map_to_origin(torch.from_numpy(p).cuda(), torch.from_numpy(d).cuda())
+        assert gm.dtype == torch.bool and not bool(gm[:100].any())
+        # analytic distance of every point to the faces of the mapped boxes: the masks may only differ within 1e-5 of a face
+        def margin(verts):
+            e = [verts[1] - verts[0], verts[2] - verts[0], verts[4] - verts[0]]
+            loc = np.stack([((p - verts[0]) @ (ei / np.linalg.norm(ei))) for ei in e], 1)
+            ln = np.array([np.linalg.norm(ei) for ei in e])
+            return np.minimum(np.abs(loc), np.abs(loc - ln)).min(1)
+        m = margin(gpu.to_vertices)
+        if bound_type == "both":
+            m = np.minimum(m, margin(gpu.from_vertices))
+        clear = m > 1e-5
+        assert np.array_equal(cm.numpy()[clear], gm.cpu().numpy()[clear]) and int(cm.sum()) > 200
+        both = (cm & gm.cpu()).numpy()
+        assert np.allclose(gp.cpu().numpy()[both], cp.numpy()[both], atol=2e-6) and np.allclose(gd.cpu().numpy()[both], cd.numpy()[both], atol=2e-6)
+        assert torch.equal(gp.cpu()[~gm.cpu()], torch.from_numpy(p)[~gm.cpu()])      # untouched outside the mask
+        cols = rng.random((50000, 3), dtype=np.float32)
+        want = torch.from_numpy(cols).clone()
+        want[cm] = cpu.map_color(None, None, want[cm])
+        got = gpu.map_color_(torch.from_numpy(cols).cuda(), cm.cuda())
+        assert np.allclose(got.cpu().numpy(), want.numpy(), atol=2e-6)
