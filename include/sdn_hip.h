@@ -243,6 +243,16 @@ int sdn_ffmlp_backward(const void *grad, const void *inputs, const void *weights
  * Buffer sizes: per-ray arrays N; sample arrays M_cap >= N + 128 rows; live_counts n_counters >= max_steps + 8;
  * state 16 ints; trace 2 * n_counters + 16 (ints 2 * n_counters .. +8 are a 4-deep ring of {alive rays entering the next iteration, iteration
  * number} snapshots for asynchronous read-back, the int after them a survivor-count scratch word); block_totals ceil(N / 256) + 1; n_out 1 int, zero on entry (ticket counter); cull_bits sdn_cull_grid_bytes(). */
+/* Arguments of sdn_seal_bbox_map / sdn_seal_modify_hsv as one record (host memory except `tris`), for SdnRenderCtx.seal. */
+typedef struct SdnSealBox {
+    float bounds[24];          /* n_bounds x {lo xyz, hi xyz} */
+    uint32_t n_bounds, n_tris;
+    const float *tris;         /* device, [n_tris][12] */
+    float test_dir[3], tinv[12], rinv[9], scale[3], center[3];
+    float hsv[3];              /* colour modification of the mapped samples */
+    int32_t modify_hsv;        /* 0 = leave colours alone */
+} SdnSealBox;
+
 typedef struct SdnRenderCtx {
     const float *rays_o, *rays_d, *nears, *fars;
     const uint8_t *bitfield;
@@ -270,6 +280,10 @@ typedef struct SdnRenderCtx {
     /* optional [N] scratch: per-ray cache of the cull-grid scan (the parameter beyond which a ray meets no marked cell), so
      * that only a ray's first march of a frame scans; NULL = scan in every iteration */
     float *rays_tend;
+    /* optional SealD edit: a bounding-box seal mapper applied to every iteration's samples between the marcher and the field
+     * network (sdn_seal_bbox_map) and to the colours of the mapped samples after it (sdn_seal_modify_hsv); NULL = no edit */
+    const struct SdnSealBox *seal;
+    uint8_t *seal_mask;        /* [M_cap] scratch, required with `seal` */
 } SdnRenderCtx;
 
 /* Resets per-ray state (alive = 0..N-1, rays_t = nears, accumulators = 0), the loop record and the counters, and builds

@@ -35,6 +35,21 @@ extern "C" {
 int sdn_render_finish(const SdnRenderCtx *c, float bg_color, float *image_out, float *depth_out, void *stream);
 int sdn_render_step_f16_ev(const SdnRenderCtx *c, uint32_t bound_alive, void *ev_field_begin, void *ev_field_end, void *stream);
 
+// SealD edit hooks of an iteration (no-ops without ctx->seal): samples back to their origin before the field network, colours of
+// the mapped samples after it.  m_slots bounds the slots the marcher wrote this iteration.
+static int seal_map(const SdnRenderCtx *c, uint32_t m_slots, hipStream_t st) {
+    const SdnSealBox *s = c->seal;
+    if (!s) return 0;
+    if (!c->seal_mask) return SDN_E_BADARG;
+    return sdn_seal_bbox_map(c->xyzs, c->dirs, m_slots, s->bounds, s->n_bounds, s->tris, s->n_tris, s->test_dir, s->tinv, s->rinv, s->scale,
+                             s->center, c->seal_mask, st);
+}
+static int seal_color(const SdnRenderCtx *c, uint32_t m_slots, hipStream_t st) {
+    const SdnSealBox *s = c->seal;
+    if (!s || !s->modify_hsv) return 0;
+    return sdn_seal_modify_hsv(c->rgbs, c->seal_mask, m_slots, s->hsv[0], s->hsv[1], s->hsv[2], st);
+}
+
 static bool ctx_ok(const SdnRenderCtx *c) {
     return c && c->rays_o && c->rays_d && c->nears && c->fars && c->bitfield && c->alive_a && c->alive_b && c->rays_t && c->weights_sum &&
            c->depth && c->image && c->state && c->live_counts && c->cull_bits;
@@ -61,11 +76,15 @@ int sdn_render_step_f16_ev(const SdnRenderCtx *c, uint32_t bound_alive, void *ev
     // n_alive * n_step <= N always (n_step <= N / n_alive), and <= 8 * bound_alive
     uint64_t m_bound = (uint64_t)bound_alive * 8u;
     if (m_bound > c->N) m_bound = c->N;
+    rc = seal_map(c, (uint32_t)m_bound, st);
+    if (rc) return rc;
     if (ev_field_begin) (void)hipEventRecord((hipEvent_t)ev_field_begin, st);
     rc = sdn_int::field_forward_f16(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, (uint32_t)m_bound,
                                     c->field_weights, c->field_bias0, c->grid_table, c->grid_offsets, c->grid_S, c->grid_H, c->bound,
                                     c->density_scale, c->zero_deform, c->sigmas, c->rgbs, 0u, st);
     if (ev_field_end) (void)hipEventRecord((hipEvent_t)ev_field_end, st);
+    if (rc) return rc;
+    rc = seal_color(c, (uint32_t)m_bound, st);
     if (rc) return rc;
     return sdn_int::loop_composite_compact(bound_alive, c->T_thresh, c->alive_a, c->alive_b, c->rays_t, c->sigmas, c->rgbs, c->deltas,
                                            c->weights_sum, c->depth, c->image, c->state, (uint32_t *)c->block_totals, c->n_out, c->trace,
@@ -129,11 +148,14 @@ struct FrameRun {
         } else {
             uint64_t m_bound = (uint64_t)bound * 8u;
             if (m_bound > c->N) m_bound = c->N;
+            rc = seal_map(c, (uint32_t)m_bound, st);
+            if (rc) return rc;
             if (e0) (void)hipEventRecord((hipEvent_t)e0, st);
             rc = sdn_int::field_forward_f16(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, (uint32_t)m_bound,
                                             c->field_weights, c->field_bias0, c->grid_table, c->grid_offsets, c->grid_S, c->grid_H, c->bound,
                                             c->density_scale, c->zero_deform, c->sigmas, c->rgbs, last_alive * 8u, st);
             if (e1) (void)hipEventRecord((hipEvent_t)e1, st);
+            if (!rc) rc = seal_color(c, (uint32_t)m_bound, st);
             if (!rc)
                 rc = sdn_int::loop_composite_march(bound, c->T_thresh, c->alive_a, c->alive_b, c->rays_t, c->rays_o, c->rays_d, c->bound,
                                                    c->dt_gamma, c->max_steps, c->C, c->H, c->bitfield, c->fars, c->sigmas, c->rgbs, c->xyzs,

@@ -429,7 +429,7 @@ class DeviceLoop:
     RING = 4
     MAX_TIMED = 24  # iterations whose fused-field launch can be timed in place (the headline frame has 11 + 1)
 
-    def __init__(self, model, field, N, device, max_steps=1024, T_thresh=1e-2, dt_gamma=0.0, mailbox=True):
+    def __init__(self, model, field, N, device, max_steps=1024, T_thresh=1e-2, dt_gamma=0.0, mailbox=True, mapper=None):
         import ctypes
         from sdn_backend import lib, SdnRenderCtx
         f32, i32 = torch.float32, torch.int32
@@ -464,6 +464,36 @@ class DeviceLoop:
         c.bound, c.dt_gamma, c.T_thresh, c.density_scale = float(model.bound), float(dt_gamma), float(T_thresh), float(model.density_scale)
         self.ctx = c
         self.max_steps = int(max_steps)
+        self.set_mapper(mapper)
+
+    def set_mapper(self, mapper):
+        """Hooks a SealD bounding-box seal mapper (`dnerf_amd.seal_mapper.SealBBoxMapper`, or None) into every iteration of the native
+        loop: samples are mapped back to their origin before the field kernel, colours of the mapped samples re-mapped after it."""
+        import ctypes
+        from sdn_backend import SdnSealBox
+        c = self.ctx
+        self.mapper = mapper
+        if mapper is None:
+            c.seal, c.seal_mask, self._seal = None, None, None
+            return
+        dev = self.buf["xyzs"].device
+        mapper.map_data_conversion(self.buf["xyzs"])
+        a = mapper._native_args(dev)
+        if "map_source" in mapper.map_data or "rgb" in mapper.map_data:
+            raise NotImplementedError("the native loop hooks bbox mappers with an optional hsv modification (mapSource / rgb tint: use render_frame)")
+        box = SdnSealBox()
+        for k in range(6 * a["n_bounds"]):
+            box.bounds[k] = a["bounds"][k]
+        box.n_bounds, box.n_tris, box.tris = a["n_bounds"], a["n_tris"], a["tris"].data_ptr()
+        for name, n in (("test_dir", 3), ("tinv", 12), ("rinv", 9), ("scale", 3), ("center", 3)):
+            for k in range(n):
+                getattr(box, name)[k] = a[name][k]
+        if "hsv" in mapper.map_data:
+            h = [float(v) for v in mapper.map_data["hsv"].reshape(-1).tolist()]
+            box.hsv[0], box.hsv[1], box.hsv[2], box.modify_hsv = h[0], h[1], h[2], 1
+        mask = torch.empty(self.buf["sigmas"].shape[0], dtype=torch.uint8, device=dev)
+        self._seal = (box, mask, a)      # keep the record, the mask and the triangle tensor alive
+        c.seal, c.seal_mask = ctypes.addressof(box), mask.data_ptr()
 
     def prepare_timing(self, frames):
         """Pre-creates (outside any timed region) the HIP event pairs for `frames` timed renders: MAX_TIMED pairs per frame,

@@ -64,7 +64,13 @@ class SdnRenderCtx(ctypes.Structure):
                 + [("grid_offsets", ctypes.c_int32 * 17), ("grid_S", _f32), ("grid_H", _u32)]
                 + [(n, _u32) for n in ("N", "M_cap", "n_counters", "max_steps", "C", "H")]
                 + [(n, _f32) for n in ("bound", "dt_gamma", "T_thresh", "density_scale")]
-                + [("zero_deform", ctypes.c_int32), ("aabb", _vp), ("min_near", _f32), ("reserved_", ctypes.c_int32), ("rays_tend", _vp)])
+                + [("zero_deform", ctypes.c_int32), ("aabb", _vp), ("min_near", _f32), ("reserved_", ctypes.c_int32), ("rays_tend", _vp), ("seal", _vp), ("seal_mask", _vp)])
+
+
+class SdnSealBox(ctypes.Structure):
+    """Mirror of `SdnSealBox` in include/sdn_hip.h."""
+    _fields_ = [("bounds", _f32 * 24), ("n_bounds", _u32), ("n_tris", _u32), ("tris", _vp), ("test_dir", _f32 * 3), ("tinv", _f32 * 12),
+                ("rinv", _f32 * 9), ("scale", _f32 * 3), ("center", _f32 * 3), ("hsv", _f32 * 3), ("modify_hsv", ctypes.c_int32)]
 
 
 PROTOTYPES_U32 = {

@@ -383,3 +383,35 @@ def test_native_loop_with_mapper_matches_seald_teacher(small_scene):
         c = render_frame(teacher, sc.rays_o, sc.rays_d, sc.time, fp16=True, T_thresh=1e-4, field=f, mapper=mapper)
     assert torch.isfinite(c["image"]).all()
     assert float((c["image"] - b["image"]).abs().max()) < 5e-2 and float((c["image"] - b["image"]).abs().mean()) < 2e-3
+
+
+def test_device_loop_with_mapper_equals_host_loop_with_mapper(small_scene):
+    """The seal hooks inside the native frame drivers (one frame, and a stream of frames) give the edited frame the host loop
+    with the same mapper gives, bit for bit; and un-hooking restores the unedited frame."""
+    from dnerf_amd import fused, seal_mapper as SM
+    from dnerf_amd.renderer import render_frame, DeviceLoop, PipelinedDeviceLoop
+    sc = small_scene
+    half, centre = 0.12, (0.0, 0.47, 0.0)
+    raw = [[centre[0] + sx * half, centre[1] + sy * half, centre[2] + sz * half] for sz in (-1, 1) for sy in (-1, 1) for sx in (-1, 1)]
+    T = np.eye(4); T[0, 3] = 0.35
+    mapper = SM.get_seal_mapper({"type": "bbox", "raw": raw, "transform": T.tolist(), "scale": [1.0, 1.0, 1.0], "boundType": "to",
+                                 "hsv": [0.3, 0.0, 0.0]})
+    import copy
+    model = copy.deepcopy(sc.model)
+    SM.fill_bitfield(model.density_bitfield, mapper.map_data["force_fill_bound"].cpu().numpy(), model.grid_size, model.bound)
+    f = fused.FusedField(model, sc.time, fp16=True)
+    N, dev = sc.rays_o.shape[0], sc.rays_o.device
+    host = render_frame(model, sc.rays_o, sc.rays_d, sc.time, fp16=True, field=f, mapper=mapper)
+    plain = render_frame(model, sc.rays_o, sc.rays_d, sc.time, fp16=True, field=f)
+    assert not torch.equal(host["image"], plain["image"])
+    loop = DeviceLoop(model, f, N, dev, mapper=mapper)
+    a = loop.render(sc.rays_o, sc.rays_d, sc.time)
+    assert torch.equal(a["image"], host["image"]) and a["n_samples"] == host["n_samples"]
+    loop.set_mapper(None)
+    b = loop.render(sc.rays_o, sc.rays_d, sc.time)
+    assert torch.equal(b["image"], plain["image"])
+    pl = PipelinedDeviceLoop(model, f, N, dev, contexts=2, mapper=mapper)
+    outs, _ = pl.render_frames([sc.rays_o] * 3, [sc.rays_d] * 3, sc.time, outputs=[(torch.empty(N, 3, device=dev), torch.empty(N, device=dev)) for _ in range(3)])
+    torch.cuda.synchronize()
+    for img, _ in outs:
+        assert torch.equal(img, host["image"])
