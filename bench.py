@@ -244,16 +244,17 @@ def main():
 
     def stream_of_frames(k, every=0):
         """k frames through the pipelined driver; every > 0: the field launches of every `every`-th frame are timed in place."""
-        # instrumented frames: the first and the last of the stream are rendered with nothing else in flight -- the pipeline is
-        # empty / draining there anyway -- and their launch durations are the kernel's own (the roofline figure); every `every`-th
-        # frame in between is instrumented while it overlaps like all the others (what a launch takes while it shares the device)
-        marked = sorted(set(range(0, k, every)) | {k - 1}) if every else []
+        # instrumented frames: the first (and in a long stream the last) frame is rendered with nothing else in flight -- the
+        # pipeline is empty / draining there anyway -- and its launch durations are the kernel's own (the roofline figure); every
+        # `every`-th frame in between is instrumented while it overlaps like all the others (a launch while it shares the device)
+        excl_set = exclusive_frames(k)
+        marked = sorted(set(range(0, k, every)) | excl_set) if every else []
         timing = make_timing(len(marked))
         per_frame, it = [None] * k, iter(timing)
         exclusive = [False] * k
         for f in marked:
             per_frame[f] = next(it)
-            exclusive[f] = f in (0, k - 1)
+            exclusive[f] = f in excl_set
         outputs = None
         if world > 1:  # every frame keeps its own shard output until it has been gathered
             outputs = [(torch.empty(n_local, 3, dtype=torch.float32, device=dev), torch.empty(n_local, dtype=torch.float32, device=dev))
@@ -350,15 +351,15 @@ def main():
     }
     if rank == 0:
         if ploop is not None:
-            marked = sorted(set(range(0, args.steps, every)) | {args.steps - 1})
-            n_instrumented, n_excl = len(marked), len({0, args.steps - 1})
+            marked = sorted(set(range(0, args.steps, every)) | exclusive_frames(args.steps))
+            n_instrumented, n_excl = len(marked), len(exclusive_frames(args.steps))
         else:
             n_excl = n_instrumented
         result["roofline"], result["kernel_times"] = roofline(timers, fp16, n_samples_local, n_iters, n_excl, n_instrumented - n_excl)
         if result["roofline"]:
             result["roofline"]["instrumented_steps"] = (
                 f"{n_instrumented} of {args.steps} timed steps (every {every}th" + (", plus the last" if ploop is not None else "") + ")"
-                + (f"; {n_excl} of them (the first and the last) rendered with nothing else in flight -- their launches give achieved / frac -- and "
+                + (f"; {n_excl} of them (the first" + (" and the last" if n_excl > 1 else "") + ") rendered with nothing else in flight -- their launches give achieved / frac -- and "
                    f"{n_instrumented - n_excl} overlapped like the uninstrumented steps (the `overlapped` entry)" if ploop is not None else ""))
             # field FLOPs of the whole timed region over its wall time: a lower bound of the kernel's rate that no overlap can inflate
             result["roofline"]["whole_job_mfma_frac"] = FIELD_FLOP_PER_POINT * n_samples * args.steps / elapsed / 1e12 / MFMA_F16_PEAK_TFLOPS
@@ -367,6 +368,12 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def exclusive_frames(k):
+    """Frames of a k-frame stream that are rendered with nothing else in flight so that their launch durations are the kernel's
+    own: the first (the pipeline is empty there anyway) and, in a long enough stream, the last (it is draining anyway)."""
+    return {0, k - 1} if k >= 16 else {0}
 
 
 def roofline(timers, fp16, n_samples, n_iters, steps, steps_overlapped=0):
