@@ -172,6 +172,17 @@ struct FrameRun {
         return (int)e;
     }
 
+    // has the survivor count of iteration it-1 arrived (non-blocking)?  settle() will then not wait
+    bool ready() const {
+        if (it == 0) return true;
+        const uint32_t prev = (it - 1) & 3u;
+        if (mail_dev) {
+            const uint64_t want = ((uint64_t)tag << 16) | it;
+            return (__atomic_load_n(reinterpret_cast<const uint64_t *>(host_snap) + prev, __ATOMIC_ACQUIRE) >> 32) == want;
+        }
+        return hipEventQuery((hipEvent_t)ev_copy[prev]) == hipSuccess;
+    }
+
     // wait for the survivor count of iteration it-1 (iteration `it` is already enqueued), then advance
     int settle() {
         if (it >= 1) {
@@ -312,64 +323,82 @@ int sdn_render_frames_pipelined_f16(const SdnRenderCtx *const *ctxs, uint32_t n_
         frame_of[slot] = (int)next++;
         return runs[slot].begin();
     };
-    int rc = start(0);
-    if (rc) return rc;
+    // Event-driven: every frame in flight always has exactly one iteration enqueued beyond the one whose survivor count the host
+    // has seen; whichever frame's count arrives is advanced at once (oldest first when several are ready), so a frame never
+    // idles behind another frame's longer iteration.
     const bool stats = getenv("SDN_DRIVER_STATS") != nullptr;   // host-side time split of the driver loop, to stderr
-    double t_enq = 0, t_set = 0, t_max_enq = 0, t_max_set = 0;
+    double t_work = 0, t_idle = 0;
     uint32_t n_loops = 0;
     auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto launch_next = [&]() -> int {   // start the next frame if a context is free and the overlap rule allows it
+        if (next >= n_frames) return 0;
+        const uint32_t slot = next % n_ctx;
+        if (frame_of[slot] >= 0) return 0;
+        int newest = -1;
+        bool any_active = false, excl_in_flight = false;
+        for (uint32_t c = 0; c < n_ctx; c++) {
+            if (frame_of[c] < 0) continue;
+            any_active = true;
+            if (newest < 0 || frame_of[c] > frame_of[newest]) newest = (int)c;
+            if (exclusive_frames && exclusive_frames[frame_of[c]]) excl_in_flight = true;
+        }
+        bool ok = !any_active || (uint64_t)runs[newest].last_alive * overlap_div <= local[slot].N;
+        // an exclusive frame has the device to itself (used to time its kernels undisturbed): it starts only when nothing
+        // else is in flight, and nothing starts while it is
+        if (exclusive_frames && any_active && (exclusive_frames[next] || excl_in_flight)) ok = false;
+        if (!ok) return 0;
+        int r = start(slot);
+        if (!r) r = runs[slot].enqueue();
+        return r;
+    };
+    int rc = launch_next();
+    if (rc) return rc;
+    auto t_last = stats ? now() : 0.0;
+    uint32_t idle_spins = 0;
     while (finished < n_frames) {
         n_loops++;
-        // contexts in frame order, oldest first: its kernels are the ones the stream of frames is waiting for
+        bool progress = false;
+        // contexts in frame order, oldest first
         uint32_t order[kMaxCtx], n_act = 0;
-        for (uint32_t s = 0; s < n_ctx; s++)
-            if (frame_of[s] >= 0) order[n_act++] = s;
+        for (uint32_t s2 = 0; s2 < n_ctx; s2++)
+            if (frame_of[s2] >= 0) order[n_act++] = s2;
         for (uint32_t a = 1; a < n_act; a++)
             for (uint32_t b = a; b > 0 && frame_of[order[b]] < frame_of[order[b - 1]]; b--) { const uint32_t t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
-        const double t0 = stats ? now() : 0;
-        for (uint32_t a = 0; a < n_act; a++) { rc = runs[order[a]].enqueue(); if (rc) return rc; }
-        const double t1 = stats ? now() : 0;
-        uint32_t newest_alive = 0;
-        bool any_active = false;
         for (uint32_t a = 0; a < n_act; a++) {
-            const uint32_t s = order[a];
-            rc = runs[s].settle();
+            const uint32_t s2 = order[a];
+            if (!runs[s2].ready()) continue;
+            progress = true;
+            rc = runs[s2].settle();
             if (rc) return rc;
-            if (runs[s].done) {
-                const int f = frame_of[s];
-                rc = sdn_render_finish(&local[s], bg_color, image_outs[f], depth_outs[f], streams[s]);
+            if (runs[s2].done) {
+                const int f = frame_of[s2];
+                rc = sdn_render_finish(&local[s2], bg_color, image_outs[f], depth_outs[f], streams[s2]);
                 if (rc) return rc;
-                if (iterations_out) iterations_out[f] = runs[s].it + 1;
-                frame_of[s] = -1;
+                if (iterations_out) iterations_out[f] = runs[s2].it + 1;
+                frame_of[s2] = -1;
                 finished++;
             } else {
-                any_active = true;
-                newest_alive = runs[s].last_alive;     // order is oldest first: the last one kept is the newest frame's
+                rc = runs[s2].enqueue();
+                if (rc) return rc;
             }
+            rc = launch_next();
+            if (rc) return rc;
         }
-        if (stats) {
-            const double t2 = now();
-            t_enq += t1 - t0; t_set += t2 - t1;
-            if (t1 - t0 > t_max_enq) t_max_enq = t1 - t0;
-            if (t2 - t1 > t_max_set) t_max_set = t2 - t1;
-        }
-        if (next < n_frames) {
-            const uint32_t slot = next % n_ctx;
-            bool ok = !any_active || (uint64_t)newest_alive * overlap_div <= local[slot].N;
-            if (exclusive_frames && any_active) {
-                // an exclusive frame has the device to itself (used to time its kernels undisturbed): it starts only when nothing
-                // else is in flight, and nothing starts while it is
-                bool excl_in_flight = false;
+        if (!progress) {
+            rc = launch_next();
+            if (rc) return rc;
+            if ((++idle_spins & 0xFFFFFu) == 0) {   // nothing arrives for a long time: surface a device error instead of spinning for ever
                 for (uint32_t c = 0; c < n_ctx; c++)
-                    if (frame_of[c] >= 0 && exclusive_frames[frame_of[c]]) excl_in_flight = true;
-                if (exclusive_frames[next] || excl_in_flight) ok = false;
+                    if (frame_of[c] >= 0) { hipError_t q = hipStreamQuery((hipStream_t)streams[c]); if (q != hipSuccess && q != hipErrorNotReady) return (int)q; }
             }
-            if (frame_of[slot] < 0 && ok) { rc = start(slot); if (rc) return rc; }
+        } else {
+            idle_spins = 0;
         }
+        if (stats) { const double t = now(); (progress ? t_work : t_idle) += t - t_last; t_last = t; }
     }
     if (stats)
-        fprintf(stderr, "[sdn driver] frames %u contexts %u loops %u  enqueue %.0f us (max %.0f)  settle/wait %.0f us (max %.0f)  mailbox %d\n", n_frames,
-                n_ctx, n_loops, t_enq, t_max_enq, t_set, t_max_set, runs[0].mail_dev != nullptr);
+        fprintf(stderr, "[sdn driver] frames %u contexts %u loops %u  host busy %.0f us  idle-polling %.0f us  mailbox %d\n", n_frames, n_ctx, n_loops, t_work,
+                t_idle, runs[0].mail_dev != nullptr);
     return 0;
 }
 
