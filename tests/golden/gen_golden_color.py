@@ -21,6 +21,6 @@ hsv = ref.rgb2hsv_torch(t.clone())
 back = ref.hsv2rgb_torch(hsv.clone())
 hsv_in = torch.from_numpy(rng.random((256, 3), dtype=np.float32)).view(-1, 3, 1)
 rgb_from = ref.hsv2rgb_torch(hsv_in.clone())
-np.savez("tests/golden/color_reference_torch.npz", rgb=rgb, hsv=hsv.view(-1, 3).numpy(), back=back.view(-1, 3).numpy(),
+np.savez(__import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "color_reference_torch.npz"), rgb=rgb, hsv=hsv.view(-1, 3).numpy(), back=back.view(-1, 3).numpy(),
          hsv_in=hsv_in.view(-1, 3).numpy(), rgb_from=rgb_from.view(-1, 3).numpy())
 print("ok", float((back.view(-1, 3) - t.view(-1, 3)).abs().max()))

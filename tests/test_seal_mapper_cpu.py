@@ -1,5 +1,5 @@
 """The SealD bounding-box mapper (dnerf_amd/seal_mapper.py) on the CPU: colour conversions against vectors generated from the
-reference's pure-torch `SealNeRF/color_utils.py` (tests/gen_golden_color.py), the box / inside-test geometry against an analytic
+reference's pure-torch `SealNeRF/color_utils.py` (tests/golden/gen_golden_color.py), the box / inside-test geometry against an analytic
 oriented-box test, and the map_to_origin algebra (it inverts the configured edit)."""
 import os
 
