@@ -75,8 +75,10 @@ int sdn_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *b
  * point offset, point count); counter [2] int32 (points, rays) is ADDED to, as in the reference.
  * Difference: slot allocation is a deterministic prefix scan in ray order (rays[i,0] == i) instead
  * of two racing atomicAdds, so results are reproducible; per ray the samples are identical.
- * scratch: caller-provided workspace of sdn_march_rays_train_scratch_bytes(N) bytes. */
-uint64_t sdn_march_rays_train_scratch_bytes(uint32_t N);
+ * scratch: caller-provided workspace of sdn_march_rays_train_scratch_bytes(N, max_steps) bytes, 16-byte aligned (scan
+ * workspace, the slice's cull grid, and the parameter t of every sample: each ray is marched ONCE -- the counting pass records
+ * t, a parallel pass rebuilds positions / deltas from it -- where the reference marches every ray twice). */
+uint64_t sdn_march_rays_train_scratch_bytes(uint32_t N, uint32_t max_steps);
 int sdn_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound,
                          float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                          const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,

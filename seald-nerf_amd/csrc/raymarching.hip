@@ -273,6 +273,41 @@ __device__ __forceinline__ bool ray_may_hit(const uint32_t *cull_bits, float ox,
     return true;
 }
 
+// LDS-resident occupancy caches of the marching kernels (FAST configuration with a cull grid only)
+struct OccCache {
+    const uint32_t *s_cull = nullptr;            // 32^3 mark bits
+    const unsigned long long *fine = nullptr;    // fine bits of the marked bounding box (one word = 4x4x4 voxels)
+    int fx0 = 0, fy0 = 0, fz0 = 0, fnx = 0, fny = 0, fnz = 0;   // bounding box of the marked cull cells (origin, extent)
+};
+
+// Cooperative load by a 256-thread workgroup; contains a barrier, so every thread of the workgroup must call it.
+template <bool FAST>
+__device__ __forceinline__ void occ_cache_load(const uint32_t *__restrict__ cull, const uint8_t *__restrict__ grid, uint4 *s_cull4,
+                                               unsigned long long *s_fine, OccCache &oc) {
+    if constexpr (FAST) {
+        if (cull) {  // kernel-uniform
+            s_cull4[threadIdx.x] = reinterpret_cast<const uint4 *>(cull)[threadIdx.x];
+            const int *meta = reinterpret_cast<const int *>(cull + kCullWords);
+            oc.fx0 = meta[0]; oc.fy0 = meta[1]; oc.fz0 = meta[2];
+            oc.fnx = meta[3] - oc.fx0 + 1; oc.fny = meta[4] - oc.fy0 + 1;
+            const int fnz = meta[5] - oc.fz0 + 1;
+            oc.fnz = fnz;
+            if (oc.fnx > 0 && oc.fny > 0 && fnz > 0 && (uint32_t)(oc.fnx * oc.fny * fnz) <= kFineCacheCells) {
+                const unsigned long long *__restrict__ blocks = reinterpret_cast<const unsigned long long *>(grid);
+                const int cells = oc.fnx * oc.fny * fnz;
+                for (int i = (int)threadIdx.x; i < cells; i += 256) {
+                    const int cx = oc.fx0 + i % oc.fnx, cy = oc.fy0 + (i / oc.fnx) % oc.fny, cz = oc.fz0 + i / (oc.fnx * oc.fny);
+                    s_fine[i] = blocks[morton3D_8bit((uint32_t)cx, (uint32_t)cy, (uint32_t)cz)];
+                }
+                oc.fine = s_fine;
+            }
+            __syncthreads();
+            oc.s_cull = reinterpret_cast<const uint32_t *>(s_cull4);
+        }
+    }
+}
+
+
 // ---------------------------------------------------------------------------
 // utils
 // ---------------------------------------------------------------------------
@@ -364,18 +399,37 @@ __global__ void __launch_bounds__(256) k_march_train_count(const float *__restri
                                                            const uint8_t *__restrict__ grid, float bound, float dt_gamma,
                                                            uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                                                            const float *__restrict__ nears, const float *__restrict__ fars,
-                                                           const float *__restrict__ noises, uint32_t *__restrict__ num_steps_out) {
+                                                           const float *__restrict__ noises, uint32_t *__restrict__ num_steps_out,
+                                                           const uint32_t *__restrict__ cull, float *__restrict__ sample_t) {
+    // The one marching pass of a training step: counts every ray's samples AND records their parameters t (sample_t
+    // [N, max_steps]), from which the emit pass rebuilds positions and deltas with the marcher's own expressions -- the reference
+    // (and the first version of this file) marches every ray a second time to write them.  Same LDS occupancy caches and exact
+    // cull-grid early-out as the inference marcher: most rays of a training batch miss the object and stop here at once.
+    __shared__ uint4 s_cull4[FAST ? 256 : 1];
+    __shared__ unsigned long long s_fine[FAST ? kFineCacheCells : 1];
+    OccCache oc;
+    occ_cache_load<FAST>(cull, grid, s_cull4, s_fine, oc);
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
     if (n >= N) return;
     MarcherT<FAST> m;
     m.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid);
+    m.fine = oc.fine; m.fx0 = oc.fx0; m.fy0 = oc.fy0; m.fz0 = oc.fz0; m.fnx = oc.fnx; m.fny = oc.fny; m.fnz = oc.fnz;
     const float far = fars[n];
     float t = nears[n];
     t += m.step_size(t) * noises[n];
     uint32_t num_steps = 0;
     float x, y, z, dt;
-    while (t < far && num_steps < max_steps) {
-        if (m.probe(t, x, y, z, dt)) { num_steps++; t += dt; }
+    bool go = t < far;
+    float t_end = far;
+    if (FAST && oc.s_cull && go)
+        go = ray_may_hit(oc.s_cull, m.ox, m.oy, m.oz, m.dx, m.dy, m.dz, t, far, t_end, oc.fx0, oc.fy0, oc.fz0, oc.fnx, oc.fny, oc.fnz);
+    float *ts = sample_t + (size_t)n * max_steps;
+    while (go && t < far && t < t_end && num_steps < max_steps) {
+        if (m.probe(t, x, y, z, dt, oc.s_cull)) {
+            ts[num_steps] = t;
+            num_steps++;
+            t += dt;
+        }
     }
     num_steps_out[n] = num_steps;
 }
@@ -453,40 +507,41 @@ __global__ void k_march_train_finish(int32_t *__restrict__ counter, const uint32
     }
 }
 
+// Emit pass: one wave per ray, one lane per sample.  From the recorded t of a sample the marcher's own expressions give its
+// position (clamp(o + t d)), its step dt = step_size(t) and the parameter after it, t + dt; delta[1] is the difference of two
+// consecutive "after" parameters (the first one against the perturbed start) -- bit for bit what the sequential loop wrote
+// (raymarching.cu:427-479), but coalesced and without marching again.
 template <bool FAST>
-__global__ void __launch_bounds__(256) k_march_train_write(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                                                           const uint8_t *__restrict__ grid, float bound, float dt_gamma,
-                                                           uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
-                                                           const float *__restrict__ nears, const float *__restrict__ fars,
-                                                           const float *__restrict__ noises, const int32_t *__restrict__ rays,
-                                                           const int32_t *__restrict__ counter, float *__restrict__ xyzs,
-                                                           float *__restrict__ dirs, float *__restrict__ deltas) {
-    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+__global__ void __launch_bounds__(256) k_march_train_emit(const float *__restrict__ rays_o, const float *__restrict__ rays_d, float bound,
+                                                          float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                                          const float *__restrict__ nears, const float *__restrict__ noises,
+                                                          const int32_t *__restrict__ rays, const int32_t *__restrict__ counter,
+                                                          const float *__restrict__ sample_t, float *__restrict__ xyzs,
+                                                          float *__restrict__ dirs, float *__restrict__ deltas) {
+    const uint32_t n = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (n >= N) return;
     const uint32_t ray_base = (uint32_t)counter[1];  // not yet bumped: k_march_train_finish runs after this kernel
     const uint32_t point_index = (uint32_t)rays[(size_t)(ray_base + n) * 3 + 1];
     const uint32_t num_steps = (uint32_t)rays[(size_t)(ray_base + n) * 3 + 2];
-    if (num_steps == 0) return;
-    if (point_index + num_steps > M) return;
+    if (num_steps == 0 || point_index + num_steps > M) return;
     MarcherT<FAST> m;
-    m.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid);
-    const float far = fars[n];
-    float t = nears[n];
-    t += m.step_size(t) * noises[n];
-    float *px = xyzs + (size_t)point_index * 3, *pd = dirs + (size_t)point_index * 3, *pl = deltas + (size_t)point_index * 2;
-    uint32_t step = 0;
-    float last_t = t, x, y, z, dt;
-    while (t < far && step < num_steps) {
-        if (m.probe(t, x, y, z, dt)) {
-            px[0] = x; px[1] = y; px[2] = z;
-            pd[0] = m.dx; pd[1] = m.dy; pd[2] = m.dz;
-            t += dt;
-            pl[0] = dt;
-            pl[1] = t - last_t;
-            last_t = t;
-            px += 3; pd += 3; pl += 2;
-            step++;
-        }
+    m.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, nullptr);
+    float t0 = nears[n];
+    t0 += m.step_size(t0) * noises[n];
+    const float *ts = sample_t + (size_t)n * max_steps;
+    for (uint32_t k = lane; k < num_steps; k += 64u) {
+        const float t = ts[k];
+        const float dt = m.step_size(t);
+        const float after = t + dt;
+        float last = t0;
+        if (k > 0) { const float tp = ts[k - 1]; last = tp + m.step_size(tp); }
+        const size_t p = (size_t)point_index + k;
+        xyzs[p * 3] = clampf_(m.ox + t * m.dx, -bound, bound);
+        xyzs[p * 3 + 1] = clampf_(m.oy + t * m.dy, -bound, bound);
+        xyzs[p * 3 + 2] = clampf_(m.oz + t * m.dz, -bound, bound);
+        dirs[p * 3] = m.dx; dirs[p * 3 + 1] = m.dy; dirs[p * 3 + 2] = m.dz;
+        deltas[p * 2] = dt;
+        deltas[p * 2 + 1] = after - last;
     }
 }
 
@@ -562,40 +617,6 @@ __global__ void __launch_bounds__(256) k_composite_train_bwd(const float *__rest
 //   * cull: exact early-out for rays that cannot produce a sample (see ray_may_hit);
 //   * live_idx / live_count: the slots that received a sample are appended (one atomicAdd per wave, ballot-free prefix
 //     via wave shuffles) to a compact list so that the field network is evaluated on samples, not on padded slots.
-// LDS-resident occupancy caches of the marching kernels (FAST configuration with a cull grid only)
-struct OccCache {
-    const uint32_t *s_cull = nullptr;            // 32^3 mark bits
-    const unsigned long long *fine = nullptr;    // fine bits of the marked bounding box (one word = 4x4x4 voxels)
-    int fx0 = 0, fy0 = 0, fz0 = 0, fnx = 0, fny = 0, fnz = 0;   // bounding box of the marked cull cells (origin, extent)
-};
-
-// Cooperative load by a 256-thread workgroup; contains a barrier, so every thread of the workgroup must call it.
-template <bool FAST>
-__device__ __forceinline__ void occ_cache_load(const uint32_t *__restrict__ cull, const uint8_t *__restrict__ grid, uint4 *s_cull4,
-                                               unsigned long long *s_fine, OccCache &oc) {
-    if constexpr (FAST) {
-        if (cull) {  // kernel-uniform
-            s_cull4[threadIdx.x] = reinterpret_cast<const uint4 *>(cull)[threadIdx.x];
-            const int *meta = reinterpret_cast<const int *>(cull + kCullWords);
-            oc.fx0 = meta[0]; oc.fy0 = meta[1]; oc.fz0 = meta[2];
-            oc.fnx = meta[3] - oc.fx0 + 1; oc.fny = meta[4] - oc.fy0 + 1;
-            const int fnz = meta[5] - oc.fz0 + 1;
-            oc.fnz = fnz;
-            if (oc.fnx > 0 && oc.fny > 0 && fnz > 0 && (uint32_t)(oc.fnx * oc.fny * fnz) <= kFineCacheCells) {
-                const unsigned long long *__restrict__ blocks = reinterpret_cast<const unsigned long long *>(grid);
-                const int cells = oc.fnx * oc.fny * fnz;
-                for (int i = (int)threadIdx.x; i < cells; i += 256) {
-                    const int cx = oc.fx0 + i % oc.fnx, cy = oc.fy0 + (i / oc.fnx) % oc.fny, cz = oc.fz0 + i / (oc.fnx * oc.fny);
-                    s_fine[i] = blocks[morton3D_8bit((uint32_t)cx, (uint32_t)cy, (uint32_t)cz)];
-                }
-                oc.fine = s_fine;
-            }
-            __syncthreads();
-            oc.s_cull = reinterpret_cast<const uint32_t *>(s_cull4);
-        }
-    }
-}
-
 // Marches one ray from parameter t for up to n_step samples into its slots (the loop of raymarching.cu:750-804), zero-fills
 // the unused slots and returns the number of samples written.
 // tend (may be null): this ray's cached cull result.  The bound t_end found by ray_may_hit -- beyond it the ray meets no
@@ -1253,9 +1274,13 @@ int sdn_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *b
     return sdn_launch_status();
 }
 
-uint64_t sdn_march_rays_train_scratch_bytes(uint32_t N) {
-    // num_steps[N] + block_totals[ceil(N/1024)] + base_out[2]
-    return ((uint64_t)N + sdn_div_up(N, kScanBlock) + 2u) * sizeof(uint32_t);
+static uint64_t train_scratch_words(uint32_t N) { return (uint64_t)N + sdn_div_up(N, kScanBlock) + 2u; }   // num_steps, block totals, bases
+
+uint64_t sdn_march_rays_train_scratch_bytes(uint32_t N, uint32_t max_steps) {
+    // scan workspace | cull grid of the time slice | t of every sample [N, max_steps]
+    const uint64_t head = (train_scratch_words(N) * sizeof(uint32_t) + 15u) & ~(uint64_t)15u;
+    const uint64_t cull = ((uint64_t)(kCullWords + 8u) * sizeof(uint32_t) + 15u) & ~(uint64_t)15u;
+    return head + cull + (uint64_t)N * max_steps * sizeof(float);
 }
 
 int sdn_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
@@ -1265,25 +1290,34 @@ int sdn_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
     if (N == 0) return 0;
     if (!rays_o || !rays_d || !grid || !nears || !fars || !xyzs || !dirs || !deltas || !rays || !counter || !noises || !scratch)
         return SDN_E_BADARG;
-    if (C == 0 || C > 16 || H == 0 || max_steps == 0) return SDN_E_BADARG;
+    if (C == 0 || C > 16 || H == 0 || max_steps == 0 || ((uintptr_t)scratch & 15u)) return SDN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     uint32_t *num_steps = (uint32_t *)scratch;
     const uint32_t nb = sdn_div_up(N, kScanBlock);
     uint32_t *block_totals = num_steps + N;
     uint32_t *base_out = block_totals + nb;
+    const uint64_t head = (train_scratch_words(N) * sizeof(uint32_t) + 15u) & ~(uint64_t)15u;
+    const uint64_t cull_bytes = ((uint64_t)(kCullWords + 8u) * sizeof(uint32_t) + 15u) & ~(uint64_t)15u;
+    uint32_t *cull = (uint32_t *)((unsigned char *)scratch + head);
+    float *sample_t = (float *)((unsigned char *)scratch + head + cull_bytes);
     const bool fast = fast_config(bound, C, H);
+    const bool use_cull = fast && H == 128;
+    if (use_cull) {
+        int rc = sdn_int::build_cull(grid, cull, st);
+        if (rc) return rc;
+    }
     if (fast) hipLaunchKernelGGL(k_march_train_count<true>, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
-                                 max_steps, N, C, H, nears, fars, noises, num_steps);
+                                 max_steps, N, C, H, nears, fars, noises, num_steps, use_cull ? (const uint32_t *)cull : nullptr, sample_t);
     else hipLaunchKernelGGL(k_march_train_count<false>, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
-                            max_steps, N, C, H, nears, fars, noises, num_steps);
+                            max_steps, N, C, H, nears, fars, noises, num_steps, (const uint32_t *)nullptr, sample_t);
     hipLaunchKernelGGL(k_scan_block_totals, dim3(nb), dim3(kScanBlock), 0, st, num_steps, N, block_totals);
     // The reference writes ray records at rays[atomicAdd(counter+1, 1)] and points at atomicAdd(counter, n):
     // both bases are read on the device from the counter the caller hands in (zeroed by dnerf/renderer.py:291-292).
     hipLaunchKernelGGL(k_march_train_offsets, dim3(nb), dim3(kScanBlock), 0, st, num_steps, N, block_totals, rays, counter, base_out);
-    if (fast) hipLaunchKernelGGL(k_march_train_write<true>, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
-                                 max_steps, N, C, H, M, nears, fars, noises, rays, counter, xyzs, dirs, deltas);
-    else hipLaunchKernelGGL(k_march_train_write<false>, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
-                            max_steps, N, C, H, M, nears, fars, noises, rays, counter, xyzs, dirs, deltas);
+    if (fast) hipLaunchKernelGGL(k_march_train_emit<true>, dim3(sdn_div_up(N, 4u)), dim3(256), 0, st, rays_o, rays_d, bound, dt_gamma, max_steps, N, C, H, M,
+                                 nears, noises, rays, counter, sample_t, xyzs, dirs, deltas);
+    else hipLaunchKernelGGL(k_march_train_emit<false>, dim3(sdn_div_up(N, 4u)), dim3(256), 0, st, rays_o, rays_d, bound, dt_gamma, max_steps, N, C, H, M,
+                            nears, noises, rays, counter, sample_t, xyzs, dirs, deltas);
     hipLaunchKernelGGL(k_march_train_finish, dim3(1), dim3(64), 0, st, counter, base_out, N);
     return sdn_launch_status();
 }

@@ -139,7 +139,7 @@ class _march_rays_train(Function):
         if step_counter is None:
             step_counter = torch.zeros(2, dtype=_i32, device=dev)
         noises = torch.rand(N, dtype=_f32, device=dev) if perturb else torch.zeros(N, dtype=_f32, device=dev)
-        scratch = torch.empty(int(_lib.sdn_march_rays_train_scratch_bytes(N)), dtype=torch.uint8, device=dev)
+        scratch = torch.empty(int(_lib.sdn_march_rays_train_scratch_bytes(N, int(max_steps))), dtype=torch.uint8, device=dev)
         _check(_lib.sdn_march_rays_train(_ptr(rays_o, _f32, "rays_o"), _ptr(rays_d, _f32, "rays_d"),
                                          _ptr(density_bitfield, torch.uint8, "density_bitfield"), float(bound), float(dt_gamma),
                                          int(max_steps), N, int(C), int(H), M, _ptr(nears.contiguous(), _f32, "nears"),

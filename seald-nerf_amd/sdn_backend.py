@@ -78,7 +78,7 @@ PROTOTYPES_U32 = {
     "sdn_cull_grid_bytes": [],
 }
 PROTOTYPES_U64 = {
-    "sdn_march_rays_train_scratch_bytes": [_u32],
+    "sdn_march_rays_train_scratch_bytes": [_u32, _u32],
     "sdn_compact_alive_scratch_bytes": [_u32],
     "sdn_ffmlp_scratch_bytes": [_u32, _u32, _u32, _u32, _u32],
 }
