@@ -25,81 +25,77 @@ def _scratch(B, input_dim, output_dim, hidden_dim, num_layers, device):
 
 
 class _ffmlp_forward(Function):
+    """One launch per direction: `sdn_ffmlp_forward` (keeps the hidden post-activations) or `sdn_ffmlp_inference`, and
+    `sdn_ffmlp_backward` (activation-gradient chain + split-K weight gradients).  Argument order of `.apply` is the reference's:
+    (inputs, weights, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, inference, calc_grad_inputs)."""
+
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.half)
     def forward(ctx, inputs, weights, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
                 inference=False, calc_grad_inputs=False):
-        """ffmlp.py:17-49.  inputs [B, input_dim] f16, weights flat f16 -> outputs [B, output_dim (16)] f16."""
-        inputs = _dev(inputs).contiguous()
-        weights = _dev(weights).contiguous()
-        B = inputs.shape[0]
-        outputs = torch.empty(B, output_dim, device=inputs.device, dtype=inputs.dtype)
-        scratch = _scratch(B, input_dim, output_dim, hidden_dim, num_layers, inputs.device)
-        if not inference:
-            forward_buffer = torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
-            with _timed("ffmlp_forward", B):
-                _check(_lib.sdn_ffmlp_forward(_ptr(inputs, torch.half, "inputs"), _ptr(weights, torch.half, "weights"), B, input_dim,
-                                              output_dim, hidden_dim, num_layers, activation, output_activation,
-                                              _ptr(forward_buffer), _ptr(outputs), _ptr(scratch), _stream()), "ffmlp_forward")
-            ctx.save_for_backward(inputs, weights, outputs, forward_buffer)
-            ctx.dims = (input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs)
-        else:
-            with _timed("ffmlp_inference", B):
-                _check(_lib.sdn_ffmlp_inference(_ptr(inputs, torch.half, "inputs"), _ptr(weights, torch.half, "weights"), B, input_dim,
-                                                output_dim, hidden_dim, num_layers, activation, output_activation,
-                                                _ptr(outputs), _ptr(scratch), _stream()), "ffmlp_inference")
-        return outputs
+        x, w = _dev(inputs).contiguous(), _dev(weights).contiguous()
+        rows = x.shape[0]
+        geom = (int(input_dim), int(output_dim), int(hidden_dim), int(num_layers))
+        y = x.new_empty((rows, geom[1]))
+        work = _scratch(rows, *geom, x.device)
+        common = (_ptr(x, torch.half, "inputs"), _ptr(w, torch.half, "weights"), rows, *geom, int(activation), int(output_activation))
+        if inference:
+            with _timed("ffmlp_inference", rows):
+                _check(_lib.sdn_ffmlp_inference(*common, _ptr(y), _ptr(work), _stream()), "ffmlp_inference")
+            return y
+        hidden = x.new_empty((geom[3], rows, geom[2]))        # post-activations of every hidden layer, for backward
+        with _timed("ffmlp_forward", rows):
+            _check(_lib.sdn_ffmlp_forward(*common, _ptr(hidden), _ptr(y), _ptr(work), _stream()), "ffmlp_forward")
+        ctx.save_for_backward(x, w, y, hidden)
+        ctx.dims = geom + (int(activation), int(output_activation), bool(calc_grad_inputs))
+        return y
 
     @staticmethod
     @custom_bwd(device_type="cuda")
     def backward(ctx, grad):
-        """ffmlp.py:51-81.  grad [B, output_dim] -> (grad_inputs | None, grad_weights)."""
-        grad = grad.contiguous()
-        B = grad.shape[0]
-        inputs, weights, outputs, forward_buffer = ctx.saved_tensors
-        input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs = ctx.dims
+        x, w, _, hidden = ctx.saved_tensors
+        input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, want_dx = ctx.dims
         if activation == 2:
             raise NotImplementedError("ffmlp: the sine activation has no backward (needs pre-activations, utils.h:552-556)")
-        grad_inputs = torch.empty_like(inputs) if calc_grad_inputs else None
-        grad_weights = torch.empty_like(weights)
-        backward_buffer = torch.empty(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
-        scratch = _scratch(B, input_dim, output_dim, hidden_dim, num_layers, grad.device)
-        with _timed("ffmlp_backward", B):
-            _check(_lib.sdn_ffmlp_backward(_ptr(grad, torch.half, "grad"), _ptr(inputs), _ptr(weights), _ptr(forward_buffer), B, input_dim,
-                                           output_dim, hidden_dim, num_layers, activation, output_activation, int(bool(calc_grad_inputs)),
-                                           _ptr(backward_buffer), _ptr(grad_inputs), _ptr(grad_weights), _ptr(scratch), _stream()),
-                   "ffmlp_backward")
-        return grad_inputs, grad_weights, None, None, None, None, None, None, None, None
+        g = grad.contiguous()
+        rows = g.shape[0]
+        dx = torch.empty_like(x) if want_dx else None
+        dw = torch.empty_like(w)
+        pre_grads = g.new_empty((num_layers, rows, hidden_dim))
+        work = _scratch(rows, input_dim, output_dim, hidden_dim, num_layers, g.device)
+        with _timed("ffmlp_backward", rows):
+            _check(_lib.sdn_ffmlp_backward(_ptr(g, torch.half, "grad"), _ptr(x), _ptr(w), _ptr(hidden), rows, input_dim, output_dim, hidden_dim,
+                                           num_layers, activation, output_activation, int(want_dx), _ptr(pre_grads), _ptr(dx), _ptr(dw),
+                                           _ptr(work), _stream()), "ffmlp_backward")
+        return (dx, dw) + (None,) * 8
 
 
 ffmlp_forward = _ffmlp_forward.apply
 
+_ACTIVATIONS = ("relu", "exponential", "sine", "sigmoid", "squareplus", "softplus")
+
 
 def convert_activation(act):
-    """ffmlp.py:87-95."""
-    return {"relu": 0, "exponential": 1, "sine": 2, "sigmoid": 3, "squareplus": 4, "softplus": 5}.get(act, 6)
+    """Activation name -> the integer code of the kernels (ffmlp.py:87-95); anything else means 'none' (6)."""
+    return _ACTIVATIONS.index(act) if act in _ACTIVATIONS else 6
 
 
 class FFMLP(nn.Module):
-    """ffmlp.py:98-168."""
+    """Bias-free fp16 MLP  input_dim -> hidden_dim x num_layers -> output_dim (<= 16, padded to 16 inside) with ONE flat parameter
+    `.weights` laid out [hidden, in] ++ (num_layers - 1) x [hidden, hidden] ++ [16, hidden] (ffmlp.py:98-168)."""
 
     def __init__(self, input_dim, output_dim, hidden_dim, num_layers, activation='relu'):
         super().__init__()
-        self.input_dim = input_dim
-        self.output_dim = output_dim
-        self.hidden_dim = hidden_dim
-        self.num_layers = num_layers
-        self.activation = convert_activation(activation)
-        self.output_activation = convert_activation('none')  # not supported by the reference either (:108)
-        self.tensorcore_width = 16
-
         assert hidden_dim in [16, 32, 64, 128, 256], f"FFMLP only support hidden_dim in [16, 32, 64, 128, 256], but got {hidden_dim}"
         assert input_dim > 0 and input_dim % 16 == 0, f"FFMLP input_dim should be 16 * m (m  > 0), but got {input_dim}"
         assert output_dim <= 16, f"FFMLP current only supports output dim <= 16, but got {output_dim}"
         assert num_layers >= 2, f"FFMLP num_layers should be larger than 2 (3 matmuls), but got {num_layers}"
-
-        self.padded_output_dim = int(math.ceil(output_dim / 16)) * 16
-        self.num_parameters = hidden_dim * (input_dim + hidden_dim * (num_layers - 1) + self.padded_output_dim)
+        self.input_dim, self.output_dim, self.hidden_dim, self.num_layers = input_dim, output_dim, hidden_dim, num_layers
+        self.activation = convert_activation(activation)
+        self.output_activation = convert_activation('none')   # the reference supports nothing else either (:108)
+        self.tensorcore_width = 16
+        self.padded_output_dim = 16 * -(-output_dim // 16)
+        self.num_parameters = hidden_dim * (input_dim + (num_layers - 1) * hidden_dim + self.padded_output_dim)
         self.weights = nn.Parameter(torch.zeros(self.num_parameters))
         self.reset_parameters()
 
@@ -111,18 +107,17 @@ class FFMLP(nn.Module):
                 f"num_layers={self.num_layers} activation={self.activation}")
 
     def reset_parameters(self):
+        """Fixed-seed U(-sqrt(3/hidden), +sqrt(3/hidden)), as the reference (:138-141)."""
         torch.manual_seed(42)
-        std = math.sqrt(3 / self.hidden_dim)
-        self.weights.data.uniform_(-std, std)
+        bound = math.sqrt(3 / self.hidden_dim)
+        self.weights.data.uniform_(-bound, bound)
 
     def forward(self, inputs):
-        """inputs [B, input_dim] -> [B, output_dim]  (:147-168, including its always-positive batch padding)."""
-        B, C = inputs.shape
-        pad = 128 - (B % 128)
-        if pad > 0:
-            inputs = torch.cat([inputs, torch.zeros(pad, C, dtype=inputs.dtype, device=inputs.device)], dim=0)
-        outputs = ffmlp_forward(inputs, self.weights, self.input_dim, self.padded_output_dim, self.hidden_dim, self.num_layers,
-                                self.activation, self.output_activation, not self.training, inputs.requires_grad)
-        if B != outputs.shape[0] or self.padded_output_dim != self.output_dim:
-            outputs = outputs[:B, :self.output_dim]
-        return outputs
+        """[B, input_dim] -> [B, output_dim].  The batch is padded with 128 - B % 128 zero rows like the reference does (:154-157,
+        always at least one: kept so that saved shapes match), though the kernels take any batch."""
+        rows, cols = inputs.shape
+        filler = inputs.new_zeros((128 - rows % 128, cols))
+        padded = torch.cat([inputs, filler], dim=0)
+        out = ffmlp_forward(padded, self.weights, self.input_dim, self.padded_output_dim, self.hidden_dim, self.num_layers,
+                            self.activation, self.output_activation, not self.training, padded.requires_grad)
+        return out[:rows, :self.output_dim]
