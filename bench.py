@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--groups", type=int, default=1, help="device loop only: render the frame as G interleaved ray groups on G streams")
     ap.add_argument("--mode", default="render", choices=["render", "train", "seald"],
                     help="render: the headline 800x800 inference frame; train: one dnerf training step on 4096 rays (BASELINE config 3)")
+    ap.add_argument("--scene", default="jumpingjacks", choices=["jumpingjacks", "lego"],
+                    help="synthetic occupancy: the jumpingjacks-like figure (headline, BASELINE configs 1-4) or the lego-like box (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-side", type=int, default=96, help="side of the CPU-baseline sample image")
     return ap.parse_args()
@@ -192,7 +194,7 @@ def main():
     from dnerf_amd import fused
 
     fp16 = not args.fp32
-    sc = build_scene(H=args.size, W=args.size, device=dev, seed=0)
+    sc = build_scene(H=args.size, W=args.size, device=dev, seed=0, kind=args.scene)
     n_total = sc.rays_o.shape[0]
     if world > 1:
         from dnerf_amd.dist import shard_rays, FrameGather
@@ -342,7 +344,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f16" if fp16 else "f32", "data": "synthetic",
-        "config": {"workload": f"dnerf jumpingjacks-like {args.size}x{args.size} full-frame inference render, "
+        "config": {"workload": f"dnerf {args.scene}-like {args.size}x{args.size} full-frame inference render, "
                                f"{'-O (fp16 field network, fp16 grid table)' if fp16 else 'fp32'}, 1 timestep (t=0.5), "
                                f"T_thresh 1e-2, max_steps 1024, dt_gamma 0",
                    "rays": n_total, "sampled_points_per_frame": n_samples, "loop_iterations": n_iters,
