@@ -649,13 +649,14 @@ class PipelinedDeviceLoop:
     parts of one frame (marching chains, tail iterations, launch gaps) run under the throughput-bound field kernels of another.
     Every frame is the one `DeviceLoop.render` produces, bit for bit; what changes is frames per second."""
 
-    def __init__(self, model, field, N, device, overlap_div=1, contexts=2, **kw):
+    def __init__(self, model, field, N, device, overlap_div=1, contexts=2, mailbox=True, **kw):
         import ctypes
         from sdn_backend import SdnRenderCtx, HostMailbox
         self.N, self.device, self.overlap_div, self.K = N, device, int(overlap_div), int(contexts)
-        self.loops = [DeviceLoop(model, field, N, device, **kw) for _ in range(self.K)]
+        self.loops = [DeviceLoop(model, field, N, device, mailbox=mailbox, **kw) for _ in range(self.K)]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.K)]
-        self.host_state = HostMailbox(self.K)
+        # mailbox=False: ordinary pinned memory -> the driver's event + side-stream copy read-back (see DeviceLoop)
+        self.host_state = HostMailbox(self.K) if mailbox else torch.zeros(self.K, 8, dtype=torch.int32).pin_memory()
         self._ctxs = (ctypes.POINTER(SdnRenderCtx) * self.K)(*[ctypes.pointer(lp.ctx) for lp in self.loops])
         self._fixed = None
 

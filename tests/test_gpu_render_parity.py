@@ -311,8 +311,9 @@ def test_pipelined_frames_equal_one_at_a_time(small_scene):
     for ro, rd in cams:
         o = one.render(ro, rd, sc.time)
         ref.append((o["image"].clone(), o["depth"].clone(), len(o["trace"])))
-    for div, K in ((1, 2), (8, 2), (1 << 20, 2), (1, 3)):   # next frame at once / in the tail / only when the previous one is over; 3 in flight
-        pl = PipelinedDeviceLoop(sc.model, f, N, dev, overlap_div=div, contexts=K)
+    # next frame at once / in the tail / only when the previous one is over; 3 in flight; event + copy read-back instead of the mailbox
+    for div, K, mail in ((1, 2, True), (8, 2, True), (1 << 20, 2, True), (1, 3, True), (1, 2, False)):
+        pl = PipelinedDeviceLoop(sc.model, f, N, dev, overlap_div=div, contexts=K, mailbox=mail)
         outs = [(torch.empty(N, 3, device=dev), torch.empty(N, device=dev)) for _ in cams]
         _, iters = pl.render_frames([c[0] for c in cams], [c[1] for c in cams], sc.time, outputs=outs)
         torch.cuda.synchronize()
