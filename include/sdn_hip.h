@@ -202,6 +202,30 @@ int sdn_field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *
                           int zero_deform, float *sigmas, float *rgbs, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * density-grid maintenance  (reference: NeRFRenderer.update_extra_state, dnerf/renderer.py:453-555; the network queries of
+ * :470-497 / :503-533, the EMA of :536-538, the mean + packbits of :539-545).  No host synchronisation in any of the three.
+ * ------------------------------------------------------------------------- */
+/* tmp_slice[cell] = density_scale * sigma(jittered centre of `cell`, t) for one time slice and one cascade, through the fused
+ * field network (weights / bias0 / table / offsets_host / S / H / bound / zero_deform as for sdn_field_forward_f16; bias0 carries
+ * the -- perturbed -- time).  cells [n] Morton indices with the live count on the device (cell_count), or both NULL = the cells
+ * 0..n-1.  Point of a cell, in the reference's fp32 operation order (:480-490):
+ *   (2 * coord * (1 / (grid_size - 1)) - 1) * (cas_bound - cas_bound / grid_size) + (r * 2 - 1) * cas_bound / grid_size
+ * (the division by the host scalar grid_size - 1 is the reciprocal multiplication torch performs for `tensor / scalar` on the device)
+ * with r = noise[list position, dim] (uniform [0,1), what torch.rand_like supplies there) or, noise == NULL, a counter-based
+ * generator on `seed`.  A cell listed more than once keeps one of its values (as tmp_grid[indices] = sigmas does). */
+int sdn_density_query_cells_f16(const int32_t *cells, const uint32_t *cell_count, uint32_t n, const float *noise, uint32_t seed,
+                                uint32_t grid_size, float cas_bound, const void *weights, const float *bias0, const void *table,
+                                const int32_t *offsets_host, float S, uint32_t H, float bound, float density_scale, int zero_deform,
+                                float *tmp_slice, void *stream);
+/* :536-538  density = max(density * decay, tmp) where density >= 0 and tmp >= 0, over n cells (n % 4 == 0, 16-byte aligned);
+ * *sum (device, fp64, zeroed by the caller before the first slice) += sum of clamp(density, 0) after the update. */
+int sdn_density_grid_ema(float *density_grid, const float *tmp_grid, uint64_t n, float decay, double *sum, void *stream);
+/* :539-545  mean = *sum / n; threshold = min(mean, density_thresh); bitfield bit (i % 8) of byte i / 8 = density[i] > threshold
+ * (raymarching.cu:268-289) for all n cells of all slices at once (n % 8 == 0).  mean_out (device [2], or NULL) = {mean, threshold}. */
+int sdn_density_grid_pack(const float *density_grid, uint64_t n, const double *sum, float density_thresh, float *mean_out,
+                          uint8_t *bitfield, void *stream);
+
+/* ---------------------------------------------------------------------------
  * ffmlp: fully fused bias-free MLP on fp16  (reference: ffmlp/src/ffmlp.h:8-14, ffmlp/src/ffmlp.cu:630-894,
  * Python wrapper ffmlp/ffmlp.py:15-168).  Layout as in the reference: inputs [B, input_dim], outputs [B, 16],
  * forward_buffer / backward_buffer [num_layers, B, hidden_dim], all fp16 and point-major; weights flat fp16,

@@ -86,7 +86,33 @@ struct FieldArgs {
     float bound;
     float density_scale;
     int zero_deform;          // t == 0: canonical frame (dnerf/network.py:140-141)
+    // density-grid query (CELLS variant): the points are jittered centres of occupancy-grid cells, built in the kernel
+    const float *cell_noise;  // [count,3] uniform [0,1) by list position, or nullptr = counter-based generator on cell_seed
+    uint32_t cell_seed;
+    float cell_inv;           // 1 / (grid_size - 1) in fp32: torch divides a tensor by a host scalar as a multiplication by its reciprocal
+    float cell_span;          // bound_cas - half_grid   (dnerf/renderer.py:484-488)
+    float cell_half;          // half_grid = bound_cas / grid_size
 };
+
+// Morton code -> one coordinate (bits 0, 3, 6, ...): raymarching.cu:282-289
+__device__ __forceinline__ uint32_t compact_bits3(uint32_t x) {
+    x &= 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    return (x | (x >> 16)) & 0x0000ffffu;
+}
+
+// counter-based uniform [0,1): PCG output permutation of (seed, counter); 24 random mantissa bits
+__device__ __forceinline__ float cell_uniform(uint32_t seed, uint32_t counter) {
+    uint32_t v = (counter ^ seed) * 747796405u + 2891336453u;
+    v = ((v >> ((v >> 28u) + 4u)) ^ v) * 277803737u;
+    v = (v >> 22u) ^ v;
+    v = (v ^ seed) * 747796405u + 2891336453u;
+    v = ((v >> ((v >> 28u) + 4u)) ^ v) * 277803737u;
+    v = (v >> 22u) ^ v;
+    return (float)(v >> 8) * (1.0f / 16777216.0f);
+}
 
 __device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
@@ -187,7 +213,9 @@ __device__ __forceinline__ half8 lds_frag(const unsigned char *buf, int blk, uin
 //   <2, 8>: the latency variant for launches of at most one workgroup per CU (the tail iterations of a frame, every iteration
 //           of a ray-sharded frame): with two waves per SIMD nothing hides an LDS round trip per MFMA, so a whole k-step of
 //           fragments is read ahead (256-VGPR budget).
-template <int OCC, int LA>
+// CELLS: the density-grid query of update_extra_state (dnerf/renderer.py:453-555): slot p is a Morton cell index, the point is
+//   that cell's jittered centre, only sigma is evaluated and it is stored at sigmas[p] (a slice of tmp_grid).
+template <int OCC, int LA, bool CELLS>
 __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, TiledLevels lv) {
     constexpr int kGridBatch = OCC >= 4 ? 4 : 8;   // grid levels (per lane-half) whose gathers are in flight together (register budget)
     __shared__ __attribute__((aligned(16))) unsigned char s_w[2][kStageBytes];
@@ -219,8 +247,22 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     stage_load(P.weights + (size_t)kBlkD0 * 1024, s_w[0], 16 * 1024, wave, lane);
     stage_load(P.weights + (size_t)kBlkD1 * 1024, s_w[1], kStageBytes, wave, lane);
 
-    const float x0 = P.xyzs[(size_t)p * 3], x1 = P.xyzs[(size_t)p * 3 + 1], x2 = P.xyzs[(size_t)p * 3 + 2];
-    const float d0 = P.dirs[(size_t)p * 3], d1 = P.dirs[(size_t)p * 3 + 1], d2 = P.dirs[(size_t)p * 3 + 2];
+    float x0, x1, x2, d0 = 0, d1 = 0, d2 = 0;
+    if constexpr (CELLS) {
+        // dnerf/renderer.py:480-490 (== :517-524), the same fp32 operations in the same order:
+        //   xyzs = 2 * coords / (grid_size - 1) - 1;  cas_xyzs = xyzs * (bound - half_grid);  cas_xyzs += (rand * 2 - 1) * half_grid
+        float xs[3];
+        #pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const float c = (float)compact_bits3(p >> d);
+            const float r = P.cell_noise ? P.cell_noise[(size_t)ii * 3 + d] : cell_uniform(P.cell_seed, ii * 3u + (uint32_t)d);
+            xs[d] = ((2.0f * c) * P.cell_inv - 1.0f) * P.cell_span + (r * 2.0f - 1.0f) * P.cell_half;
+        }
+        x0 = xs[0]; x1 = xs[1]; x2 = xs[2];
+    } else {
+        x0 = P.xyzs[(size_t)p * 3]; x1 = P.xyzs[(size_t)p * 3 + 1]; x2 = P.xyzs[(size_t)p * 3 + 2];
+        d0 = P.dirs[(size_t)p * 3]; d1 = P.dirs[(size_t)p * 3 + 1]; d2 = P.dirs[(size_t)p * 3 + 2];
+    }
 
     // ---------------- deform layer 0: freq features as B fragments ----------------
     // lane-half h owns (freq, dim) pairs 15h .. 15h+14 (sin and cos) plus x0,x1 (h = 0) / x2,pad (h = 1)
@@ -477,6 +519,10 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     const float sigma = P.density_scale * expf(round_h(hv[0]));
 
     SDN_TS();   // 7: sigma
+    if constexpr (CELLS) {
+        if (h == 0 && valid) P.sigmas[p] = sigma;   // duplicates in the list: any one of them wins, as with tmp_grid[indices] = sigmas
+        return;
+    }
     // ---------------- colour net: [SH(16) ++ geo_feat(15)] -> 64 -> 64 -> 3 ----------------
     half8 cf[2], dummy;
     acc_to_frags<false>(hv, cf[0], dummy);  // registers 0..7 of every lane = h[0..15]; column of h[0] is zero in the packed weights
@@ -584,6 +630,7 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
     a.xyzs = xyzs; a.dirs = dirs; a.live_idx = live_idx; a.live_count = live_count; a.state = state; a.M = M;
     a.weights = (const unsigned char *)weights; a.bias0 = bias0; a.table = (const __half *)table;
     a.sigmas = sigmas; a.rgbs = rgbs; a.bound = bound; a.density_scale = density_scale; a.zero_deform = zero_deform;
+    a.cell_noise = nullptr; a.cell_seed = 0; a.cell_inv = a.cell_span = a.cell_half = 0;
     const uint32_t wgs = sdn_div_up(M, (uint32_t)kPointsPerWG);
     static int cus = 0;
     if (cus == 0) {
@@ -594,9 +641,31 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
     // expect_points (0 = unknown): the caller's estimate of the live points when M is only a loose bound of them
     const uint32_t busy = expect_points ? sdn_div_up(expect_points < M ? expect_points : M, (uint32_t)kPointsPerWG) : wgs;
     if (busy <= (uint32_t)cus)
-        hipLaunchKernelGGL((k_field_f16<2, 8>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+        hipLaunchKernelGGL((k_field_f16<2, 8, false>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
     else
-        hipLaunchKernelGGL((k_field_f16<4, 2>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+        hipLaunchKernelGGL((k_field_f16<4, 2, false>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+    return sdn_launch_status();
+}
+
+// sigma * density_scale of jittered occupancy-grid cell centres -> tmp_grid slice (density.hip drives the whole update)
+int field_cells_f16(const int32_t *cells, const uint32_t *cell_count, uint32_t n, const float *noise, uint32_t seed, uint32_t grid_size,
+                    float cas_bound, const void *weights, const float *bias0, const void *table, const int32_t *offsets_host, float S,
+                    uint32_t H, float bound, float density_scale, int zero_deform, float *tmp_slice, hipStream_t st) {
+    TiledLevels lv;
+    int rc = fill_tiled_levels(lv, offsets_host, S, H);
+    if (rc) return rc;
+    FieldArgs a;
+    a.xyzs = nullptr; a.dirs = nullptr; a.live_idx = (const uint32_t *)cells; a.live_count = cell_count; a.state = nullptr; a.M = n;
+    a.weights = (const unsigned char *)weights; a.bias0 = bias0; a.table = (const __half *)table;
+    a.sigmas = tmp_slice; a.rgbs = nullptr; a.bound = bound; a.density_scale = density_scale; a.zero_deform = zero_deform;
+    a.cell_noise = noise; a.cell_seed = seed;
+    const float half_grid = cas_bound / (float)grid_size;
+    a.cell_inv = 1.0f / (float)(grid_size - 1); a.cell_span = cas_bound - half_grid; a.cell_half = half_grid;
+    const uint32_t wgs = sdn_div_up(n, (uint32_t)kPointsPerWG);
+    if (wgs <= 256u)
+        hipLaunchKernelGGL((k_field_f16<2, 8, true>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+    else
+        hipLaunchKernelGGL((k_field_f16<4, 2, true>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
     return sdn_launch_status();
 }
 

@@ -31,4 +31,8 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
                       uint32_t M, const void *weights, const float *bias0, const void *table, const int32_t *offsets_host, float S,
                       uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, uint32_t expect_points, hipStream_t st);
 
+int field_cells_f16(const int32_t *cells, const uint32_t *cell_count, uint32_t n, const float *noise, uint32_t seed, uint32_t grid_size,
+                    float cas_bound, const void *weights, const float *bias0, const void *table, const int32_t *offsets_host, float S,
+                    uint32_t H, float bound, float density_scale, int zero_deform, float *tmp_slice, hipStream_t st);
+
 }  // namespace sdn_int

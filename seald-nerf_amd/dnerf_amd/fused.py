@@ -148,3 +148,107 @@ class FusedField:
                                                         self.density_scale, self.zero_deform, ptr(sigmas), ptr(rgbs), stream()),
                   "field_forward_f16")
         return sigmas, rgbs
+
+
+class DensityGridUpdater:
+    """NeRFRenderer.update_extra_state (dnerf/renderer.py:453-555) on the device: the 64 x 128^3 density queries go through the
+    CELLS variant of the fused field kernel (one launch per time slice and cascade, cell centres built and jittered in the kernel),
+    the EMA / maximum update, the mean and the bitfield are three more kernels, and nothing is read back to the host.
+
+    The partial update (`iter_density` 16..99) draws the same two populations as the reference -- N = H^3 / 4 uniformly random cells
+    plus N uniformly random *occupied* cells, with repetition -- but picks the occupied ones by rank (cumsum + searchsorted) instead
+    of `torch.nonzero`, which would synchronise once per slice.
+    """
+
+    def __init__(self, model, field=None):
+        self.model = model
+        dev = model.density_grid.device
+        self.field = field if field is not None else FusedField(model, model.times[0].reshape(1, 1).to(dev), fp16=True)
+        n = model.grid_size ** 3
+        self.tmp = torch.empty(n, dtype=torch.float32, device=dev)
+        self.sum = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.mean = torch.zeros(2, dtype=torch.float32, device=dev)   # {mean density, threshold used}
+        self.seed = 0x5EA1D
+
+    def refresh(self):
+        """Re-pack the (trained) weights and the fp16 table; call after optimizer steps."""
+        f, enc = self.field, self.model.encoder
+        f.weights.copy_(torch.from_numpy(pack_weights(self.model)))
+        f.table.copy_(enc.embeddings.detach())
+
+    def time_bias(self, times):
+        """[T] (perturbed) times -> bias0 [T,128], the expression of FusedField.set_time for every slice at once."""
+        with torch.no_grad():
+            enc_t = freq_encode(times.reshape(-1, 1).float(), 6, 13)
+            w = self.model.deform_net[0].weight.detach()[:, 63:76]
+            return (enc_t.to(torch.float16).float() @ w.to(torch.float16).float().t()).contiguous()
+
+    def query_cells(self, out, bias0, zero_deform, cas_bound, cells=None, cell_count=None, n=None, noise=None, seed=0):
+        """out[cell] = density_scale * sigma for the listed (or the first n) cells of one slice."""
+        f = self.field
+        if cells is not None:
+            n = cells.shape[0]
+        with sdn_backend.timed("density_query_cells_f16", n):
+            check(sdn_backend.lib.sdn_density_query_cells_f16(ptr(cells, torch.int32, "cells"), ptr(cell_count), n, ptr(noise, torch.float32, "noise"),
+                                                              int(seed) & 0xFFFFFFFF, self.model.grid_size, float(cas_bound), ptr(f.weights),
+                                                              ptr(bias0, torch.float32, "bias0"), ptr(f.table), f.offsets_host.ctypes.data,
+                                                              f.S, f.H, f.bound, f.density_scale, int(zero_deform), ptr(out, torch.float32, "out"),
+                                                              stream()), "density_query_cells_f16")
+        return out
+
+    @torch.no_grad()
+    def partial_cells(self):
+        """[T, C, 2N] int32 cell lists and [T, C] live counts of the partial update (dnerf/renderer.py:503-515), no host sync."""
+        import raymarching
+        m = self.model
+        G, T, C = m.grid_size, m.time_size, m.cascade
+        dev = m.density_grid.device
+        N = G ** 3 // 4
+        coords = torch.randint(0, G, (T * C * N, 3), device=dev, dtype=torch.int32)
+        uniform = raymarching.morton3D(coords).view(T, C, N)
+        ranks = torch.cumsum((m.density_grid > 0).view(T * C, -1), dim=1, dtype=torch.int32)           # rank of every occupied cell
+        total = ranks[:, -1:]                                                                            # [T*C, 1] occupied cells
+        pick = torch.minimum((torch.rand(T * C, N, device=dev) * total).to(torch.int32), (total - 1).clamp(min=0))
+        occupied = torch.searchsorted(ranks, pick, right=True).clamp_(max=G ** 3 - 1).to(torch.int32).view(T, C, N)   # (clamp: slices with no occupied cell)
+        cells = torch.cat([uniform, occupied], dim=2).contiguous()
+        counts = (N + N * (total.view(T, C) > 0)).to(torch.int32).contiguous()                          # no occupied cell: uniform part only
+        return cells, counts
+
+    @torch.no_grad()
+    def update(self, decay=0.95, noise=None, time_noise=None):
+        """One update_extra_state pass (density grid + bitfield).  noise [T, C, n, 3] / time_noise [T, C] uniform [0,1): supply what
+        torch.rand_like would have drawn (tests); default = in-kernel generator / host generator."""
+        m = self.model
+        G, T, C = m.grid_size, m.time_size, m.cascade
+        H3 = G ** 3
+        dev = m.density_grid.device
+        full = m.iter_density < 16
+        partial = (not full) and m.iter_density < 100
+        if time_noise is None:
+            time_noise = torch.rand(T, C)
+        times = m.times.reshape(T, 1).cpu() + (time_noise.cpu().float() * 2 - 1) * (0.5 / m.time_size)     # [T, C] dnerf/renderer.py:486,492
+        bias = self.time_bias(times.reshape(-1).to(dev)).view(T, C, 128)
+        zero = (times == 0).tolist()
+        self.sum.zero_()
+        cells = counts = None
+        if partial:
+            cells, counts = self.partial_cells()
+        self.seed = (self.seed * 1664525 + 1013904223) & 0xFFFFFFFF
+        grid = m.density_grid
+        for t in range(T):
+            for cas in range(C):
+                cas_bound = min(2 ** cas, m.bound)
+                nz = None if noise is None else noise[t, cas]
+                if full:
+                    self.query_cells(self.tmp, bias[t, cas], zero[t][cas], cas_bound, n=H3, noise=nz, seed=self.seed + 64 * t + cas)
+                else:
+                    self.tmp.fill_(-1.0)
+                    if partial:
+                        self.query_cells(self.tmp, bias[t, cas], zero[t][cas], cas_bound, cells=cells[t, cas], cell_count=counts[t, cas:cas + 1],
+                                         noise=nz, seed=self.seed + 64 * t + cas)
+                check(sdn_backend.lib.sdn_density_grid_ema(ptr(grid[t, cas]), ptr(self.tmp), H3, float(decay), ptr(self.sum), stream()),
+                      "density_grid_ema")
+        check(sdn_backend.lib.sdn_density_grid_pack(ptr(grid), grid.numel(), ptr(self.sum), float(m.density_thresh), ptr(self.mean),
+                                                    ptr(m.density_bitfield), stream()), "density_grid_pack")
+        m.iter_density += 1
+        return self.mean

@@ -63,13 +63,31 @@ class NeRFRenderer(nn.Module):
         if cuda_ray:
             self.register_buffer("density_grid", torch.zeros(self.time_size, self.cascade, self.grid_size ** 3))
             self.register_buffer("density_bitfield", torch.zeros(self.time_size, self.cascade * self.grid_size ** 3 // 8, dtype=torch.uint8))
-            self.mean_density = 0
+            self._mean_density, self._mean_density_dev, self._density_updater = 0, None, None
             self.iter_density = 0
             times = ((torch.arange(self.time_size, dtype=torch.float32) + 0.5) / self.time_size).view(-1, 1, 1)
             self.register_buffer("times", times)
             self.register_buffer("step_counter", torch.zeros(16, 2, dtype=torch.int32))
             self.mean_count = 0
             self.local_step = 0
+
+    @property
+    def mean_density(self):
+        """Python float as in the reference; after a native update it is read from the device only when somebody asks."""
+        if getattr(self, "_mean_density_dev", None) is not None:
+            self._mean_density = float(self._mean_density_dev[0])
+            self._mean_density_dev = None
+        return self._mean_density
+
+    @mean_density.setter
+    def mean_density(self, value):
+        self._mean_density, self._mean_density_dev = value, None
+
+    def use_native_density_update(self, field=None):
+        """Route update_extra_state through csrc/density.hip + the fused field kernel (`-O` numerics; dnerf_amd/fused.py)."""
+        from .fused import DensityGridUpdater
+        self._density_updater = DensityGridUpdater(self, field)
+        return self._density_updater
 
     def forward(self, x, d, t):
         raise NotImplementedError()
@@ -215,6 +233,11 @@ class NeRFRenderer(nn.Module):
     def update_extra_state(self, decay=0.95, S=128):
         if not self.cuda_ray:
             return
+        if getattr(self, "_density_updater", None) is not None:
+            self._density_updater.refresh()
+            self._mean_density_dev = self._density_updater.update(decay)
+            self._update_step_counter()
+            return
         dev = self.density_bitfield.device
         tmp_grid = -torch.ones_like(self.density_grid)
         half_time = 0.5 / self.time_size
@@ -259,6 +282,9 @@ class NeRFRenderer(nn.Module):
         density_thresh = min(self.mean_density, self.density_thresh)
         for t_idx in range(self.time_size):
             raymarching.packbits(self.density_grid[t_idx], density_thresh, self.density_bitfield[t_idx])
+        self._update_step_counter()
+
+    def _update_step_counter(self):
         total_step = min(16, self.local_step)
         if total_step > 0:
             self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
