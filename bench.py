@@ -47,7 +47,7 @@ def parse():
                          "0 = strictly one frame at a time)")
     ap.add_argument("--contexts", type=int, default=3, help="--pipeline: loop contexts (frames in flight)")
     ap.add_argument("--groups", type=int, default=1, help="device loop only: render the frame as G interleaved ray groups on G streams")
-    ap.add_argument("--mode", default="render", choices=["render", "train", "seald"],
+    ap.add_argument("--mode", default="render", choices=["render", "train", "seald", "density"],
                     help="render: the headline 800x800 inference frame; train: one dnerf training step on 4096 rays (BASELINE config 3)")
     ap.add_argument("--scene", default="jumpingjacks", choices=["jumpingjacks", "lego"],
                     help="synthetic occupancy: the jumpingjacks-like figure (headline, BASELINE configs 1-4) or the lego-like box (config 5)")
@@ -160,10 +160,66 @@ def seald_mode(args):
                                  "loop": "device", "frames_in_flight": args.contexts}}))
 
 
+def density_mode(args):
+    """The density-grid maintenance pass between training epochs (update_extra_state, dnerf/renderer.py:453-555):
+    64 time slices x 128^3 cells through the density network + EMA + mean + bitfield.  Times the full update (iter_density < 16)
+    and the partial update (16..99) on the device path (csrc/density.hip + the CELLS variant of the fused field kernel, including
+    the per-call weight re-packing) next to the reference-shaped op-by-op pass on the same HIP operators.  One JSON line."""
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    import gc
+    from dnerf_amd.bench_scene import build_scene, build_model
+    sc = build_scene(H=8, W=8, device=dev, seed=0)
+
+    def fresh(native):
+        m = build_model(0, dev)
+        m.load_state_dict(sc.model.state_dict())
+        m.reset_extra_state()
+        if native:
+            m.use_native_density_update()
+        return m
+
+    def timed(m, first_iter, steps):
+        out = []
+        for k in range(steps):
+            m.iter_density = first_iter
+            gc.collect(); gc.disable()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.autocast("cuda", dtype=torch.float16):
+                m.update_extra_state()
+            torch.cuda.synchronize()
+            out.append(time.perf_counter() - t0)
+            gc.enable()
+        return sorted(out)[len(out) // 2]
+
+    nat, ref = fresh(True), fresh(False)
+    cells = nat.time_size * nat.cascade * nat.grid_size ** 3
+    res = {}
+    for name, m, steps in (("native", nat, max(3, args.steps // 4)), ("op_by_op", ref, 3)):
+        timed(m, 0, 1)                                           # warm-up (allocator, first launches)
+        res[name + "_full_ms"] = timed(m, 0, steps) * 1e3
+        res[name + "_partial_ms"] = timed(m, 16, steps) * 1e3
+    t_full = res["native_full_ms"] * 1e-3
+    # dominant kernel: the fused field kernel, sigma branch only: deform MLP + sigma MLP = 2 * (76*128 + 6*128*128 + 128*3 + 32*64 + 64*16) MAC
+    flop = 2.0 * (76 * 128 + 6 * 128 * 128 + 128 * 3 + 32 * 64 + 64 * 16) * cells
+    print(json.dumps({"metric": "density-grid full update (update_extra_state), 64 x 128^3 cells", "value": cells / t_full, "unit": "cells/s",
+                      "ms_per_step": res["native_full_ms"], "higher_is_better": True, "n_gpus": 1, "dtype": "f16", "data": "synthetic",
+                      **{k: round(v, 3) for k, v in res.items()},
+                      "speedup_full": res["op_by_op_full_ms"] / res["native_full_ms"], "speedup_partial": res["op_by_op_partial_ms"] / res["native_partial_ms"],
+                      "whole_pass_mfma": {"achieved": flop / t_full / 1e12, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / t_full / 1e12 / MFMA_F16_PEAK_TFLOPS},
+                      "config": {"workload": "SURVEY 8(f)2: density-grid maintenance", "time_slices": nat.time_size, "grid": nat.grid_size,
+                                 "cells": cells, "partial_cells_per_slice": 2 * (nat.grid_size ** 3 // 4),
+                                 "native": "sdn_density_query_cells_f16 per slice + sdn_density_grid_ema + sdn_density_grid_pack, incl. weight re-pack",
+                                 "op_by_op": "renderer mirror on the HIP operators (the reference's structure)"}}))
+
+
 def main():
     args = parse()
     if args.mode == "train":
         return train_mode(args)
+    if args.mode == "density":
+        return density_mode(args)
     if args.mode == "seald":
         return seald_mode(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))

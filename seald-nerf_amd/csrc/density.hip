@@ -16,23 +16,27 @@ namespace {
 
 constexpr int kEmaBlock = 256;
 
-// dnerf/renderer.py:536-538.  Four cells per thread; block partial sums reduced in fp64, one atomic per block.
+constexpr int kEmaPerThread = 8;   // float4s per thread: few, fat workgroups -- the fp64 atomics on one address serialise (2048 of them cost ~20 us)
+
+// dnerf/renderer.py:536-538.  Block partial sums reduced in fp64, one atomic per block.
 __global__ void __launch_bounds__(kEmaBlock) k_density_ema(float4 *__restrict__ grid, const float4 *__restrict__ tmp, uint32_t n4, float decay,
                                                            double *__restrict__ sum) {
-    const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-    float local = 0.0f;
-    if (i < n4) {
-        float4 g = grid[i];
-        const float4 t = tmp[i];
-        // valid = (grid >= 0) & (tmp >= 0) -- false for NaN on either side, as in the reference's mask
-        if (g.x >= 0 && t.x >= 0) g.x = fmaxf(g.x * decay, t.x);
-        if (g.y >= 0 && t.y >= 0) g.y = fmaxf(g.y * decay, t.y);
-        if (g.z >= 0 && t.z >= 0) g.z = fmaxf(g.z * decay, t.z);
-        if (g.w >= 0 && t.w >= 0) g.w = fmaxf(g.w * decay, t.w);
-        grid[i] = g;
-        local = (fmaxf(g.x, 0.0f) + fmaxf(g.y, 0.0f)) + (fmaxf(g.z, 0.0f) + fmaxf(g.w, 0.0f));
+    double v = 0.0;
+    #pragma unroll
+    for (int k = 0; k < kEmaPerThread; k++) {
+        const uint32_t i = threadIdx.x + (blockIdx.x * kEmaPerThread + k) * kEmaBlock;
+        if (i < n4) {
+            float4 g = grid[i];
+            const float4 t = tmp[i];
+            // valid = (grid >= 0) & (tmp >= 0) -- false for NaN on either side, as in the reference's mask
+            if (g.x >= 0 && t.x >= 0) g.x = fmaxf(g.x * decay, t.x);
+            if (g.y >= 0 && t.y >= 0) g.y = fmaxf(g.y * decay, t.y);
+            if (g.z >= 0 && t.z >= 0) g.z = fmaxf(g.z * decay, t.z);
+            if (g.w >= 0 && t.w >= 0) g.w = fmaxf(g.w * decay, t.w);
+            grid[i] = g;
+            v += (double)((fmaxf(g.x, 0.0f) + fmaxf(g.y, 0.0f)) + (fmaxf(g.z, 0.0f) + fmaxf(g.w, 0.0f)));
+        }
     }
-    double v = (double)local;
     #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     __shared__ double s_part[kEmaBlock / 64];
@@ -95,7 +99,7 @@ int sdn_density_grid_ema(float *density_grid, const float *tmp_grid, uint64_t n,
     if (!density_grid || !tmp_grid || !sum) return SDN_E_BADARG;
     if ((n & 3u) != 0 || (n >> 2) > 0xFFFFFFFFull || (((uintptr_t)density_grid | (uintptr_t)tmp_grid) & 15u) != 0) return SDN_E_BADARG;
     const uint32_t n4 = (uint32_t)(n >> 2);
-    hipLaunchKernelGGL(k_density_ema, dim3(sdn_div_up(n4, (uint32_t)kEmaBlock)), dim3(kEmaBlock), 0, (hipStream_t)stream, (float4 *)density_grid,
+    hipLaunchKernelGGL(k_density_ema, dim3(sdn_div_up(n4, (uint32_t)(kEmaBlock * kEmaPerThread))), dim3(kEmaBlock), 0, (hipStream_t)stream, (float4 *)density_grid,
                        (const float4 *)tmp_grid, n4, decay, sum);
     return sdn_launch_status();
 }

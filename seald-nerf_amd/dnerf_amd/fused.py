@@ -157,7 +157,7 @@ class DensityGridUpdater:
 
     The partial update (`iter_density` 16..99) draws the same two populations as the reference -- N = H^3 / 4 uniformly random cells
     plus N uniformly random *occupied* cells, with repetition -- but picks the occupied ones by rank (cumsum + searchsorted) instead
-    of `torch.nonzero`, which would synchronise once per slice.
+    of `torch.nonzero`, which would synchronise once per slice, and hands the kernel the union sorted by Morton index.
     """
 
     def __init__(self, model, field=None):
@@ -178,7 +178,7 @@ class DensityGridUpdater:
 
     def time_bias(self, times):
         """[T] (perturbed) times -> bias0 [T,128], the expression of FusedField.set_time for every slice at once."""
-        with torch.no_grad():
+        with torch.no_grad(), torch.autocast("cuda", enabled=False):   # (the trainer calls update_extra_state under autocast)
             enc_t = freq_encode(times.reshape(-1, 1).float(), 6, 13)
             w = self.model.deform_net[0].weight.detach()[:, 63:76]
             return (enc_t.to(torch.float16).float() @ w.to(torch.float16).float().t()).contiguous()
@@ -209,8 +209,11 @@ class DensityGridUpdater:
         ranks = torch.cumsum((m.density_grid > 0).view(T * C, -1), dim=1, dtype=torch.int32)           # rank of every occupied cell
         total = ranks[:, -1:]                                                                            # [T*C, 1] occupied cells
         pick = torch.minimum((torch.rand(T * C, N, device=dev) * total).to(torch.int32), (total - 1).clamp(min=0))
-        occupied = torch.searchsorted(ranks, pick, right=True).clamp_(max=G ** 3 - 1).to(torch.int32).view(T, C, N)   # (clamp: slices with no occupied cell)
-        cells = torch.cat([uniform, occupied], dim=2).contiguous()
+        occupied = torch.searchsorted(ranks, pick, right=True).to(torch.int32)
+        occupied = torch.where(total > 0, occupied, 0x7FFFFFFF).view(T, C, N)      # nothing occupied: sentinels, sorted past the live count
+        # Sorted by Morton index: neighbouring lanes then gather neighbouring table rows (measured 0.33 ms instead of 0.64 ms per
+        # slice for the query).  The order of the list carries no meaning in the reference (tmp_grid[indices] = sigmas).
+        cells = torch.sort(torch.cat([uniform, occupied], dim=2), dim=2).values.contiguous()
         counts = (N + N * (total.view(T, C) > 0)).to(torch.int32).contiguous()                          # no occupied cell: uniform part only
         return cells, counts
 

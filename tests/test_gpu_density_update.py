@@ -180,11 +180,15 @@ def test_partial_update_invariants(scene):
     N = m.grid_size ** 3 // 4
     assert cells.shape == (m.time_size, 1, 2 * N) and cells.dtype == torch.int32
     assert int(counts[5, 0]) == N and bool((counts[torch.arange(m.time_size) != 5] == 2 * N).all())
-    t = 9
-    assert bool((before[t, 0][cells[t, 0, N:].long()] > 0).all())          # second half: occupied cells only
-    assert 0 <= int(cells.min()) and int(cells.max()) < m.grid_size ** 3
-    occ_frac = float((cells[t, 0, :N].long() % 3 != 0).float().mean())     # first half: uniform over all cells
-    assert abs(occ_frac - 2 / 3) < 0.01
+    H3 = m.grid_size ** 3
+    for t in (5, 9):
+        live = cells[t, 0, :int(counts[t, 0])].long()
+        assert 0 <= int(live.min()) and int(live.max()) < H3 and bool((live[1:] >= live[:-1]).all())   # valid, sorted by Morton index
+    # N uniform draws over all cells (2/3 of them occupied here) + N draws among the occupied ones
+    live = cells[9, 0].long()
+    assert abs(float((before[9, 0][live] > 0).float().mean()) - (2 / 3 + 1) / 2) < 0.01
+    assert abs(float(live.float().mean()) / H3 - 0.5) < 0.01
+    assert bool((cells[5, 0, N:] == 0x7FFFFFFF).all())                     # nothing occupied in slice 5: sentinels past the live count
     torch.manual_seed(5)                         # same lists inside update()
     mean = up.update(0.95)
     after = m.density_grid
