@@ -51,6 +51,11 @@ def parse():
                     help="render: the headline 800x800 inference frame; train: one dnerf training step on 4096 rays (BASELINE config 3)")
     ap.add_argument("--scene", default="jumpingjacks", choices=["jumpingjacks", "lego"],
                     help="synthetic occupancy: the jumpingjacks-like figure (headline, BASELINE configs 1-4) or the lego-like box (config 5)")
+    ap.add_argument("--train-mlp", default="ffmlp", choices=["ffmlp", "linear"],
+                    help="--mode train: deformation / colour MLPs through the fused-MLP operator (dnerf_amd/network_ff.py) or as the "
+                         "reference's nn.Linear stack under autocast")
+    ap.add_argument("--train-graph", type=int, default=1, help="--mode train with --train-mlp ffmlp: replay the step as one captured HIP "
+                                                                "graph (dnerf_amd/train_graph.py); 0 = launch it from Python")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-side", type=int, default=96, help="side of the CPU-baseline sample image")
     return ap.parse_args()
@@ -65,13 +70,20 @@ def train_mode(args):
     import sdn_backend
     from dnerf_amd.bench_scene import build_scene
     sc = build_scene(H=args.size, W=args.size, device=dev, seed=0)
-    model = sc.model.train()
+    model = sc.model
+    if args.train_mlp == "ffmlp" and not args.fp32:
+        from dnerf_amd.network_ff import NeRFNetworkFF
+        model = NeRFNetworkFF(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1).to(dev)
+        model.load_state_dict(sc.model.state_dict())
+    model.train()
     n_rays = 4096
     g = torch.Generator(device="cpu").manual_seed(0)
     idx = torch.randint(0, sc.rays_o.shape[0], (n_rays,), generator=g).to(dev)
     rays_o, rays_d = sc.rays_o[idx][None].contiguous(), sc.rays_d[idx][None].contiguous()
     target = torch.rand(1, n_rays, 3, generator=torch.Generator(device="cpu").manual_seed(2)).to(dev)
-    opt = torch.optim.Adam(model.get_params(1e-2, 1e-3), betas=(0.9, 0.99), eps=1e-15)
+    graphed = bool(args.train_graph) and type(model).__name__ == "NeRFNetworkFF"
+    # the graph needs the optimizer that takes GradScaler's found_inf on the device (fused + capturable Adam)
+    opt = torch.optim.Adam(model.get_params(1e-2, 1e-3), betas=(0.9, 0.99), eps=1e-15, **({"fused": True, "capturable": True} if graphed else {}))
     scaler = torch.amp.GradScaler("cuda", enabled=not args.fp32)
 
     def step():
@@ -88,6 +100,12 @@ def train_mode(args):
     for _ in range(2):  # first steps: unknown point budget (M = N * max_steps buffers, host read-back), as in the reference
         step()
     model.mean_count = int(model.step_counter[:2, 0].sum().item() / 2)  # what update_extra_state does (dnerf/renderer.py:550-552)
+    if graphed:
+        from dnerf_amd.train_graph import GraphedTrainStep
+        gstep = GraphedTrainStep(model, opt, scaler, n_rays, dev)
+        gstep.load(rays_o, rays_d, target, sc.time)
+        gstep.capture()
+        step = gstep  # noqa: F811  (inputs stay in the graph's buffers: a data loader would copy each batch in, 3 x 48 KiB)
     for _ in range(args.warmup):
         step()
     n_points = int(model.step_counter[(model.local_step - 1) % 16, 0].item())
@@ -109,7 +127,10 @@ def train_mode(args):
                       "value": args.steps / dt, "unit": "steps/s", "points_per_s": n_points * args.steps / dt, "rays_per_s": n_rays * args.steps / dt,
                       "ms_per_step": dt / args.steps * 1e3, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "dtype": "f32" if args.fp32 else "f16",
                       "data": "synthetic", "config": {"workload": "BASELINE config 3", "rays": n_rays, "sampled_points_per_step": n_points,
-                                                      "mean_count": model.mean_count}, "kernel_times": summ}))
+                                                      "mean_count": model.mean_count,
+                                                      "mlps": "deform + colour MLPs on the fused-MLP operator (ffmlp), density MLP hipBLASLt" if type(model).__name__ == "NeRFNetworkFF" else "nn.Linear stack (hipBLASLt GEMMs)",
+                                                      "launch": "one captured HIP graph per step (fused capturable Adam)" if graphed else "eager (Python launches)"},
+                      "kernel_times": summ}))
 
 
 def seald_mode(args):

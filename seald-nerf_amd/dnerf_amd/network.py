@@ -104,14 +104,15 @@ class NeRFNetwork(NeRFRenderer):
         deform = self._deform(x, t)
         if t == 0:  # canonical frame: no deformation (device compare => host sync, as in the reference :140)
             deform = torch.zeros_like(x)
-        sigma, geo_feat = self._sigma(x + deform)
+        # (explicit promotion: torch's mixed fp32 + fp16 add kernel takes 73 us for these 27 000 elements on gfx950, the cast + add 9 us)
+        sigma, geo_feat = self._sigma(x + deform.to(x.dtype))
         return sigma, self._color(d, geo_feat), deform
 
     def density(self, x, t):
         """network.py:171-206."""
         deform = self._deform(x, t)
         if t != 0:
-            x = x + deform
+            x = x + deform.to(x.dtype)
         sigma, geo_feat = self._sigma(x)
         return {"deform": deform, "sigma": sigma, "geo_feat": geo_feat}
 

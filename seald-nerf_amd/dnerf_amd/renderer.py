@@ -131,7 +131,9 @@ class NeRFRenderer(nn.Module):
             counter = self.step_counter[self.local_step % 16]
             counter.zero_()
             self.local_step += 1
-            xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield[t], self.cascade,
+            # (index_select with the device index: `density_bitfield[t]` with a 0-dim device tensor reads t back to the host)
+            bitfield = self.density_bitfield.index_select(0, t.reshape(1))[0]
+            xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, bitfield, self.cascade,
                                                                     self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
                                                                     force_all_rays, dt_gamma, max_steps)
             sigmas, rgbs, deform = self(xyzs, dirs, time)

@@ -1,0 +1,80 @@
+"""A dnerf training step as ONE HIP graph (MI355X: the step is launch-bound -- ~200 kernels of a few microseconds each for 4096
+rays / ~9000 samples, 1.6 ms of device time inside 2.9 ms of wall time when launched from Python).
+
+What the step is (nerf/utils.py:849-930 `train_one_epoch` -> `train_step` with `-O`): render the ray batch through the
+occupancy-grid path (`march_rays_train`, field network under autocast, `composite_rays_train`), a colour loss, GradScaler-scaled
+backward (composite backward, MLP backward, `grid_encode` backward atomics), Adam.  To be capturable the step may not read anything
+back to the host, so:
+  * the point budget must be known (`model.mean_count > 0`: the reference's own steady state, raymarching.py:200-203; run the first
+    steps eagerly and call `update_extra_state`, as the reference does);
+  * the network must not branch on `t == 0` on the host (`NeRFNetworkFF.forward` selects on the device);
+  * the optimizer is the fused, capturable Adam, which takes GradScaler's `found_inf` on the device (no `.item()` per step).
+Inputs live in fixed buffers the caller's batch is copied into; `time` is read by the kernels from device memory, so the frame time
+may change from step to step.  `step_counter` bookkeeping (`local_step`, the 16-slot ring read by `update_extra_state`) is replayed
+outside the graph with one small device copy.
+"""
+import torch
+
+
+class GraphedTrainStep:
+    def __init__(self, model, optimizer, scaler, n_rays, device, loss_fn=None, warmup=3, **render_kw):
+        if not getattr(model, "cuda_ray", False) or model.mean_count <= 0:
+            raise ValueError("GraphedTrainStep needs the occupancy-grid path with a known point budget (model.mean_count > 0)")
+        self.model, self.opt, self.scaler = model, optimizer, scaler
+        self.loss_fn = loss_fn or (lambda out, target: ((out["image"] - target) ** 2).mean())
+        self.render_kw = dict(staged=False, perturb=True, bg_color=1, force_all_rays=False, max_steps=1024)
+        self.render_kw.update(render_kw)
+        f32 = torch.float32
+        self.rays_o = torch.zeros(1, n_rays, 3, dtype=f32, device=device)
+        self.rays_d = torch.zeros(1, n_rays, 3, dtype=f32, device=device)
+        self.rays_d[..., 2] = 1
+        self.target = torch.zeros(1, n_rays, 3, dtype=f32, device=device)
+        self.time = torch.full((1, 1), 0.5, dtype=f32, device=device)
+        self.graph, self.loss, self.warmup = None, None, warmup
+
+    def _step(self):
+        with torch.autocast("cuda", dtype=torch.float16, enabled=self.scaler.is_enabled()):
+            out = self.model.render(self.rays_o, self.rays_d, self.time, **self.render_kw)
+            loss = self.loss_fn(out, self.target)
+        self.scaler.scale(loss).backward()
+        self.scaler.step(self.opt)
+        self.scaler.update()
+        return loss
+
+    def load(self, rays_o, rays_d, target, time):
+        self.rays_o.copy_(rays_o.reshape(self.rays_o.shape))
+        self.rays_d.copy_(rays_d.reshape(self.rays_d.shape))
+        self.target.copy_(target.reshape(self.target.shape))
+        self.time.copy_(time.reshape(1, 1))
+
+    def capture(self):
+        """Warm-up steps on a side stream (they train like any other step), then the capture."""
+        m = self.model
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                self.opt.zero_grad(set_to_none=True)
+                self._step()
+        torch.cuda.current_stream().wait_stream(side)
+        self._slot = m.local_step % 16                 # the ring slot run_cuda will bake into the graph
+        self.graph = torch.cuda.CUDAGraph()
+        self.opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss = self._step()
+        m.local_step -= 1                              # recording the step did not run it
+        return self
+
+    def __call__(self, rays_o=None, rays_d=None, target=None, time=None):
+        """One training step; returns the (static) loss tensor.  Arguments, if given, are copied into the graph's input buffers."""
+        if self.graph is None:
+            self.capture()
+        if rays_o is not None:
+            self.load(rays_o, rays_d, target, time)
+        m = self.model
+        self.graph.replay()
+        slot = m.local_step % 16
+        if slot != self._slot:
+            m.step_counter[slot].copy_(m.step_counter[self._slot])
+        m.local_step += 1
+        return self.loss

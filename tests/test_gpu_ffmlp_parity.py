@@ -166,3 +166,97 @@ def test_ffmlp_ragged_batches_match_the_padded_result(B):
     gw, gw_ref = wg.grad.cpu().numpy().astype(np.float32), gw_ref.astype(np.float32)
     assert np.linalg.norm(gw - gw_ref) <= 1e-2 * np.linalg.norm(gw_ref) + 1e-6
     del guard
+
+
+def test_dnerf_network_on_the_fused_operator_matches_the_linear_stack():
+    """dnerf_amd/network_ff.py: same parameters, deformation and colour MLPs through ffmlp_forward; forward values and every
+    parameter gradient against the autocast nn.Linear network (dnerf/network.py:123-169) on the same points."""
+    from dnerf_amd.bench_scene import build_model
+    from dnerf_amd.network_ff import NeRFNetworkFF
+    ref = build_model(0, "cuda").train()
+    ff = NeRFNetworkFF(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1).cuda().train()
+    ff.load_state_dict(ref.state_dict())
+    g = torch.Generator(device="cuda").manual_seed(0)
+    M = 9000
+    x = (torch.rand(M, 3, device="cuda", generator=g) - 0.5)
+    d = torch.nn.functional.normalize(torch.randn(M, 3, device="cuda", generator=g), dim=1)
+    t = torch.tensor([[0.5]], device="cuda")
+    w_s, w_c, w_d = torch.rand(M, device="cuda", generator=g), torch.rand(M, 3, device="cuda", generator=g), torch.rand(M, 3, device="cuda", generator=g)
+    outs, grads = [], []
+    for net in (ref, ff):
+        net.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            sigma, rgb, deform = net(x, d, t)
+            # sigma is exp(logit) with logits up to ~6 here: weigh it down so that the three terms pull comparably
+            loss = (torch.log1p(sigma.float()) * w_s).sum() + (rgb.float() * w_c).sum() + (deform.float() * w_d).sum() * 10
+        (loss * 64.0).backward()
+        outs.append((sigma.detach().float(), rgb.detach().float(), deform.detach().float()))
+        grads.append({n: p.grad.detach().float().clone() for n, p in net.named_parameters() if p.grad is not None})
+    (s0, c0, d0), (s1, c1, d1) = outs
+    assert d1.dtype == torch.float32 and float((d1 - d0).abs().max()) <= 2e-3 * float(d0.abs().max()) + 1e-4
+    rel = (s1 - s0).abs() / s0.abs().clamp(min=1e-3)
+    assert float(rel.median()) < 2e-3 and float(rel.max()) < 5e-2
+    assert float((c1 - c0).abs().max()) < 1e-2
+    assert set(grads[0]) == set(grads[1]) and any(k.startswith("deform_net") for k in grads[0]) and "encoder.embeddings" in grads[0]
+    for name, g0 in grads[0].items():
+        g1 = grads[1][name]
+        assert float((g1 - g0).norm()) <= 3e-2 * float(g0.norm()) + 1e-6, (name, float((g1 - g0).norm()), float(g0.norm()))
+    # inference mode and the fp32 fallback
+    ff.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        s2, c2, _ = ff(x, d, t)
+    assert torch.equal(s2.float(), s1) and torch.equal(c2.float(), c1)
+    with torch.no_grad():
+        s3, _, _ = ff(x, d, t)
+        s4, _, _ = ref.eval()(x, d, t)
+    assert torch.equal(s3, s4)
+
+
+def test_graphed_training_step_trains_like_the_eager_step():
+    """dnerf_amd/train_graph.py: the step replayed from one HIP graph against the same step launched from Python (same fused Adam,
+    same GradScaler, perturb off so both see the same samples): losses and parameters stay together over several steps; the only
+    difference is the order of the fp16 atomics in the grid backward."""
+    from dnerf_amd.bench_scene import build_scene
+    from dnerf_amd.network_ff import NeRFNetworkFF
+    from dnerf_amd.train_graph import GraphedTrainStep
+    sc = build_scene(H=64, W=64, device="cuda", seed=0)
+    n_rays = 2048
+    idx = torch.randint(0, sc.rays_o.shape[0], (n_rays,), generator=torch.Generator().manual_seed(0)).cuda()
+    rays_o, rays_d = sc.rays_o[idx][None].contiguous(), sc.rays_d[idx][None].contiguous()
+    target = torch.rand(1, n_rays, 3, generator=torch.Generator().manual_seed(2)).cuda()
+    losses, finals = [], []
+    for graphed in (False, True):
+        m = NeRFNetworkFF(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1).cuda().train()
+        m.load_state_dict(sc.model.state_dict())
+        opt = torch.optim.Adam(m.get_params(1e-2, 1e-3), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
+        scaler = torch.amp.GradScaler("cuda")
+        # point budget from one eager pass, as the reference's first epoch provides it
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            m.render(rays_o, rays_d, sc.time, staged=False, perturb=False, bg_color=1, force_all_rays=False, max_steps=1024)
+        m.mean_count = int(m.step_counter[0, 0].item())
+        assert m.mean_count > 100
+        m.local_step = 0
+        gs = GraphedTrainStep(m, opt, scaler, n_rays, "cuda", warmup=0, perturb=False)
+        gs.load(rays_o, rays_d, target, sc.time)
+        run = []
+        if graphed:
+            gs.capture()
+            assert m.local_step == 0
+            for k in range(6):
+                run.append(float(gs()))
+            assert m.local_step == 6 and int(m.step_counter[5, 0]) == int(m.step_counter[0, 0]) > 0
+        else:
+            for k in range(6):
+                opt.zero_grad(set_to_none=True)
+                run.append(float(gs._step().detach()))
+        losses.append(run)
+        finals.append({n: p.detach().float().clone() for n, p in m.named_parameters()})
+    a, b = losses
+    assert a[-1] < a[0] and b[-1] < b[0]                       # it trains
+    assert all(abs(x - y) <= 2e-2 * abs(x) for x, y in zip(a, b)), (a, b)
+    # Parameters: Adam with eps = 1e-15 moves every element by ~lr per step in the direction of sign(grad), so elements whose gradient
+    # is at the noise level of the atomics' summation order walk apart by up to 2 lr per step; bound, not tolerance.
+    for name, p in finals[0].items():
+        q = finals[1][name]
+        lr = 1e-2 if name.startswith("encoder") else 1e-3
+        assert float((p - q).abs().max()) <= 2.5 * 6 * lr, name
