@@ -223,20 +223,22 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const T *__restrict__ grad, co
                                                   uint32_t interp) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t b = tid * N_C / C;
-    if (b >= B) return;
     const uint32_t level = blockIdx.y;
     const uint32_t ch = tid * N_C - b * C;
     T *__restrict__ grad_grid = grad_grid_all + (size_t)lp.offset[level] * C;
     const uint32_t hashmap_size = lp.hashmap_size[level];
     const float scale = lp.scale[level];
     const uint32_t resolution = lp.resolution[level];
+    const uint32_t lane = threadIdx.x & 63u;
 
+    // No early return: every lane of the wave takes part in the run aggregation below (an idle lane contributes nothing).
+    bool active = b < B;
     float pos[D];
     uint32_t pos_grid[D];
     #pragma unroll
     for (uint32_t d = 0; d < D; d++) {
-        const float v = inputs[(size_t)b * D + d];
-        if (v < 0 || v > 1) return;
+        const float v = active ? inputs[(size_t)b * D + d] : 0.0f;
+        if (v < 0 || v > 1) active = false;
         pos[d] = v * scale + (align_corners ? 0.0f : 0.5f);
         pos_grid[d] = (uint32_t)floorf(pos[d]);
         pos[d] -= (float)pos_grid[d];
@@ -244,7 +246,7 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const T *__restrict__ grad, co
     }
     float grad_cur[N_C];
     #pragma unroll
-    for (uint32_t c = 0; c < N_C; c++) grad_cur[c] = Num<T>::ld(grad + ((size_t)level * B + b) * C + ch + c);
+    for (uint32_t c = 0; c < N_C; c++) grad_cur[c] = active ? Num<T>::ld(grad + ((size_t)level * B + b) * C + ch + c) : 0.0f;
 
     #pragma unroll
     for (uint32_t idx = 0; idx < (1u << D); idx++) {
@@ -256,12 +258,37 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const T *__restrict__ grad, co
             else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
         }
         const uint32_t index = grid_index<D, C>(gridtype, align_corners, hashmap_size, resolution, pgl) + ch;
+        // Consecutive lanes are consecutive samples -- in training, neighbours along a ray, a fraction of a coarse cell apart -- so on
+        // the coarse levels whole runs of lanes update the SAME row, and a wave's same-address atomics are executed one after the
+        // other by the L2 (the 9 000-sample training batch spent 176 us here, nearly all of it in the few hundred hot rows of levels
+        // 0-3).  Each run of equal rows is summed across its lanes in fp32 (segmented inclusive scan over run numbers) and its last
+        // lane issues ONE atomic.  Runs of one lane -- every fine level, any unordered batch -- behave exactly as before.
+        const uint32_t key = active ? index : 0xFFFFFFFFu - lane;            // idle lanes: a private key each
+        const uint32_t prev_key = __shfl_up(key, 1, 64);
+        const unsigned long long heads = __ballot(lane == 0 || prev_key != key);
+        const uint32_t run = (uint32_t)__popcll(heads & (~0ull >> (63u - lane)));   // run number, non-decreasing with the lane
+        float acc[N_C];
+        #pragma unroll
+        for (uint32_t c = 0; c < N_C; c++) acc[c] = w * grad_cur[c];
+        if (__popcll(heads) != 64) {   // wave-uniform: something to merge
+            #pragma unroll
+            for (uint32_t off = 1; off < 64; off <<= 1) {
+                const uint32_t r = __shfl_up(run, off, 64);
+                #pragma unroll
+                for (uint32_t c = 0; c < N_C; c++) {
+                    const float o = __shfl_up(acc[c], off, 64);
+                    if (lane >= off && r == run) acc[c] += o;
+                }
+            }
+        }
+        const bool tail = lane == 63u || ((heads >> (lane + 1u)) & 1ull);
+        if (!active || !tail) continue;
         if constexpr (sizeof(T) == 2) {
-            if constexpr (N_C == 2) atomic_add_h2((__half *)grad_grid + index, w * grad_cur[0], w * grad_cur[1]);
-            else atomic_add_h1((__half *)grad_grid + index, w * grad_cur[0]);
+            if constexpr (N_C == 2) atomic_add_h2((__half *)grad_grid + index, acc[0], acc[1]);
+            else atomic_add_h1((__half *)grad_grid + index, acc[0]);
         } else {
             #pragma unroll
-            for (uint32_t c = 0; c < N_C; c++) atomic_add_f32((float *)grad_grid + index + c, w * grad_cur[c]);
+            for (uint32_t c = 0; c < N_C; c++) atomic_add_f32((float *)grad_grid + index + c, acc[c]);
         }
     }
 }
