@@ -53,3 +53,73 @@ class FrameGather:
             dist.all_gather_into_tensor(self.gathered, local)  # RCCL over xGMI when the backend is "nccl"
         self.frame[self.all_idx] = self.gathered  # padding rows rewrite a pixel with its own value
         return self.frame
+
+
+class GradSync:
+    """Data-parallel training: every rank trains on its own ray batch with a full replica, gradients are averaged
+    before the optimizer step.  Two exchanges per step over RCCL / xGMI:
+
+      * the embedding-table gradient (6 119 864 x 2 fp32 = 46.7 MiB, one ring all-reduce: ~0.55 ms at 153 GB/s per link) -- in the
+        eager step it is issued from a post-accumulate hook, i.e. the moment `grid_encode` backward has produced it, and runs under
+        the deformation MLP's backward, which autograd executes next;
+      * one flat bucket with every other gradient (113 k values).
+
+    Under GradScaler the ranks' scales stay identical: an inf / nan on one rank spreads through the sum, every rank skips the step.
+    With the graphed step (train_graph.py) the exchange sits between the backward graph and the optimizer graph (`reduce_all`)."""
+
+    def __init__(self, model, group=None, table_name="encoder.embeddings"):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        self.table = [p for n, p in named if n == table_name]
+        self.rest = [p for n, p in named if n != table_name]
+        self._handle, self._hook = None, None
+
+    def broadcast_parameters(self, src=0):
+        """Replicas start equal (the reference has no DP; this is what DistributedDataParallel does at construction)."""
+        for p in self.table + self.rest:
+            self.dist.broadcast(p.data, src, group=self.group)
+
+    def _reduce(self, t, async_op=False):
+        if t.is_cuda and self.dist.get_backend(self.group) == "gloo":  # one-GPU rehearsal: gloo moves host memory
+            host = t.cpu()
+            self.dist.all_reduce(host, group=self.group)
+            t.copy_(host)
+            return None
+        return self.dist.all_reduce(t, group=self.group, async_op=async_op)
+
+    def install_hook(self):
+        """Eager step: start the table exchange as soon as its gradient exists."""
+        def fire(p):
+            self._handle = self._reduce(p.grad, async_op=True)
+        self._hook = [p.register_post_accumulate_grad_hook(fire) for p in self.table]
+        return self
+
+    def remove_hook(self):
+        for h in self._hook or []:
+            h.remove()
+        self._hook = None
+
+    def reduce_all(self):
+        """Call after backward, before the optimizer (GradScaler.step): finishes / performs the table exchange, exchanges the flat
+        bucket, turns sums into means."""
+        from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
+        if self._hook:
+            if self._handle is not None:
+                self._handle.wait()
+            self._handle = None
+        else:
+            for p in self.table:
+                if p.grad is not None:
+                    self._reduce(p.grad)
+        grads = [p.grad for p in self.rest if p.grad is not None]
+        if grads:
+            flat = _flatten_dense_tensors(grads)
+            self._reduce(flat)
+            flat.div_(self.world)
+            for g, f in zip(grads, _unflatten_dense_tensors(flat, grads)):
+                g.copy_(f)
+        for p in self.table:
+            if p.grad is not None:
+                p.grad.div_(self.world)

@@ -17,7 +17,9 @@ import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, scaler, n_rays, device, loss_fn=None, warmup=3, **render_kw):
+    def __init__(self, model, optimizer, scaler, n_rays, device, loss_fn=None, warmup=3, grad_sync=None, **render_kw):
+        """grad_sync: a `dnerf_amd.dist.GradSync` for data-parallel training -- the step is then two graphs (forward + backward |
+        optimizer) with the gradient all-reduces between them."""
         if not getattr(model, "cuda_ray", False) or model.mean_count <= 0:
             raise ValueError("GraphedTrainStep needs the occupancy-grid path with a known point budget (model.mean_count > 0)")
         self.model, self.opt, self.scaler = model, optimizer, scaler
@@ -30,16 +32,28 @@ class GraphedTrainStep:
         self.rays_d[..., 2] = 1
         self.target = torch.zeros(1, n_rays, 3, dtype=f32, device=device)
         self.time = torch.full((1, 1), 0.5, dtype=f32, device=device)
-        self.graph, self.loss, self.warmup = None, None, warmup
+        self.graph, self.graph_opt, self.loss, self.warmup, self.grad_sync = None, None, None, warmup, grad_sync
 
     def _step(self):
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.scaler.is_enabled()):
             out = self.model.render(self.rays_o, self.rays_d, self.time, **self.render_kw)
             loss = self.loss_fn(out, self.target)
         self.scaler.scale(loss).backward()
+        if self.grad_sync is not None:
+            self.grad_sync.reduce_all()
+        self._optimize()
+        return loss
+
+    def _backward_only(self):
+        with torch.autocast("cuda", dtype=torch.float16, enabled=self.scaler.is_enabled()):
+            out = self.model.render(self.rays_o, self.rays_d, self.time, **self.render_kw)
+            loss = self.loss_fn(out, self.target)
+        self.scaler.scale(loss).backward()
+        return loss
+
+    def _optimize(self):
         self.scaler.step(self.opt)
         self.scaler.update()
-        return loss
 
     def load(self, rays_o, rays_d, target, time):
         self.rays_o.copy_(rays_o.reshape(self.rays_o.shape))
@@ -60,8 +74,15 @@ class GraphedTrainStep:
         self._slot = m.local_step % 16                 # the ring slot run_cuda will bake into the graph
         self.graph = torch.cuda.CUDAGraph()
         self.opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
-            self.loss = self._step()
+        if self.grad_sync is None:
+            with torch.cuda.graph(self.graph):
+                self.loss = self._step().detach()
+        else:
+            with torch.cuda.graph(self.graph):
+                self.loss = self._backward_only().detach()
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+                self._optimize()
         m.local_step -= 1                              # recording the step did not run it
         return self
 
@@ -73,6 +94,9 @@ class GraphedTrainStep:
             self.load(rays_o, rays_d, target, time)
         m = self.model
         self.graph.replay()
+        if self.graph_opt is not None:
+            self.grad_sync.reduce_all()                # RCCL all-reduces of the gradients the backward graph left in place
+            self.graph_opt.replay()
         slot = m.local_step % 16
         if slot != self._slot:
             m.step_counter[slot].copy_(m.step_counter[self._slot])

@@ -65,3 +65,65 @@ def test_shards_partition_the_image_and_are_balanced():
     centre = (abs(ys - 400) < 64) & (abs(xs - 400) < 64)
     owners = ((ys // 16) * 50 + (xs // 16)) % 8
     assert len(set(owners[centre])) == 8
+
+
+class _ToyField(torch.nn.Module):
+    """Stand-in with the parameter layout GradSync distinguishes: a big table named `encoder.embeddings` + small MLP weights."""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = torch.nn.Module()
+        self.encoder.embeddings = torch.nn.Parameter(torch.zeros(1000, 2))
+        self.net = torch.nn.ModuleList([torch.nn.Linear(2, 8, bias=False), torch.nn.Linear(8, 3, bias=False)])
+
+    def forward(self, idx):
+        h = self.encoder.embeddings[idx]
+        return self.net[1](torch.relu(self.net[0](h)))
+
+
+def _dp_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dnerf_amd.dist import GradSync
+        torch.manual_seed(100 + rank)                      # replicas start DIFFERENT; broadcast makes them equal
+        model = _ToyField()
+        torch.nn.init.normal_(model.encoder.embeddings)
+        sync = GradSync(model)
+        sync.broadcast_parameters()
+        start = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+        ok = True
+        for use_hook in (False, True):
+            if use_hook:
+                sync.install_hook()
+            g = torch.Generator().manual_seed(7 + rank)    # every rank its own batch
+            idx = torch.randint(0, 1000, (64,), generator=g)
+            target = torch.randn(64, 3, generator=g)
+            model.zero_grad(set_to_none=True)
+            ((model(idx) - target) ** 2).mean().backward()
+            local = [p.grad.clone() for p in model.parameters()]
+            sync.reduce_all()
+            # reference: gather every rank's local gradients and average them
+            for p, mine in zip(model.parameters(), local):
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(parts, mine)
+                ok = ok and torch.allclose(p.grad, torch.stack(parts).mean(0), rtol=1e-6, atol=1e-7)
+            if use_hook:
+                sync.remove_hook()
+        # replicas that step on the averaged gradient stay identical
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        opt.step()
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        parts = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(parts, flat)
+        ok = ok and all(torch.equal(parts[0], q) for q in parts) and not torch.equal(flat, start)
+        np.save(os.path.join(out_dir, f"dp_{rank}.npy"), np.array([ok]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_exchange_gloo(tmp_path):
+    world = 2
+    mp.spawn(_dp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(bool(np.load(tmp_path / f"dp_{r}.npy")[0]) for r in range(world))
