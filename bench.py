@@ -47,7 +47,7 @@ def parse():
                          "0 = strictly one frame at a time)")
     ap.add_argument("--contexts", type=int, default=3, help="--pipeline: loop contexts (frames in flight)")
     ap.add_argument("--groups", type=int, default=1, help="device loop only: render the frame as G interleaved ray groups on G streams")
-    ap.add_argument("--mode", default="render", choices=["render", "train", "seald", "density"],
+    ap.add_argument("--mode", default="render", choices=["render", "train", "seald", "seald-train", "density"],
                     help="render: the headline 800x800 inference frame; train: one dnerf training step on 4096 rays (BASELINE config 3)")
     ap.add_argument("--scene", default="jumpingjacks", choices=["jumpingjacks", "lego"],
                     help="synthetic occupancy: the jumpingjacks-like figure (headline, BASELINE configs 1-4) or the lego-like box (config 5)")
@@ -181,6 +181,95 @@ def seald_mode(args):
                                  "loop": "device", "frames_in_flight": args.contexts}}))
 
 
+def seald_train_mode(args):
+    """SealD-NeRF edit-training step (StudentTrainer.train_gui, SealDNeRF/utils.py:667-777) on 4096 rays of the 800x800
+    camera: the teacher renders the edited scene (bbox seal mapper, T_thresh 1e-4), the student -- deformation network frozen --
+    trains on it.  Native: teacher through the device loop with the fused field + seal kernels, student step as one HIP graph
+    (dnerf_amd/seald_train.py).  Reference-shaped: `SealDNeRFTeacher.render` op by op + an eager autocast step on the nn.Linear
+    network with torch's Adam.  One JSON line."""
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    import gc
+    from dnerf_amd.bench_scene import build_scene
+    from dnerf_amd.network_ff import NeRFNetworkFF
+    from dnerf_amd.seald import SealDNeRFTeacher
+    from dnerf_amd.seald_train import EditTrainStep, freeze_deformation
+    from dnerf_amd import seal_mapper as SM
+    sc = build_scene(H=args.size, W=args.size, device=dev, seed=0)
+    half, centre = 0.12, (0.0, 0.47, 0.0)
+    raw = [[centre[0] + sx * half, centre[1] + sy * half, centre[2] + sz * half] for sz in (-1, 1) for sy in (-1, 1) for sx in (-1, 1)]
+    T = np.eye(4); T[0, 3] = 0.35
+    mapper = SM.get_seal_mapper({"type": "bbox", "raw": raw, "transform": T.tolist(), "scale": [1.0, 1.0, 1.0], "boundType": "to",
+                                 "hsv": [0.3, 0.0, 0.0]})
+    SM.fill_bitfield(sc.model.density_bitfield, mapper.map_data["force_fill_bound"].cpu().numpy(), sc.model.grid_size, sc.model.bound)
+    n_rays = 4096
+    idx = torch.randint(0, sc.rays_o.shape[0], (n_rays,), generator=torch.Generator(device="cpu").manual_seed(0)).to(dev)
+    rays_o, rays_d = sc.rays_o[idx].contiguous(), sc.rays_d[idx].contiguous()
+    kw = dict(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1)
+
+    def budget(m):   # the point budget the reference's first epoch provides
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            m.render(rays_o[None], rays_d[None], sc.time, staged=False, perturb=False, bg_color=1, force_all_rays=False, max_steps=1024)
+        m.mean_count = int(m.step_counter[0, 0].item()) + 1024
+        m.local_step = 0
+
+    def timed(fn, steps):
+        gc.collect(); gc.disable()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        gc.enable()
+        return dt / steps * 1e3
+
+    # native
+    student = NeRFNetworkFF(**kw).to(dev).train()
+    student.load_state_dict(sc.model.state_dict())
+    params = freeze_deformation(student)
+    budget(student)
+    opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
+    edit = EditTrainStep(sc.model, student, mapper, opt, torch.amp.GradScaler("cuda"), n_rays, dev, sc.time)
+    for _ in range(args.warmup):
+        edit(rays_o, rays_d, sc.time)
+    ms_native = timed(lambda: edit(rays_o, rays_d, sc.time), args.steps)
+    ms_teacher = timed(lambda: edit.proxy_truth(rays_o, rays_d, sc.time), args.steps)
+    # reference-shaped
+    from dnerf_amd.network import NeRFNetwork
+    teacher = SealDNeRFTeacher(**kw).to(dev).eval()
+    teacher.load_state_dict(sc.model.state_dict(), strict=False)
+    teacher.init_mapper(mapper)
+    ref_student = NeRFNetwork(**kw).to(dev).train()
+    ref_student.load_state_dict(sc.model.state_dict())
+    ref_params = freeze_deformation(ref_student)
+    budget(ref_student)
+    ref_opt = torch.optim.Adam(ref_params, lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+    ref_scaler = torch.amp.GradScaler("cuda")
+
+    def ref_step():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            target = teacher.render(rays_o[None], rays_d[None], sc.time, staged=True, perturb=False, bg_color=1, force_all_rays=True)["image"]
+        ref_opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            out = ref_student.render(rays_o[None], rays_d[None], sc.time, staged=False, perturb=True, bg_color=1, force_all_rays=False, max_steps=1024)
+            loss = ((out["image"] - target) ** 2).mean()
+        ref_scaler.scale(loss).backward()
+        ref_scaler.step(ref_opt)
+        ref_scaler.update()
+    for _ in range(args.warmup):
+        ref_step()
+    ms_ref = timed(ref_step, max(5, args.steps // 2))
+    print(json.dumps({"metric": "SealD-NeRF edit-training step (teacher proxy render with bbox seal mapper + student step), 4096 rays",
+                      "value": 1e3 / ms_native, "unit": "steps/s", "ms_per_step": ms_native, "teacher_render_ms": ms_teacher,
+                      "reference_shaped_ms_per_step": ms_ref, "speedup": ms_ref / ms_native, "rays_per_s": n_rays * 1e3 / ms_native,
+                      "higher_is_better": True, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "dtype": "f16", "data": "synthetic",
+                      "config": {"workload": "SURVEY 3.4 / BASELINE config 4 in training: StudentTrainer.train_gui step", "rays": n_rays,
+                                 "student": "NeRFNetworkFF, deform_net frozen, one HIP graph per step",
+                                 "teacher": "device loop + fused field + seal kernels, T_thresh 1e-4",
+                                 "reference_shaped": "SealDNeRFTeacher.render op by op + eager nn.Linear student step, torch Adam"}}))
+
+
 def density_mode(args):
     """The density-grid maintenance pass between training epochs (update_extra_state, dnerf/renderer.py:453-555):
     64 time slices x 128^3 cells through the density network + EMA + mean + bitfield.  Times the full update (iter_density < 16)
@@ -241,6 +330,8 @@ def main():
         return train_mode(args)
     if args.mode == "density":
         return density_mode(args)
+    if args.mode == "seald-train":
+        return seald_train_mode(args)
     if args.mode == "seald":
         return seald_mode(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -313,3 +313,40 @@ def test_data_parallel_graphed_step_keeps_replicas_identical(tmp_path):
     for r in range(2):
         same, first, last, two_graphs = np.load(tmp_path / f"dp_{r}.npy")
         assert same == 1.0 and two_graphs == 1.0 and last < first, (same, first, last)
+
+
+def test_seald_edit_training_step_learns_the_teachers_edit():
+    """dnerf_amd/seald_train.py (StudentTrainer.train_gui, SealDNeRF/utils.py:667-777): the teacher's mapped render is the target of the
+    student's graphed step; the deformation network stays frozen; the student moves towards the edited image."""
+    from dnerf_amd.bench_scene import build_scene
+    from dnerf_amd.network_ff import NeRFNetworkFF
+    from dnerf_amd.renderer import render_frame
+    from dnerf_amd.seald_train import EditTrainStep, freeze_deformation
+    from dnerf_amd import fused, seal_mapper as SM
+    sc = build_scene(H=64, W=64, device="cuda", seed=0)
+    half, centre = 0.12, (0.0, 0.47, 0.0)
+    raw = [[centre[0] + sx * half, centre[1] + sy * half, centre[2] + sz * half] for sz in (-1, 1) for sy in (-1, 1) for sx in (-1, 1)]
+    T = np.eye(4); T[0, 3] = 0.35
+    mapper = SM.get_seal_mapper({"type": "bbox", "raw": raw, "transform": T.tolist(), "scale": [1.0, 1.0, 1.0], "boundType": "to", "hsv": [0.3, 0.0, 0.0]})
+    SM.fill_bitfield(sc.model.density_bitfield, mapper.map_data["force_fill_bound"].cpu().numpy(), sc.model.grid_size, sc.model.bound)
+    n_rays = sc.rays_o.shape[0]
+    student = NeRFNetworkFF(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1).cuda().train()
+    student.load_state_dict(sc.model.state_dict())
+    params = freeze_deformation(student)
+    assert all(not p.requires_grad for p in student.deform_net.parameters()) and len(params) == 6   # table + 2 sigma + 3 colour matrices
+    frozen = [p.detach().clone() for p in student.deform_net.parameters()]
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        student.render(sc.rays_o[None], sc.rays_d[None], sc.time, staged=False, perturb=False, bg_color=1, force_all_rays=False, max_steps=1024)
+    student.mean_count = int(student.step_counter[0, 0].item()) + 512
+    student.local_step = 0
+    opt = torch.optim.Adam(params, lr=2e-3, betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
+    edit = EditTrainStep(sc.model, student, mapper, opt, torch.amp.GradScaler("cuda"), n_rays, "cuda", sc.time, perturb=False, warmup=1)
+    # the target is exactly the native mapped render of the teacher
+    want = render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=True, field=fused.FusedField(sc.model, sc.time, fp16=True), T_thresh=1e-4, mapper=mapper)["image"]
+    got = edit.proxy_truth(sc.rays_o, sc.rays_d, sc.time)
+    assert torch.equal(got, want)
+    plain = render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=True, field=fused.FusedField(sc.model, sc.time, fp16=True), T_thresh=1e-4)["image"]
+    assert float((want - plain).abs().max()) > 0.05                               # the edit is visible
+    losses = [float(edit(sc.rays_o, sc.rays_d, sc.time)) for _ in range(30)]
+    assert losses[-1] < 0.6 * losses[0], (losses[0], losses[-1])
+    assert all(torch.equal(a, b.detach()) for a, b in zip(frozen, student.deform_net.parameters()))
