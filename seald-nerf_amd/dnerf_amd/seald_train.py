@@ -42,3 +42,41 @@ class EditTrainStep:
     def __call__(self, rays_o, rays_d, time):
         target = self.proxy_truth(rays_o, rays_d, time)
         return self.step(rays_o, rays_d, target, time)
+
+    def run(self, batches):
+        """Software-pipelined epoch over an iterable of (rays_o, rays_d, time): the student's graph for batch k is launched (one call,
+        asynchronous) and the host then drives the teacher's loop for batch k+1 on a second stream, so the two halves of the step --
+        both chains of small launches -- overlap on the device.  The teacher is fixed, so results equal the one-after-the-other
+        order.  Returns the number of steps; the last loss is `self.step.loss`."""
+        main = torch.cuda.current_stream()
+        if not hasattr(self, "_side"):
+            self._side = torch.cuda.Stream()
+        side = self._side
+        loaded, rendered = torch.cuda.Event(), torch.cuda.Event()
+        it = iter(batches)
+        cur = next(it, None)
+        if cur is None:
+            return 0
+        if self.step.graph is None:            # capture before anything runs beside it
+            self.step.load(cur[0], cur[1], torch.zeros_like(self.loop.image_out), cur[2])
+            self.step.capture()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            target = self.proxy_truth(*cur)
+            rendered.record(side)
+        n = 0
+        while cur is not None:
+            nxt = next(it, None)
+            main.wait_event(rendered)          # the teacher's colours of batch k
+            self.step.load(cur[0], cur[1], target, cur[2])
+            loaded.record(main)                # ... are in the graph's buffer: the teacher may overwrite its output
+            self.step()
+            n += 1
+            if nxt is not None:
+                with torch.cuda.stream(side):
+                    side.wait_event(loaded)
+                    target = self.proxy_truth(*nxt)
+                    rendered.record(side)
+            cur = nxt
+        main.wait_stream(side)
+        return n

@@ -350,3 +350,11 @@ def test_seald_edit_training_step_learns_the_teachers_edit():
     losses = [float(edit(sc.rays_o, sc.rays_d, sc.time)) for _ in range(30)]
     assert losses[-1] < 0.6 * losses[0], (losses[0], losses[-1])
     assert all(torch.equal(a, b.detach()) for a, b in zip(frozen, student.deform_net.parameters()))
+    # pipelined epoch (teacher of batch k+1 under the student's step k): same kind of progress, same frozen deformation
+    before = float(edit.step.loss)
+    batch = (sc.rays_o, sc.rays_d, sc.time)
+    assert edit.run([batch] * 20) == 20
+    torch.cuda.synchronize()
+    assert float(edit.step.loss) < before
+    assert all(torch.equal(a, b.detach()) for a, b in zip(frozen, student.deform_net.parameters()))
+    assert edit.run([]) == 0
