@@ -45,7 +45,8 @@ def parse():
                     help="device loop: render the timed steps as a stream of frames through --contexts loop contexts; the next frame "
                          "starts when a context is free and the newest frame in flight is down to rays / DIV alive (1 = at once; "
                          "0 = strictly one frame at a time)")
-    ap.add_argument("--contexts", type=int, default=3, help="--pipeline: loop contexts (frames in flight)")
+    ap.add_argument("--contexts", type=int, default=4, help="--pipeline: loop contexts (frames in flight); the HIP runtime is given one "
+                                                            "hardware queue per context + the default stream (GPU_MAX_HW_QUEUES, if unset)")
     ap.add_argument("--groups", type=int, default=1, help="device loop only: render the frame as G interleaved ray groups on G streams")
     ap.add_argument("--mode", default="render", choices=["render", "train", "seald", "seald-train", "density"],
                     help="render: the headline 800x800 inference frame; train: one dnerf training step on 4096 rays (BASELINE config 3)")
@@ -329,6 +330,10 @@ def density_mode(args):
 
 def main():
     args = parse()
+    # One hardware queue per stream in use (the loop contexts + torch's default stream), set before the HIP runtime starts: with the
+    # runtime's default of 4 a fifth stream shares a queue with another frame's chain of dependent launches (4 contexts: 0.42 ms per
+    # shard-sized frame), with more queues than streams three contexts got slower (0.85 ms); measured best: contexts + 1.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, args.contexts + 1)))
     if args.mode == "train":
         return train_mode(args)
     if args.mode == "density":
