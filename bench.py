@@ -333,7 +333,10 @@ def main():
     # One hardware queue per stream in use (the loop contexts + torch's default stream), set before the HIP runtime starts: with the
     # runtime's default of 4 a fifth stream shares a queue with another frame's chain of dependent launches (4 contexts: 0.42 ms per
     # shard-sized frame), with more queues than streams three contexts got slower (0.85 ms); measured best: contexts + 1.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, args.contexts + 1)))
+    # (only the modes that keep `contexts` frames in flight: queues beyond the streams in use cost as much as too few -- the
+    # two-stream edit-training epoch ran at 3.8 instead of 1.3 ms per step with 5 queues)
+    if args.mode in ("render", "seald"):
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, args.contexts + 1)))
     if args.mode == "train":
         return train_mode(args)
     if args.mode == "density":

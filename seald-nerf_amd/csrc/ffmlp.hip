@@ -115,15 +115,14 @@ __device__ __forceinline__ half8 tr_frag(const unsigned char *tile, int s, int c
     return half8{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
 }
 
-__global__ void __launch_bounds__(256) k_ffmlp_dw(DwArgs P) {
-    __shared__ __attribute__((aligned(16))) unsigned char s_g[kDwRows * kDwStride];
-    __shared__ __attribute__((aligned(16))) unsigned char s_x[kDwRows * kDwStride];
+// one workgroup: split `split` of the batch, output block `block` of one layer's dW
+__device__ __forceinline__ void dw_block(const DwArgs &P, uint32_t split, uint32_t block, unsigned char *s_g, unsigned char *s_x) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t nbx = (P.N + 127) / 128;
-    const uint32_t mb = (blockIdx.y / nbx) * 128, nb = (blockIdx.y % nbx) * 128;   // origin of this block's <= 128 x 128 output
+    const uint32_t mb = (block / nbx) * 128, nb = (block % nbx) * 128;             // origin of this block's <= 128 x 128 output
     const uint32_t mcols = min(128u, P.Mpad - mb), ncols = min(128u, P.Npad - nb); // multiples of 32
     const uint32_t wy = wave >> 1, wx = wave & 1u;
-    const uint32_t b_begin = blockIdx.x * P.rows_per_split;
+    const uint32_t b_begin = split * P.rows_per_split;
     const uint32_t b_end = min(P.B, b_begin + P.rows_per_split);
 
     f32x16 acc[2][2];
@@ -176,7 +175,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_dw(DwArgs P) {
         }
     }
     const uint32_t n = lane & 31u, h = lane >> 5;
-    float *dst = P.partial + (size_t)blockIdx.x * P.Mpad * P.Npad;
+    float *dst = P.partial + (size_t)split * P.Mpad * P.Npad;
     #pragma unroll
     for (int a = 0; a < 2; a++)
         #pragma unroll
@@ -190,9 +189,32 @@ __global__ void __launch_bounds__(256) k_ffmlp_dw(DwArgs P) {
         }
 }
 
+__global__ void __launch_bounds__(256) k_ffmlp_dw(DwArgs P) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_g[kDwRows * kDwStride];
+    __shared__ __attribute__((aligned(16))) unsigned char s_x[kDwRows * kDwStride];
+    dw_block(P, blockIdx.x, blockIdx.y, s_g, s_x);
+}
+
+// Every layer's weight gradient in ONE launch (blockIdx.z = layer), each with its own partial-sum region: a training batch of a few
+// thousand samples is launch-bound here (2 x (L + 1) launches of < 20 us each for the deformation MLP of the dnerf network).
+constexpr int kMaxDw = 17;
+struct DwBatch {
+    DwArgs a[kMaxDw];
+    _Float16 *out[kMaxDw];
+    uint32_t nsplit[kMaxDw], blocks[kMaxDw];
+};
+
+__global__ void __launch_bounds__(256) k_ffmlp_dw_batched(DwBatch Bt) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_g[kDwRows * kDwStride];
+    __shared__ __attribute__((aligned(16))) unsigned char s_x[kDwRows * kDwStride];
+    const uint32_t z = blockIdx.z;
+    if (blockIdx.x >= Bt.nsplit[z] || blockIdx.y >= Bt.blocks[z]) return;   // workgroup-uniform, before any barrier
+    dw_block(Bt.a[z], blockIdx.x, blockIdx.y, s_g, s_x);
+}
+
 // deterministic second pass: element (m, n) = sum over the splits, 4 partial sums per element combined through LDS
-__global__ void __launch_bounds__(256) k_ffmlp_dw_reduce(const float *partial, uint32_t nsplit, uint32_t M, uint32_t N, uint32_t Mpad, uint32_t Npad, _Float16 *out) {
-    __shared__ float s_part[4][64];
+__device__ __forceinline__ void dw_reduce_block(const float *partial, uint32_t nsplit, uint32_t M, uint32_t N, uint32_t Mpad, uint32_t Npad,
+                                                _Float16 *out, float (*s_part)[64]) {
     const uint32_t x = threadIdx.x & 63u, y = threadIdx.x >> 6;
     const uint32_t idx = blockIdx.x * 64u + x;
     float s = 0.0f;
@@ -203,6 +225,18 @@ __global__ void __launch_bounds__(256) k_ffmlp_dw_reduce(const float *partial, u
     s_part[y][x] = s;
     __syncthreads();
     if (y == 0 && idx < M * N) out[idx] = (_Float16)((s_part[0][x] + s_part[1][x]) + (s_part[2][x] + s_part[3][x]));
+}
+
+__global__ void __launch_bounds__(256) k_ffmlp_dw_reduce(const float *partial, uint32_t nsplit, uint32_t M, uint32_t N, uint32_t Mpad, uint32_t Npad, _Float16 *out) {
+    __shared__ float s_part[4][64];
+    dw_reduce_block(partial, nsplit, M, N, Mpad, Npad, out, s_part);
+}
+
+__global__ void __launch_bounds__(256) k_ffmlp_dw_reduce_batched(DwBatch Bt) {
+    __shared__ float s_part[4][64];
+    const DwArgs &P = Bt.a[blockIdx.y];
+    if (blockIdx.x * 64u >= P.M * P.N) return;                               // workgroup-uniform
+    dw_reduce_block(P.partial, Bt.nsplit[blockIdx.y], P.M, P.N, P.Mpad, P.Npad, Bt.out[blockIdx.y], s_part);
 }
 
 uint32_t dw_splits(uint32_t B, uint32_t blocks) {
@@ -218,6 +252,15 @@ uint32_t dw_blocks(uint32_t M, uint32_t N) { return (((M + 31) / 32 * 32 + 127) 
 
 uint64_t dw_partial_bytes(uint32_t B, uint32_t M, uint32_t N) {
     return (uint64_t)dw_splits(B, dw_blocks(M, N)) * ((M + 31) / 32 * 32) * ((N + 31) / 32 * 32) * sizeof(float);
+}
+
+// All layers' partial sums side by side (one launch for every dW) when that stays small; else one region reused layer by layer.
+constexpr uint64_t kDwBatchedBudget = 64ull << 20;
+uint64_t dw_batched_bytes(uint32_t B, uint32_t in_dim, uint32_t W, uint32_t L) {
+    return dw_partial_bytes(B, 16, W) + (uint64_t)(L - 1) * dw_partial_bytes(B, W, W) + dw_partial_bytes(B, W, in_dim);
+}
+bool dw_batched(uint32_t B, uint32_t in_dim, uint32_t W, uint32_t L) {
+    return L + 1 <= (uint32_t)kMaxDw && dw_batched_bytes(B, in_dim, W, L) <= kDwBatchedBudget;
 }
 
 bool dims_ok(uint32_t in_dim, uint32_t out_dim, uint32_t W, uint32_t L) {
@@ -263,6 +306,7 @@ uint64_t sdn_ffmlp_scratch_bytes(uint32_t B, uint32_t input_dim, uint32_t output
     const uint64_t p1 = dw_partial_bytes(B, hidden_dim, hidden_dim), p2 = dw_partial_bytes(B, hidden_dim, input_dim);
     if (p1 > partial) partial = p1;
     if (p2 > partial) partial = p2;
+    if (dw_batched(B, input_dim, hidden_dim, num_layers)) partial = dw_batched_bytes(B, input_dim, hidden_dim, num_layers);
     return packed + partial;
 }
 
@@ -304,16 +348,29 @@ int sdn_ffmlp_backward(const void *grad, const void *inputs, const void *weights
     float *partial = (float *)((unsigned char *)scratch + (fw > bw ? fw : bw) * 1024);
     const _Float16 *fwd = (const _Float16 *)forward_buffer, *bwd = (const _Float16 *)backward_buffer;
     _Float16 *gw = (_Float16 *)grad_weights;
+    const bool batched = dw_batched(B, in, W, L);
+    DwBatch bt;
+    uint32_t n_bt = 0, max_ns = 1, max_blocks = 1, max_red = 1;
+    float *next_partial = partial;
     auto dw = [&](const _Float16 *G, uint32_t ldg, uint32_t M, const _Float16 *X, uint32_t ldx, uint32_t N, _Float16 *out) -> int {
         DwArgs d;
-        d.G = G; d.X = X; d.partial = partial; d.B = B; d.ldg = ldg; d.ldx = ldx; d.M = M; d.N = N;
+        d.G = G; d.X = X; d.partial = next_partial; d.B = B; d.ldg = ldg; d.ldx = ldx; d.M = M; d.N = N;
         d.Mpad = (M + 31) / 32 * 32; d.Npad = (N + 31) / 32 * 32;
         const uint32_t blocks = dw_blocks(M, N);
         const uint32_t ns = dw_splits(B, blocks);
         d.rows_per_split = sdn_div_up(sdn_div_up(B, ns), (uint32_t)kDwRows) * kDwRows;
         const uint32_t ns_used = sdn_div_up(B, d.rows_per_split);
+        if (batched) {                        // collected; launched together below
+            bt.a[n_bt] = d; bt.out[n_bt] = out; bt.nsplit[n_bt] = ns_used; bt.blocks[n_bt] = blocks;
+            n_bt++;
+            next_partial += dw_partial_bytes(B, M, N) / sizeof(float);
+            if (ns_used > max_ns) max_ns = ns_used;
+            if (blocks > max_blocks) max_blocks = blocks;
+            if (sdn_div_up(M * N, 64u) > max_red) max_red = sdn_div_up(M * N, 64u);
+            return 0;
+        }
         hipLaunchKernelGGL(k_ffmlp_dw, dim3(ns_used, blocks), dim3(256), 0, st, d);
-        hipLaunchKernelGGL(k_ffmlp_dw_reduce, dim3(sdn_div_up(M * N, 64u)), dim3(256), 0, st, partial, ns_used, M, N, d.Mpad, d.Npad, out);
+        hipLaunchKernelGGL(k_ffmlp_dw_reduce, dim3(sdn_div_up(M * N, 64u)), dim3(256), 0, st, d.partial, ns_used, M, N, d.Mpad, d.Npad, out);
         return sdn_launch_status();
     };
     const size_t BW = (size_t)B * W;
@@ -326,7 +383,12 @@ int sdn_ffmlp_backward(const void *grad, const void *inputs, const void *weights
         if (rc) return rc;
     }
     // input layer: dW_0 [W, in] = G_0^T inputs                                    (ffmlp.cu:866-876)
-    return dw(bwd + (size_t)(L - 1) * BW, W, W, (const _Float16 *)inputs, in, in, gw);
+    rc = dw(bwd + (size_t)(L - 1) * BW, W, W, (const _Float16 *)inputs, in, in, gw);
+    if (rc || !batched) return rc;
+    for (uint32_t k = n_bt; k < (uint32_t)kMaxDw; k++) { bt.a[k] = bt.a[0]; bt.out[k] = nullptr; bt.nsplit[k] = 0; bt.blocks[k] = 0; }
+    hipLaunchKernelGGL(k_ffmlp_dw_batched, dim3(max_ns, max_blocks, n_bt), dim3(256), 0, st, bt);
+    hipLaunchKernelGGL(k_ffmlp_dw_reduce_batched, dim3(max_red, n_bt), dim3(256), 0, st, bt);
+    return sdn_launch_status();
 }
 
 }  // extern "C"
