@@ -84,7 +84,11 @@ def train_mode(args):
     target = torch.rand(1, n_rays, 3, generator=torch.Generator(device="cpu").manual_seed(2)).to(dev)
     graphed = bool(args.train_graph) and type(model).__name__ == "NeRFNetworkFF"
     # the graph needs the optimizer that takes GradScaler's found_inf on the device (fused + capturable Adam)
-    opt = torch.optim.Adam(model.get_params(1e-2, 1e-3), betas=(0.9, 0.99), eps=1e-15, **({"fused": True, "capturable": True} if graphed else {}))
+    groups = model.get_params(1e-2, 1e-3)
+    if graphed:
+        from dnerf_amd.train_graph import merged_param_groups
+        groups = merged_param_groups(groups)   # 4 non-empty groups -> 2 (table at lr, all MLP weights at lr_net): same update, fewer launches
+    opt = torch.optim.Adam(groups, betas=(0.9, 0.99), eps=1e-15, **({"fused": True, "capturable": True} if graphed else {}))
     scaler = torch.amp.GradScaler("cuda", enabled=not args.fp32)
 
     def step():

@@ -16,6 +16,19 @@ outside the graph with one small device copy.
 import torch
 
 
+def merged_param_groups(groups):
+    """Parameter groups with identical hyper-parameters folded into one (the reference's `get_params` returns seven groups with two
+    distinct learning rates, four of them non-empty): the same Adam, but the fused optimizer launches three kernels per GROUP."""
+    merged = {}
+    for g in groups:
+        params = list(g["params"])
+        if not params:
+            continue
+        key = tuple(sorted((k, v) for k, v in g.items() if k != "params"))
+        merged.setdefault(key, []).extend(params)
+    return [dict(key, params=params) for key, params in merged.items()]
+
+
 class GraphedTrainStep:
     def __init__(self, model, optimizer, scaler, n_rays, device, loss_fn=None, warmup=3, grad_sync=None, **render_kw):
         """grad_sync: a `dnerf_amd.dist.GradSync` for data-parallel training -- the step is then two graphs (forward + backward |

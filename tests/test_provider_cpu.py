@@ -135,3 +135,26 @@ def test_colmap_mode_splits_and_interpolated_test_cameras(tmp_path):
     assert "images" not in b and b["rays_o"].shape == (1, 60, 3)
     with pytest.raises(NotImplementedError):
         NeRFDataset(_opt(tmp_path / "nowhere"), "cpu", type="train")
+
+
+def test_merged_param_groups_is_the_same_adam():
+    """dnerf_amd/train_graph.merged_param_groups: groups with identical hyper-parameters folded together update identically."""
+    from dnerf_amd.train_graph import merged_param_groups
+    torch.manual_seed(0)
+    def make():
+        torch.manual_seed(1)
+        return [torch.nn.Parameter(torch.randn(5)) for _ in range(5)]
+    a, b = make(), make()
+    def groups(p):
+        return [{"params": [p[0]], "lr": 1e-2}, {"params": [p[1], p[2]], "lr": 1e-3}, {"params": [], "lr": 1e-2},
+                {"params": [p[3]], "lr": 1e-3}, {"params": [p[4]], "lr": 1e-2}]
+    merged = merged_param_groups(groups(b))
+    assert sorted((g["lr"], len(g["params"])) for g in merged) == [(1e-3, 3), (1e-2, 2)]
+    oa = torch.optim.Adam(groups(a), betas=(0.9, 0.99), eps=1e-15)
+    ob = torch.optim.Adam(merged, betas=(0.9, 0.99), eps=1e-15)
+    for step in range(3):
+        for p, q in zip(a, b):
+            g = torch.randn(5, generator=torch.Generator().manual_seed(10 * step + 3))
+            p.grad, q.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+    assert all(torch.equal(p, q) for p, q in zip(a, b))
