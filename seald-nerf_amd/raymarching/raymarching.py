@@ -132,9 +132,9 @@ class _march_rays_train(Function):
                 mean_count += align - mean_count % align
             M = mean_count
         dev = rays_o.device
-        xyzs = torch.zeros(M, 3, dtype=_f32, device=dev)
-        dirs = torch.zeros(M, 3, dtype=_f32, device=dev)
-        deltas = torch.zeros(M, 2, dtype=_f32, device=dev)
+        # zero-initialised like the reference's (slots past the emitted samples are evaluated by the network): one fill, three views
+        flat = torch.zeros(M * 8, dtype=_f32, device=dev)
+        xyzs, dirs, deltas = flat[:3 * M].view(M, 3), flat[3 * M:6 * M].view(M, 3), flat[6 * M:].view(M, 2)
         rays = torch.empty(N, 3, dtype=_i32, device=dev)
         if step_counter is None:
             step_counter = torch.zeros(2, dtype=_i32, device=dev)
@@ -187,8 +187,8 @@ class _composite_rays_train(Function):
         grad_image = grad_image.contiguous()
         sigmas, rgbs, deltas, rays, weights_sum, depth, image = ctx.saved_tensors
         M, N, T_thresh = ctx.dims
-        grad_sigmas = torch.zeros_like(sigmas)
-        grad_rgbs = torch.zeros_like(rgbs)
+        flat = torch.zeros(4 * M, dtype=sigmas.dtype, device=sigmas.device)    # one fill for both gradients
+        grad_sigmas, grad_rgbs = flat[:M], flat[M:].view(M, 3)
         _check(_lib.sdn_composite_rays_train_backward(_ptr(grad_weights_sum, _f32, "grad_weights_sum"), _ptr(grad_image, _f32, "grad_image"),
                                                       _ptr(sigmas), _ptr(rgbs), _ptr(deltas), _ptr(rays), _ptr(weights_sum), _ptr(image),
                                                       M, N, float(T_thresh), _ptr(grad_sigmas), _ptr(grad_rgbs), _stream()),
