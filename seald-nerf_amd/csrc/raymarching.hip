@@ -138,7 +138,8 @@ struct MarcherT {
                 const int bx = (nx >> 2) - fx0, by = (ny >> 2) - fy0, bz = (nz >> 2) - fz0;
                 if ((uint32_t)bx < (uint32_t)fnx && (uint32_t)by < (uint32_t)fny && (uint32_t)bz < (uint32_t)fnz) {
                     const uint32_t b = m2((uint32_t)nx & 3u) | (m2((uint32_t)ny & 3u) << 1) | (m2((uint32_t)nz & 3u) << 2);
-                    occ = (fine[(bz * fny + by) * fnx + bx] >> b) & 1ull;
+                    // (24-bit multiplies: full-rate v_mad_u32_u24 instead of quarter-rate v_mul_lo_u32; all factors < 32)
+                    occ = (fine[__umul24(__umul24((uint32_t)bz, (uint32_t)fny) + (uint32_t)by, (uint32_t)fnx) + (uint32_t)bx] >> b) & 1ull;
                 }
             } else if (!cull_bits || cull_marked(cull_bits, nx >> 2, ny >> 2, nz >> 2)) {
                 // an unmarked cull cell holds no occupied voxel: the fine bit (a dependent L2 load) is only fetched near the object
