@@ -207,3 +207,41 @@ def test_partial_update_invariants(scene):
     frozen = after.clone()
     m.update_extra_state()
     assert torch.equal(m.density_grid, frozen) and m.iter_density == 101
+
+
+def test_query_cells_against_the_cpu_oracle(scene):
+    """The cell query tied to the CPU oracle (oracle/field.py, fp16 mode): cell -> point in numpy with the reference's fp32 operation order
+    (dnerf/renderer.py:480-490), density through the oracle's field network, against the kernel's tmp_grid entries."""
+    from oracle import render as orender
+    from oracle.field import FieldOracle
+    from dnerf_amd import fused
+    m = scene.model
+    up = fused.DensityGridUpdater(m)
+    f = up.field
+    t = 0.37
+    f.set_time(torch.tensor([[t]], device="cuda"))
+    H3, G = m.grid_size ** 3, m.grid_size
+    rng = np.random.default_rng(5)
+    cells = np.sort(rng.choice(H3, 4096, replace=False)).astype(np.int32)
+    noise = rng.random((4096, 3), dtype=np.float32)
+    out = torch.full((H3,), -1.0, device="cuda")
+    cnt = torch.tensor([4096], dtype=torch.int32, device="cuda")
+    up.query_cells(out, f.bias0, f.zero_deform, 1.0, cells=torch.from_numpy(cells).cuda(), cell_count=cnt, noise=torch.from_numpy(noise).cuda())
+    got = out[torch.from_numpy(cells).long().cuda()].cpu().numpy()
+
+    def compact(v):        # Morton code -> coordinate (raymarching.cu:282-289)
+        v = v & 0x49249249
+        v = (v | (v >> 2)) & 0xc30c30c3
+        v = (v | (v >> 4)) & 0x0f00f00f
+        v = (v | (v >> 8)) & 0xff0000ff
+        return (v | (v >> 16)) & 0x0000ffff
+    c = cells.astype(np.uint32)
+    coords = np.stack([compact(c), compact(c >> 1), compact(c >> 2)], axis=1).astype(np.float32)
+    f32 = np.float32
+    half_grid = f32(1.0 / G)
+    pts = ((f32(2) * coords) * (f32(1) / f32(G - 1)) - f32(1)) * f32(1.0 - 1.0 / G) + (noise * f32(2) - f32(1)) * half_grid
+    dirs = np.tile(np.array([[0.0, 0.0, 1.0]], dtype=np.float32), (4096, 1))
+    sigma, _, _ = FieldOracle(orender.state_of(m), mode="fp16").forward(pts.astype(np.float32), dirs, t)
+    want = sigma * m.density_scale
+    rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
+    assert np.median(rel) < 2e-3 and rel.max() < 5e-2, (np.median(rel), rel.max())
