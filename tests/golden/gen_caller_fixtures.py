@@ -1,0 +1,405 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/caller_*.npz by EXECUTING THE REFERENCE'S OWN CALLER CODE in the build container.
+
+What runs (unmodified, imported from /root/reference, never copied):
+  * dnerf/renderer.py   NeRFRenderer.run_cuda (inference + training branch), NeRFRenderer.run (uniform sampler)
+  * dnerf/network.py    NeRFNetwork.__init__ / forward / density / color  (torch CPU nn.Linear GEMMs, fp32)
+  * SealDNeRF/renderer.py + SealDNeRF/network.py   the teacher's run_cuda (T_thresh 1e-4, seal-mapper hooks)
+  * SealNeRF/seal_utils.py   SealMapper.map_mask / map_color, SealBBoxMapper.map_to_origin, moller_trumbore, points_in_mesh,
+                             modify_hsv, modify_rgb   (pure torch)
+  * nerf/utils.py       get_rays (pure torch)
+What does NOT run: the reference's CUDA extensions.  `import raymarching / gridencoder / shencoder / freqencoder` resolve to
+the oracle-backed CPU shims of tests/ref_shims/ (see its README), and third-party packages the reference imports but the executed
+code never touches are empty modules (tests/ref_shims/stubs.py).  So these fixtures pin everything ABOVE the operator boundary --
+the loop schedule, padding, time-slice selection, t == 0 rule, network wiring, bg mixing, depth normalisation, mapper hooks --
+with the reference's own statements, on top of the oracle's operators.
+
+Scene: the synthetic jumpingjacks-like benchmark scene (dnerf_amd/scene.py, dnerf_amd/bench_scene.py) at 64x64; weights come from
+the reference's NeRFNetwork constructed under torch.manual_seed(0) + the three documented deterministic adjustments; the test
+side rebuilds the same state with dnerf_amd.bench_scene and checks it against the SHA-256 digests stored here.
+
+Run in the build container only:   python tests/golden/gen_caller_fixtures.py
+Nothing in tests/, smoke() or bench.py reads /root/reference at run time; only the .npz outputs travel.
+"""
+import hashlib
+import importlib.util
+import math
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests", "ref_shims"))
+import stubs  # noqa: E402
+
+stubs.install()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import raymarching as RM  # noqa: E402  (the shim)
+
+torch.set_grad_enabled(False)
+
+
+def _load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+scene = _load_by_path("sdn_scene", os.path.join(ROOT, "seald-nerf_amd", "dnerf_amd", "scene.py"))   # pure numpy scene spec
+
+MEDIAN_SIGMA_DT = 0.05
+SEED = 0
+TIMES = (0.5, 0.0, 0.26)           # slice 32, the canonical frame (slice 0, deformation forced to zero), slice 16
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def probe_points(bitfield_slice, n, seed):
+    """Same probe set as dnerf_amd/bench_scene.py:_probe_points (centres of occupied cells, seeded)."""
+    bits = np.unpackbits(bitfield_slice, bitorder="little")
+    occ = np.nonzero(bits)[0]
+    rng = np.random.default_rng(seed)
+    idx = occ[rng.integers(0, occ.shape[0], n)].astype(np.int32)
+    c = RM.morton3D_invert(torch.from_numpy(idx)).numpy().astype(np.float32)
+    return ((c + 0.5) * (2.0 / 128) - 1.0).astype(np.float32)
+
+
+def build_reference_model(cls, bound=1, kind="jumpingjacks", bg_radius=-1, **kw):
+    """The reference's NeRFNetwork under the bench scene's recipe (bench_scene.py:build_model / calibrate_density)."""
+    torch.manual_seed(SEED)
+    model = cls(bound=bound, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=bg_radius, **kw)
+    model.encoder.embeddings.mul_(1e3)
+    model.deform_net[-1].weight.mul_(0.05)
+    model.sigma_net[-1].weight[0].abs_()
+    model.eval()
+    slices = {int(min(max(math.floor(t * model.time_size), 0), model.time_size - 1)) for t in TIMES}
+    if model.cascade == 1:
+        bits = scene.density_bitfield_all_times(model.time_size, model.grid_size, kind, times=slices)
+    else:
+        bits = scene.density_bitfield_cascades(model.time_size, model.grid_size, model.cascade, float(bound), kind, times=slices)
+    model.density_bitfield.copy_(torch.from_numpy(bits))
+    # density calibration on slice 32 at time 0.5 with the reference's own density()
+    t_idx = 32
+    dt = 2 * math.sqrt(3) / 1024
+    pts = torch.from_numpy(probe_points(bits[t_idx][: model.grid_size ** 3 // 8], 8192, SEED))
+    sigma = model.density(pts, torch.tensor([[0.5]]))["sigma"]
+    med = float(torch.log(sigma).median())
+    assert med > 0
+    model.sigma_net[-1].weight[0].mul_(math.log(MEDIAN_SIGMA_DT / dt) / med)
+    return model, bits
+
+
+def camera_rays(H, W, azimuth=30.0, elevation=30.0):
+    pose = scene.look_at_pose(azimuth, elevation)
+    ro, rd = scene.get_rays(pose, scene.intrinsics(H, W), H, W)
+    return torch.from_numpy(ro)[None], torch.from_numpy(rd)[None], pose
+
+
+def run_infer(model, ro, rd, t, **kw):
+    RM.TRACE.clear()
+    RM.LAST.clear()
+    out = model.render(ro, rd, torch.tensor([[t]], dtype=torch.float32), staged=False, bg_color=None, perturb=False, **kw)
+    return dict(image=out["image"][0].numpy().copy(), depth=out["depth"][0].numpy().copy(), weights_sum=RM.LAST["weights_sum"].numpy().copy(),
+                trace=np.array(RM.TRACE, np.int32))
+
+
+def state_digests(model):
+    return {k: sha(v.detach().numpy()) for k, v in model.state_dict().items() if not k.startswith("density_grid")}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def gen_dnerf(out):
+    import dnerf.network as ref_network
+    model, bits = build_reference_model(ref_network.NeRFNetwork)
+    digests = state_digests(model)
+    out["scene"] = dict(seed=np.int32(SEED), times=np.array(TIMES, np.float32), sigma_last_row0=model.sigma_net[-1].weight[0].numpy().copy(),
+                        digest_keys=np.array(sorted(digests)), digest_vals=np.array([digests[k] for k in sorted(digests)]),
+                        bitfield_sha=np.array([sha(bits[32]), sha(bits[0]), sha(bits[16])]))
+    ro, rd, _ = camera_rays(64, 64)
+
+    # (1) run_cuda, inference branch: dnerf/renderer.py:261-386 with composite_rays' default T_thresh (1e-2)
+    infer = {}
+    for t in TIMES:
+        r = run_infer(model, ro, rd, t)
+        for k, v in r.items():
+            infer[f"t{t}_{k}"] = v
+        print(f"[dnerf infer t={t}] iterations {len(r['trace'])}, first rows {r['trace'][:3].tolist()}, image mean {r['image'].mean():.6f}")
+    # a second camera (rays that graze the figure from above)
+    ro2, rd2, _ = camera_rays(48, 80, azimuth=200.0, elevation=55.0)
+    r = run_infer(model, ro2, rd2, 0.5)
+    for k, v in r.items():
+        infer[f"cam2_{k}"] = v
+    out["infer"] = infer
+
+    # (2) forward / density on seeded points: dnerf/network.py:123-206
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(1024, 3, generator=g) * 2 - 1) * torch.tensor([0.45, 0.7, 0.3])
+    d = torch.nn.functional.normalize(torch.randn(1024, 3, generator=g), dim=-1)
+    fwd = dict(x=x.numpy(), d=d.numpy())
+    for t in (0.0, 0.5):
+        tt = torch.tensor([[t]], dtype=torch.float32)
+        s, c, de = model(x, d, tt)
+        dens = model.density(x, tt)
+        fwd.update({f"t{t}_sigma": s.numpy(), f"t{t}_rgb": c.numpy(), f"t{t}_deform": de.numpy(), f"t{t}_density_sigma": dens["sigma"].numpy(),
+                    f"t{t}_density_geo": dens["geo_feat"].numpy(), f"t{t}_density_deform": dens["deform"].numpy()})
+    out["forward"] = fwd
+
+    # (3) run (uniform sampler, dnerf/renderer.py:129-258) as main_dnerf.py:31-32 configures it, and with the NeRF-style upsampling
+    model.cuda_ray = False
+    uni = {}
+    for up in (0, 64):
+        r = model.render(ro, rd, torch.tensor([[0.5]]), staged=True, max_ray_batch=4096, bg_color=None, perturb=False, num_steps=128,
+                         upsample_steps=up)
+        uni[f"up{up}_image"], uni[f"up{up}_depth"] = r["image"][0].numpy().copy(), r["depth"][0].numpy().copy()
+    model.cuda_ray = True
+    out["uniform"] = uni
+
+    # (4) run_cuda, training branch + the loss of dnerf/utils.py:38-124 (MSE, main_dnerf.py:103) and its gradients
+    gen_train(model, ro, rd, out)
+    return model
+
+
+def gen_train(model, ro, rd, out):
+    model.train()
+    g = torch.Generator().manual_seed(5)
+    N = 1024
+    sel = torch.randint(0, ro.shape[1], (N,), generator=g)
+    ro_t, rd_t = ro[:, sel].contiguous(), rd[:, sel].contiguous()
+    target = torch.rand(1, N, 3, generator=g)
+    noises = torch.rand(N, generator=g).numpy().astype(np.float32)
+    tr = dict(sel=sel.numpy().astype(np.int32), target=target[0].numpy(), noises=noises)
+    time = torch.tensor([[0.5]])
+    # first: mean_count 0 (M = N * max_steps, trimmed after the counter read-back); perturb: per-ray start offsets; budget: the
+    # second-epoch sizing M = mean_count rounded up (raymarching.py:195-200); overflow: a budget too small, tail rays dropped
+    # (raymarching.cu:409, 525-533)
+    for name, perturb, mean_count in (("first", False, 0), ("perturb", True, 0), ("budget", True, None), ("overflow", True, 2000)):
+        model.zero_grad(set_to_none=True)
+        model.local_step = 0
+        model.step_counter.zero_()
+        if mean_count is None:      # the reference's second-epoch behaviour: M = mean_count rounded up (raymarching.py:195-200)
+            model.mean_count = int(tr["perturb_counter"][0])
+        else:
+            model.mean_count = mean_count
+        RM.NOISES["train"] = noises if perturb else None
+        captured = {}
+        orig = RM.march_rays_train
+
+        def spy(*a, **k):
+            r = orig(*a, **k)
+            captured["rays"], captured["M"] = r[3].numpy().copy(), r[0].shape[0]
+            return r
+        RM.march_rays_train = spy
+        try:
+            with torch.enable_grad():
+                res = model.render(ro_t, rd_t, time, staged=False, bg_color=1, perturb=perturb, force_all_rays=False)
+                loss = torch.nn.MSELoss(reduction="none")(res["image"], target).mean(-1).mean()
+                loss.backward()
+        finally:
+            RM.march_rays_train = orig
+            RM.NOISES["train"] = None
+        tr[f"{name}_image"], tr[f"{name}_depth"] = res["image"][0].detach().numpy().copy(), res["depth"][0].detach().numpy().copy()
+        tr[f"{name}_rays"], tr[f"{name}_M"] = captured["rays"], np.int32(captured["M"])
+        tr[f"{name}_counter"] = model.step_counter[0].numpy().copy()
+        tr[f"{name}_loss"] = np.float32(loss.item())
+        tr[f"{name}_deform_mean_abs"] = np.float32(res["deform"].abs().mean().item())
+        for pname, p in model.named_parameters():
+            if name not in ("perturb", "overflow"):
+                break
+            if pname == "encoder.embeddings":
+                ge = p.grad.numpy()
+                off = model.encoder.offsets.numpy()
+                lv = np.stack([[ge[off[l]:off[l + 1]].astype(np.float64).sum(), np.abs(ge[off[l]:off[l + 1]]).astype(np.float64).sum(),
+                                (ge[off[l]:off[l + 1]].astype(np.float64) ** 2).sum()] for l in range(off.shape[0] - 1)])
+                nz = np.nonzero(np.abs(ge).sum(1))[0]
+                pick = nz[np.random.default_rng(3).choice(nz.shape[0], min(16384, nz.shape[0]), replace=False)]
+                pick.sort()
+                tr[f"{name}_grad_emb_levels"], tr[f"{name}_grad_emb_rows"], tr[f"{name}_grad_emb_vals"] = lv, pick.astype(np.int32), ge[pick].copy()
+                tr[f"{name}_grad_emb_nnz_rows"] = np.int64(nz.shape[0])
+            elif name == "perturb":
+                tr[f"{name}_grad_{pname}"] = p.grad.numpy().copy()
+        print(f"[dnerf train {name}] samples {int(tr[f'{name}_counter'][0])}, M {captured['M']}, loss {loss.item():.6f}")
+    model.zero_grad(set_to_none=True)
+    model.eval()
+    model.mean_count, model.local_step = 0, 0
+    out["train"] = tr
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+SEAL_CONFIG = dict(type="bbox", boundType="to", scale=[1.0, 1.0, 1.0], hsv=[0.33, 0.0, 0.0],
+                   raw=[[-0.13, 0.34, -0.13], [0.13, 0.34, -0.13], [-0.13, 0.62, -0.13], [0.13, 0.62, -0.13],
+                        [-0.13, 0.34, 0.13], [0.13, 0.34, 0.13], [-0.13, 0.62, 0.13], [0.13, 0.62, 0.13]],
+                   transform=[[1, 0, 0, 0.35], [0, 1, 0, 0.0], [0, 0, 1, 0.0], [0, 0, 0, 1]])
+
+
+def box_geometry(cfg):
+    """from / to boxes of a bbox seal config whose `raw` points are axis-aligned cuboid corners: the data SealBBoxMapper.__init__
+    (seal_utils.py:168-243) derives through trimesh + pytorch3d (absent here).  Vertex k = lo + ((k&1) ex, (k>>1&1) ey, (k>>2) ez)."""
+    raw = np.asarray(cfg["raw"], np.float64)
+    lo, hi = raw.min(0), raw.max(0)
+    verts = np.stack([np.where([(k >> a) & 1 for a in range(3)], hi, lo) for k in range(8)])
+    faces = np.array([[0, 1, 3], [0, 3, 2], [4, 7, 5], [4, 6, 7], [0, 5, 1], [0, 4, 5], [2, 3, 7], [2, 7, 6], [0, 2, 6], [0, 6, 4], [1, 5, 7], [1, 7, 3]])
+    T = np.asarray(cfg["transform"], np.float64)
+    scale = np.asarray(cfg["scale"], np.float64)
+    c = verts.mean(0)
+    to = ((verts - c) * scale + c) @ T[:3, :3].T + T[:3, 3]
+    return verts, to, faces, c, T, scale
+
+
+def reference_bbox_mapper(SU, cfg):
+    """A reference `SealBBoxMapper` whose map_data / map_triangles are filled as its __init__ would (seal_utils.py:213-243) from
+    `box_geometry`; every METHOD that then runs (map_to_origin, map_mask, map_color, map_data_conversion) is the reference's."""
+    fv, tv, faces, c, T, scale = box_geometry(cfg)
+    m = SU.SealBBoxMapper.__new__(SU.SealBBoxMapper)
+    SU.SealMapper.__init__(m, cfg)
+    bnd = lambda v: np.stack([v.min(0), v.max(0)])   # noqa: E731
+    bt = cfg.get("boundType", "to")
+    fill = np.stack([bnd(tv), bnd(fv)])
+    if bt == "to":
+        bounds, tris = bnd(tv), tv[faces]
+    elif bt == "from":
+        bounds, tris = bnd(fv), fv[faces]
+    else:
+        bounds, tris = fill, np.concatenate([tv[faces], fv[faces]])
+    m.map_triangles = torch.from_numpy(tris)
+    m.map_data = {"force_fill_bound": fill, "map_bound": bounds, "pose_center": (c + tv.mean(0)) / 2,
+                  "pose_radius": np.linalg.norm(c - tv.mean(0), 2) * 10, "transform": np.linalg.inv(T), "rotation": np.linalg.inv(T[:3, :3]),
+                  "scale": 1 / scale, "center": c}
+    if "hsv" in cfg:
+        m.map_data["hsv"] = cfg["hsv"]
+    if "rgb" in cfg:
+        m.map_data["rgb"] = cfg["rgb"]
+        m.map_data["rgb_light_offset"] = cfg.get("rgbLightOffset", 0)
+    if cfg.get("mapSource"):
+        m.map_data["empty_bound"] = bnd(fv)
+        m.map_data["map_source"] = cfg["mapSource"]
+    m.map_data_conversion(force=True)
+    return m
+
+
+def gen_seald(out):
+    import SealDNeRF.network as seald_network
+    import SealNeRF.seal_utils as SU
+    model, bits = build_reference_model(seald_network.NeRFNetwork)
+    ro, rd, _ = camera_rays(64, 64)
+    s = {}
+    # teacher without a mapper: the same loop with T_thresh = 1e-4 and un-normalised depth (SealDNeRF/renderer.py:110-292)
+    r = run_infer(model, ro, rd, 0.5)
+    for k, v in r.items():
+        s[f"plain_{k}"] = v
+    # teacher with the bbox mapper (BASELINE config 4: head copied 0.35 aside + hue shift); the marcher must sample inside the target
+    # box, so its cells are marked occupied first (what the trainer's force-fill does): cells whose centre lies in force_fill_bound
+    mapper = reference_bbox_mapper(SU, SEAL_CONFIG)
+    filled = fill_bitfield_np(bits, mapper.map_data["force_fill_bound"].numpy())
+    model.density_bitfield.copy_(torch.from_numpy(filled))
+    model.seal_mapper = mapper
+    r = run_infer(model, ro, rd, 0.5)
+    for k, v in r.items():
+        s[f"mapped_{k}"] = v
+    s["filled_bitfield_sha"] = np.array(sha(filled[32]))
+    print(f"[seald] plain iterations {len(s['plain_trace'])}, mapped iterations {len(s['mapped_trace'])}, "
+          f"pixels changed by the edit {(np.abs(s['mapped_image'] - s['plain_image']).max(1) > 1e-3).sum()}")
+    out["seald"] = s
+
+    # pure-torch geometry / colour helpers on seeded inputs (seal_utils.py:132-153,245-286,638-693,747-777)
+    g = torch.Generator().manual_seed(21)
+    pts = (torch.rand(6000, 3, generator=g) * 2 - 1) * torch.tensor([0.7, 0.8, 0.4]) + torch.tensor([0.1, 0.2, 0.0])
+    pts[:8] = 0.0            # the reference's map_mask drops points with a zero coordinate (`points.all(1)`)
+    pts[8:16, 1] = 0.0
+    dirs = torch.nn.functional.normalize(torch.randn(6000, 3, generator=g), dim=-1)
+    h = {}
+    for name, cfg in (("to", SEAL_CONFIG),
+                      ("both_rot", dict(SEAL_CONFIG, boundType="both", scale=[1.3, 0.8, 1.1], rgb=[0.9, 0.2, 0.1], rgbLightOffset=0.05,
+                                        transform=_rot_transform(25.0, [0.3, -0.1, 0.05]))),
+                      ("from_src", dict(SEAL_CONFIG, boundType="from", mapSource=[0.5, 0.5, 0.5]))):
+        m = reference_bbox_mapper(SU, cfg)
+        p2, d2, mask = m.map_to_origin(pts.clone(), dirs.clone())
+        h[f"{name}_points"], h[f"{name}_dirs"], h[f"{name}_mask"] = p2.numpy().copy(), d2.numpy().copy(), mask.numpy().copy()
+        cols = torch.rand(int(mask.sum()), 3, generator=g)
+        h[f"{name}_colors_in"] = cols.numpy().copy()
+        h[f"{name}_colors_out"] = m.map_color(p2[mask], d2[mask], cols.clone()).numpy().copy()
+        h[f"{name}_tris"] = m.map_triangles.numpy().copy()
+    h["pts"], h["dirs"] = pts.numpy(), dirs.numpy()
+    tris = torch.from_numpy(h["both_rot_tris"]).float()
+    h["pim_default_dir"] = SU.points_in_mesh(pts, tris).numpy().copy()
+    h["mt_hits"] = SU.moller_trumbore(pts[:512], dirs[:512], tris).numpy().copy()
+    rgb = torch.rand(1024, 3, generator=g)
+    rgb[:16] = torch.round(rgb[:16] * 2) / 2
+    h["rgb"] = rgb.numpy().copy()
+    h["modify_hsv"] = SU.modify_hsv(rgb.clone(), torch.tensor([0.2, -0.1, 0.05])).numpy().copy()
+    h["modify_rgb"] = SU.modify_rgb(rgb.clone(), torch.tensor([0.2, 0.6, 0.9]), 0.1).numpy().copy()
+    out["seal_helpers"] = h
+
+
+def _rot_transform(deg, trans):
+    a = math.radians(deg)
+    T = np.eye(4)
+    T[:3, :3] = [[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]]
+    T[:3, 3] = trans
+    return T.tolist()
+
+
+def fill_bitfield_np(bits, bounds, H=128, bound=1.0):
+    """Cells (cascade 0) whose centre lies strictly inside one of `bounds` [B,2,3], OR-ed into every time slice."""
+    c = (np.arange(H, dtype=np.float32) + np.float32(0.5)) * np.float32(2.0 * bound / H) - np.float32(bound)
+    inside = np.zeros((H, H, H), bool)
+    for lo, hi in np.asarray(bounds, np.float32).reshape(-1, 2, 3):
+        m = [(c > lo[a]) & (c < hi[a]) for a in range(3)]
+        inside |= m[0][:, None, None] & m[1][None, :, None] & m[2][None, None, :]
+    ix, iy, iz = np.nonzero(inside)
+    idx = scene.morton3d(ix, iy, iz)
+    flat = np.zeros(H * H * H, np.uint8)
+    flat[idx] = 1
+    packed = np.packbits(flat.reshape(-1, 8), axis=1, bitorder="little").reshape(-1)
+    out = bits.copy()
+    out[:, : packed.shape[0]] |= packed[None]
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def gen_get_rays(out):
+    import nerf.utils as NU
+    g = {}
+    pose = torch.from_numpy(np.stack([scene.look_at_pose(30.0, 30.0), scene.look_at_pose(110.0, 10.0)]))
+    intr = scene.intrinsics(40, 56)
+    g["poses"], g["intrinsics"] = pose.numpy(), intr
+    r = NU.get_rays(pose, intr, 40, 56, -1)
+    g["all_rays_o"], g["all_rays_d"], g["all_inds"] = r["rays_o"].numpy(), r["rays_d"].numpy(), r["inds"].numpy() if "inds" in r else np.zeros(0)
+    torch.manual_seed(7)
+    r = NU.get_rays(pose, intr, 40, 56, 512)
+    g["rand_rays_o"], g["rand_rays_d"], g["rand_inds"] = r["rays_o"].numpy(), r["rays_d"].numpy(), r["inds"].numpy()
+    torch.manual_seed(8)
+    r = NU.get_rays(pose[:1], intr, 40, 56, 256, patch_size=8)
+    g["patch_rays_o"], g["patch_rays_d"], g["patch_inds"] = r["rays_o"].numpy(), r["rays_d"].numpy(), r["inds"].numpy()
+    torch.manual_seed(9)
+    err = torch.rand(1, 128 * 128, generator=torch.Generator().manual_seed(10))
+    r = NU.get_rays(pose[:1], intr, 40, 56, 300, error_map=err)
+    g["err_map"] = err.numpy()
+    g["err_rays_o"], g["err_rays_d"], g["err_inds"], g["err_inds_coarse"] = (r["rays_o"].numpy(), r["rays_d"].numpy(), r["inds"].numpy(),
+                                                                             r["inds_coarse"].numpy())
+    out["get_rays"] = g
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def main():
+    which = set(sys.argv[1:]) or {"dnerf", "seald", "get_rays"}
+    out = {}
+    if "dnerf" in which:
+        gen_dnerf(out)
+    if "seald" in which:
+        gen_seald(out)
+    if "get_rays" in which:
+        gen_get_rays(out)
+    for name, d in out.items():
+        path = os.path.join(HERE, f"caller_{name}.npz")
+        np.savez_compressed(path, **d)
+        print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()
