@@ -19,7 +19,11 @@ def state_of(model):
     return {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if not k.startswith("density_grid")}
 
 
-def render_frame_oracle(sc, mode="fp32", T_thresh=1e-2, max_steps=1024, dt_gamma=0.0, bg_color=1.0, field=None):
+def render_frame_oracle(sc, mode="fp32", T_thresh=1e-2, max_steps=1024, dt_gamma=0.0, bg_color=1.0, field=None, mapper=None,
+                        normalize_depth=True):
+    """`mapper` (optional): an object with the seal-mapper interface (`map_to_origin(points, dirs) -> points', dirs', mask` and
+    `map_color(points, dirs, colors)` on torch CPU tensors), hooked where SealDNeRF/renderer.py:245-267 hooks it.
+    `normalize_depth=False` returns the raw accumulated depth as the SealD teacher does (SealDNeRF/renderer.py:281)."""
     model = sc.model
     field = field or FieldOracle(state_of(model), bound=model.bound, density_scale=model.density_scale, mode=mode)
     ro = sc.rays_o.detach().cpu().numpy().reshape(-1, 3)
@@ -45,14 +49,23 @@ def render_frame_oracle(sc, mode="fp32", T_thresh=1e-2, max_steps=1024, dt_gamma
         sig = np.zeros(xyzs.shape[0], np.float32)
         rgb = np.zeros((xyzs.shape[0], 3), np.float32)
         if live.any():  # dead slots never reach the compositor (delta == 0 terminates the ray first)
-            s, c, _ = field.forward(xyzs[live], dirs[live], t)
+            qx, qd, mapped = xyzs[live], dirs[live], None
+            if mapper is not None:
+                import torch
+                px, pd, mapped = mapper.map_to_origin(torch.from_numpy(qx.copy()), torch.from_numpy(qd.copy()))
+                qx, qd, mapped = px.numpy(), pd.numpy(), mapped.numpy()
+            s, c, _ = field.forward(qx, qd, t)
+            if mapped is not None and mapped.any():
+                import torch
+                c = c.copy()
+                c[mapped] = mapper.map_color(torch.from_numpy(qx[mapped]), torch.from_numpy(qd[mapped]), torch.from_numpy(c[mapped])).numpy()
             sig[live], rgb[live] = s, c
         O.composite_rays(n_alive, n_step, alive, rays_t, sig, rgb, deltas, ws, dp, im, T_thresh)
         trace.append((n_alive, n_step, xyzs.shape[0]))
         alive = alive[alive >= 0]
         step += n_step
     image = im + (1 - ws)[:, None] * np.float32(bg_color)
-    depth = np.clip(dp - nears, 0, None) / (fars - nears)
+    depth = np.clip(dp - nears, 0, None) / (fars - nears) if normalize_depth else dp
     return {"image": image.astype(np.float32), "depth": depth.astype(np.float32), "weights_sum": ws, "trace": trace, "n_samples": n_samples}
 
 

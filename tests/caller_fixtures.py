@@ -48,3 +48,21 @@ def fixture_scene(device="cpu", H=64, W=64, time=0.5, azimuth=30.0, elevation=30
     t_idx = int(min(max(math.floor(time * model.time_size), 0), model.time_size - 1))
     return SimpleNamespace(model=model, rays_o=torch.from_numpy(ro).to(device), rays_d=torch.from_numpy(rd).to(device),
                            time=torch.tensor([[time]], dtype=torch.float32, device=device), H=H, W=W, t_idx=t_idx, bitfield=bits[t_idx])
+
+
+def fill_bitfield_host(bits, bounds, H=128, bound=1.0):
+    """numpy form of dnerf_amd.seal_mapper.fill_bitfield (cells of cascade 0 whose centre lies strictly inside one of `bounds`
+    [B,2,3], OR-ed into every time slice) -- the occupancy the edit fixtures were rendered with."""
+    from dnerf_amd import scene
+    c = (np.arange(H, dtype=np.float32) + np.float32(0.5)) * np.float32(2.0 * bound / H) - np.float32(bound)
+    inside = np.zeros((H, H, H), bool)
+    for lo, hi in np.asarray(bounds, np.float32).reshape(-1, 2, 3):
+        m = [(c > lo[a]) & (c < hi[a]) for a in range(3)]
+        inside |= m[0][:, None, None] & m[1][None, :, None] & m[2][None, None, :]
+    ix, iy, iz = np.nonzero(inside)
+    flat = np.zeros(H * H * H, np.uint8)
+    flat[scene.morton3d(ix, iy, iz)] = 1
+    packed = np.packbits(flat.reshape(-1, 8), axis=1, bitorder="little").reshape(-1)
+    out = bits.copy()
+    out[:, : packed.shape[0]] |= packed[None]
+    return out
