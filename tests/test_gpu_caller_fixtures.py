@@ -1,0 +1,190 @@
+"""GPU parity against what the REFERENCE'S OWN caller code produced (tests/golden/caller_*.npz; generated in the build container
+by tests/golden/gen_caller_fixtures.py from dnerf/renderer.py + dnerf/network.py + SealDNeRF/renderer.py running over oracle-backed
+operators).  Nothing of the reference is read here: fixtures are data.  Bars (north_star): ray / point indices and compaction
+counts bit-exact, fp32 image / depth / gradients 1e-4; the -O (fp16) paths at fp16 distance, stated per test."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from caller_fixtures import fill_bitfield_host, fixture_model, fixture_scene, load  # noqa: E402
+from test_caller_fixtures_cpu import SEAL_CONFIG  # noqa: E402
+
+CASES = [("t0.5", dict(time=0.5)), ("t0.0", dict(time=0.0)), ("t0.26", dict(time=0.26)),
+         ("cam2", dict(time=0.5, H=48, W=80, azimuth=200.0, elevation=55.0))]
+
+
+@pytest.fixture(scope="module")
+def model_bits():
+    return fixture_model("cuda")
+
+
+def _cmp_frame(out, fx, case, atol, trace=True):
+    if trace:
+        assert [tuple(r) for r in fx[f"{case}_trace"].tolist()] == [tuple(r) for r in out["trace"]]
+    img, dep, ws = out["image"].cpu().numpy(), out["depth"].cpu().numpy(), out["weights_sum"].cpu().numpy()
+    np.testing.assert_allclose(ws, fx[f"{case}_weights_sum"], rtol=0, atol=atol)
+    np.testing.assert_allclose(img, fx[f"{case}_image"], rtol=0, atol=atol)
+    miss = np.isnan(fx[f"{case}_depth"])
+    assert np.array_equal(miss, np.isnan(dep))
+    np.testing.assert_allclose(dep[~miss], fx[f"{case}_depth"][~miss], rtol=0, atol=atol)
+
+
+@pytest.mark.parametrize("case,kw", CASES)
+def test_hip_ops_loop_fp32_reproduces_reference_run_cuda(model_bits, case, kw):
+    """The reference-shaped loop (`model.render` = run_cuda's control flow) and the native `render_frame`, both on the HIP
+    operators with fp32 torch GEMMs."""
+    from dnerf_amd.renderer import render_frame
+    fx = load("infer")
+    sc = fixture_scene("cuda", model_bits=model_bits, **kw)
+    out = render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=False)
+    _cmp_frame(out, fx, case, 1e-4)
+    with torch.no_grad():
+        a = sc.model.render(sc.rays_o[None], sc.rays_d[None], sc.time, staged=False, perturb=False, bg_color=None)
+    np.testing.assert_allclose(a["image"][0].cpu().numpy(), fx[f"{case}_image"], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("case,kw", CASES)
+def test_native_device_loop_f16_reproduces_reference_run_cuda(model_bits, case, kw):
+    """The product path: fused MFMA field kernel (-O numerics) in the device-driven loop.  fp16 network => the per-iteration
+    survivor counts may differ by early-termination ties; image / depth within fp16 distance of the reference's fp32 render."""
+    from dnerf_amd.fused import FusedField
+    from dnerf_amd.renderer import DeviceLoop
+    fx = load("infer")
+    sc = fixture_scene("cuda", model_bits=model_bits, **kw)
+    field = FusedField(sc.model, sc.time)
+    loop = DeviceLoop(sc.model, field, sc.rays_o.shape[0], "cuda")
+    out = loop.render(sc.rays_o, sc.rays_d, sc.time)
+    torch.cuda.synchronize()
+    ref_tr, tr = fx[f"{case}_trace"], np.array(out["trace"])
+    assert tuple(tr[0]) == tuple(ref_tr[0]) and abs(len(tr) - len(ref_tr)) <= 1
+    assert np.abs(tr[:len(ref_tr), 0] - ref_tr[:len(tr), 0]).max() <= 3
+    img = out["image"].cpu().numpy()
+    assert np.abs(img - fx[f"{case}_image"]).max() < 2e-2 and np.abs(img - fx[f"{case}_image"]).mean() < 2e-4
+    dep, miss = out["depth"].cpu().numpy(), np.isnan(fx[f"{case}_depth"])
+    assert np.array_equal(miss, np.isnan(dep)) and np.abs(dep[~miss] - fx[f"{case}_depth"][~miss]).max() < 2e-2
+
+
+@pytest.mark.parametrize("t", [0.0, 0.5])
+def test_field_network_reproduces_reference_forward(model_bits, t):
+    from dnerf_amd.fused import FusedField
+    fx = load("forward")
+    model, _ = model_bits
+    x, d = torch.from_numpy(fx["x"]).cuda(), torch.from_numpy(fx["d"]).cuda()
+    tt = torch.tensor([[t]], dtype=torch.float32, device="cuda")
+    with torch.no_grad():
+        sigma, rgb, deform = model(x, d, tt)
+        dens = model.density(x, tt)
+    np.testing.assert_allclose(sigma.cpu().numpy(), fx[f"t{t}_sigma"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(rgb.cpu().numpy(), fx[f"t{t}_rgb"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(deform.cpu().numpy(), fx[f"t{t}_deform"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(dens["sigma"].cpu().numpy(), fx[f"t{t}_density_sigma"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(dens["geo_feat"].cpu().numpy(), fx[f"t{t}_density_geo"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(dens["deform"].cpu().numpy(), fx[f"t{t}_density_deform"], rtol=1e-4, atol=1e-6)
+    # fused -O kernel: fp16 weights / activations / table => a few fp16 ulps on the logit; sigma = exp(logit) in [~1, ~50]
+    field = FusedField(model, tt)
+    s16, c16 = field(x, d)
+    rel = (s16.cpu().numpy() - fx[f"t{t}_sigma"]) / np.maximum(fx[f"t{t}_sigma"], 1e-3)
+    assert np.abs(rel).max() < 5e-2 and np.abs(rel).mean() < 5e-3
+    assert np.abs(c16.cpu().numpy() - fx[f"t{t}_rgb"]).max() < 1e-2
+
+
+def test_seald_teacher_native_loop_reproduces_reference(model_bits):
+    """BASELINE config 4 at 64x64: T_thresh 1e-4, bbox seal mapper (head copied 0.35 aside + hue shift) on the sample stream."""
+    from dnerf_amd.fused import FusedField
+    from dnerf_amd.renderer import DeviceLoop, render_frame
+    from dnerf_amd.seal_mapper import SealBBoxMapper
+    fx = load("seald")
+    model, bits = model_bits
+    sc = fixture_scene("cuda", model_bits=model_bits)
+    keep = model.density_bitfield.clone()
+    try:
+        out = render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=False, T_thresh=1e-4)
+        assert fx["plain_trace"].tolist() == [list(r) for r in out["trace"]]
+        np.testing.assert_allclose(out["image"].cpu().numpy(), fx["plain_image"], rtol=0, atol=1e-4)
+        mapper = SealBBoxMapper(SEAL_CONFIG)
+        filled = fill_bitfield_host(bits, mapper.map_data["force_fill_bound"].cpu().numpy())
+        model.density_bitfield.copy_(torch.from_numpy(filled))
+        out = render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=False, T_thresh=1e-4, mapper=mapper)
+        assert fx["mapped_trace"].tolist() == [list(r) for r in out["trace"]]
+        np.testing.assert_allclose(out["image"].cpu().numpy(), fx["mapped_image"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(out["weights_sum"].cpu().numpy(), fx["mapped_weights_sum"], rtol=0, atol=1e-4)
+        raw_depth = out["depth"] * (out["fars"] - out["nears"]) + out["nears"]      # the teacher returns the un-normalised depth
+        hit = fx["mapped_weights_sum"] > 0.5
+        np.testing.assert_allclose(raw_depth.cpu().numpy()[hit], fx["mapped_depth"][hit], rtol=1e-3, atol=1e-3)
+        # product path: seal kernels inside the native frame driver, fused -O field
+        field = FusedField(sc.model, sc.time)
+        loop = DeviceLoop(sc.model, field, sc.rays_o.shape[0], "cuda", T_thresh=1e-4, mapper=mapper)
+        fast = loop.render(sc.rays_o, sc.rays_d, sc.time)
+        torch.cuda.synchronize()
+        img = fast["image"].cpu().numpy()
+        assert np.abs(img - fx["mapped_image"]).max() < 2e-2 and np.abs(img - fx["mapped_image"]).mean() < 2e-4
+        assert abs(len(fast["trace"]) - len(fx["mapped_trace"])) <= 1
+    finally:
+        model.density_bitfield.copy_(keep)
+
+
+def _train_once(model, fx, name, perturb, mean_count, monkeypatch):
+    import raymarching.raymarching as rm_mod
+    noises = torch.from_numpy(fx["noises"]).cuda()
+    real_rand = torch.rand
+
+    def fake_rand(*size, **kw):      # the operator draws its per-ray offsets with torch.rand(N): replay the fixture's
+        n = size[0] if len(size) == 1 and isinstance(size[0], int) else None
+        return noises.clone() if n == noises.shape[0] else real_rand(*size, **kw)
+    monkeypatch.setattr(rm_mod.torch, "rand", fake_rand)
+    sc = fixture_scene("cuda", model_bits=(model, None))
+    sel = torch.from_numpy(fx["sel"]).long().cuda()
+    ro, rd = sc.rays_o[sel][None].contiguous(), sc.rays_d[sel][None].contiguous()
+    target = torch.from_numpy(fx["target"]).cuda()[None]
+    model.train()
+    model.zero_grad(set_to_none=True)
+    model.local_step, model.mean_count = 0, mean_count
+    model.step_counter.zero_()
+    res = model.render(ro, rd, sc.time, staged=False, bg_color=1, perturb=perturb, force_all_rays=False)
+    loss = torch.nn.MSELoss(reduction="none")(res["image"], target).mean(-1).mean()
+    loss.backward()
+    model.eval()
+    monkeypatch.undo()
+    return res, loss
+
+
+@pytest.mark.parametrize("name,perturb", [("first", False), ("perturb", True), ("budget", True), ("overflow", True)])
+def test_training_branch_reproduces_reference(model_bits, name, perturb, monkeypatch):
+    """run_cuda's training branch (dnerf/renderer.py:289-330) + the MSE loss of dnerf/utils.py:38-124: sample counts and the
+    per-ray (offset, count) table exact, image / loss 1e-4, and -- where the fixture holds them -- every MLP weight gradient and
+    the hash-grid gradient against the reference network's own autograd."""
+    fx = load("train")
+    model, _ = model_bits
+    mean_count = {"first": 0, "perturb": 0, "budget": int(fx["perturb_counter"][0]), "overflow": 2000}[name]
+    try:
+        res, loss = _train_once(model, fx, name, perturb, mean_count, monkeypatch)
+        assert model.step_counter[0].cpu().numpy().tolist() == fx[f"{name}_counter"].tolist()
+        np.testing.assert_allclose(res["image"][0].detach().cpu().numpy(), fx[f"{name}_image"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(float(loss), float(fx[f"{name}_loss"]), rtol=1e-4)
+        dep, ref_dep = res["depth"][0].detach().cpu().numpy(), fx[f"{name}_depth"]
+        assert np.array_equal(np.isnan(dep), np.isnan(ref_dep))
+        np.testing.assert_allclose(np.nan_to_num(dep), np.nan_to_num(ref_dep), rtol=0, atol=1e-4)
+        if name in ("perturb", "overflow"):
+            ge = model.encoder.embeddings.grad.cpu().numpy()
+            off = model.encoder.offsets.cpu().numpy()
+            lv = np.stack([[ge[off[l]:off[l + 1]].astype(np.float64).sum(), np.abs(ge[off[l]:off[l + 1]]).astype(np.float64).sum(),
+                            (ge[off[l]:off[l + 1]].astype(np.float64) ** 2).sum()] for l in range(16)])
+            ref_lv = fx[f"{name}_grad_emb_levels"]
+            np.testing.assert_allclose(lv[:, 1:], ref_lv[:, 1:], rtol=1e-4)
+            np.testing.assert_allclose(lv[:, 0], ref_lv[:, 0], rtol=0, atol=1e-4 * ref_lv[:, 1].max())
+            rows = fx[f"{name}_grad_emb_rows"]
+            scale = float(np.abs(fx[f"{name}_grad_emb_vals"]).max())
+            np.testing.assert_allclose(ge[rows], fx[f"{name}_grad_emb_vals"], rtol=1e-4, atol=1e-4 * scale)
+            assert int((np.abs(ge).sum(1) != 0).sum()) == int(fx[f"{name}_grad_emb_nnz_rows"])
+        if name == "perturb":
+            for pname, p in model.named_parameters():
+                if pname == "encoder.embeddings":
+                    continue
+                ref = fx[f"{name}_grad_{pname}"]
+                np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-3, atol=1e-4 * float(np.abs(ref).max()), err_msg=pname)
+    finally:
+        model.zero_grad(set_to_none=True)
+        model.eval()
+        model.mean_count, model.local_step = 0, 0
