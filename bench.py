@@ -28,6 +28,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA
 GRID_BYTES_PER_POINT = {"f16": 588.0, "f32": 1164.0}  # gathers + 12 B in + outputs
 FIELD_FLOP_PER_POINT = 235520.0                          # 117 760 MAC
+PMC_SUMMARY = "r02_field_pmc_summary.json"               # rocprofv3 --pmc summary the static `traffic` figure comes from
 
 
 def parse():
@@ -47,7 +48,13 @@ def parse():
                          "0 = strictly one frame at a time)")
     ap.add_argument("--contexts", type=int, default=4, help="--pipeline: loop contexts (frames in flight); the HIP runtime is given one "
                                                             "hardware queue per context + the default stream (GPU_MAX_HW_QUEUES, if unset)")
-    ap.add_argument("--groups", type=int, default=1, help="device loop only: render the frame as G interleaved ray groups on G streams")
+    ap.add_argument("--cameras", type=int, default=20, help="frames of the test sequence (camera orbit + time ramp 0..1); the timed steps cycle through it")
+    ap.add_argument("--static-frame", action="store_true", help="render ONE camera at t = 0.5 over and over (the round-1 workload) instead of the sequence")
+    ap.add_argument("--group-frames", type=int, default=0, help="frames rendered together by one loop (frame group); 0 = --gpus (1 on one GPU); "
+                                                                 "reduced to a divisor of --steps")
+    ap.add_argument("--emulate-rank-of", type=int, default=1, metavar="N",
+                    help="one GPU only: render rank 0's shard of an N-way ray split of every frame (what one rank of --gpus N does, without "
+                         "the gathers) -- to measure shard-sized loops / frame groups on one GPU; rays_per_s then counts shard rays")
     ap.add_argument("--mode", default="render", choices=["render", "train", "seald", "seald-train", "density"],
                     help="render: the headline 800x800 inference frame; train: one dnerf training step on 4096 rays (BASELINE config 3)")
     ap.add_argument("--scene", default="jumpingjacks", choices=["jumpingjacks", "lego"],
@@ -372,22 +379,48 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    from dnerf_amd.bench_scene import build_scene
+    from dnerf_amd.bench_scene import build_scene, camera_path
     from dnerf_amd.renderer import render_frame, FrameWorkspace
     from dnerf_amd import fused
 
     fp16 = not args.fp32
     sc = build_scene(H=args.size, W=args.size, device=dev, seed=0, kind=args.scene)
     n_total = sc.rays_o.shape[0]
-    if world > 1:
-        from dnerf_amd.dist import shard_rays, FrameGather
-        idx, per = shard_rays(n_total, args.size, rank, world)
-        idx_t = torch.from_numpy(idx).to(dev)
-        rays_o, rays_d = sc.rays_o[idx_t].contiguous(), sc.rays_d[idx_t].contiguous()
-        gather = FrameGather(n_total, args.size, world, dev)
+    K = args.steps
+    # The workload: a D-NeRF test sequence -- one camera pose AND one time stamp per frame (dnerf/provider.py test split,
+    # dnerf/utils.py:151-161; slice select dnerf/renderer.py:285): the camera orbits once while t runs 0 -> 1 over `--cameras` frames,
+    # repeated when --steps is larger.  --static-frame renders one camera at t = 0.5 over and over instead (the round-1 workload).
+    n_cams = 1 if args.static_frame else max(1, min(args.cameras, K))
+    if args.static_frame:
+        cam_o, cam_d, cam_t = [sc.rays_o], [sc.rays_d], [0.5]
     else:
-        rays_o, rays_d = sc.rays_o, sc.rays_d
-    n_local = rays_o.shape[0]
+        cam_o, cam_d, cam_t = camera_path(sc, n_cams, dev)
+    gather = None
+    if world > 1 or args.emulate_rank_of > 1:
+        # ray-parallel: this rank renders its interleaved 16x16 tiles of EVERY frame
+        from dnerf_amd.dist import shard_rays, FrameGather
+        parts = world if world > 1 else args.emulate_rank_of
+        idx, per = shard_rays(n_total, args.size, rank if world > 1 else 0, parts)
+        idx_t = torch.from_numpy(idx).to(dev)
+        cam_o = [r[idx_t].contiguous() for r in cam_o]
+        cam_d = [r[idx_t].contiguous() for r in cam_d]
+        if world > 1:
+            gather = FrameGather(n_total, args.size, world, dev)
+    n_local = cam_o[0].shape[0]
+    # Frame groups: F consecutive frames' shards rendered by ONE loop (per-ray time constants), so that the ~30 dependent launches
+    # of a loop are paid once per F frames; default F = gpus (a rank's batch keeps the size of one full frame), 1 on one GPU.
+    want_f = args.group_frames if args.group_frames > 0 else (world if world > 1 else 1)
+    F = max(d for d in range(1, min(want_f, 16) + 1) if K % d == 0)
+    n_groups = K // F
+    frame_cam = [f % n_cams for f in range(K)]
+    if F == 1:
+        grp_o, grp_d = [cam_o[c] for c in frame_cam], [cam_d[c] for c in frame_cam]
+        grp_t = [cam_t[c] for c in frame_cam]
+    else:
+        grp_o = [torch.cat([cam_o[frame_cam[g * F + i]] for i in range(F)]).contiguous() for g in range(n_groups)]
+        grp_d = [torch.cat([cam_d[frame_cam[g * F + i]] for i in range(F)]).contiguous() for g in range(n_groups)]
+        grp_t = [[cam_t[frame_cam[g * F + i]] for i in range(F)] for g in range(n_groups)]
+    n_loop = n_local * F
     ws = FrameWorkspace(n_local, dev)
     field_kind = args.field
     if field_kind == "auto":
@@ -400,16 +433,15 @@ def main():
         loop_kind = "device" if field is not None else "host"
     dloop = None
     if loop_kind == "device":
-        from dnerf_amd.renderer import DeviceLoop, GroupedDeviceLoop
-        if args.groups > 1:
-            dloop = GroupedDeviceLoop(sc.model, field, rays_o, rays_d, args.groups, args.size, dev)
-        else:
-            dloop = DeviceLoop(sc.model, field, n_local, dev)
+        from dnerf_amd.renderer import DeviceLoop
+        dloop = DeviceLoop(sc.model, field, n_loop, dev, frames=F)
+    elif F > 1:
+        raise SystemExit("frame groups need the device loop (fused field)")
 
     ploop = None
-    if args.pipeline > 0 and dloop is not None and args.groups == 1:
+    if args.pipeline > 0 and dloop is not None:
         from dnerf_amd.renderer import PipelinedDeviceLoop
-        ploop = PipelinedDeviceLoop(sc.model, field, n_local, dev, overlap_div=args.pipeline, contexts=args.contexts)
+        ploop = PipelinedDeviceLoop(sc.model, field, n_loop, dev, overlap_div=args.pipeline, contexts=args.contexts, frames=F)
 
     def make_timing(frames):
         """Event pairs (created outside the timed region) for the field launches of `frames` instrumented frames."""
@@ -427,11 +459,19 @@ def main():
         torch.cuda.synchronize()
         return out
 
+    def gather_outputs(img, dep):
+        """One RCCL all-gather per FRAME (+ local un-permute), for single frames and for the frames of a group alike."""
+        if F == 1:
+            gather(img, dep)
+        else:
+            gather.gather_group(img, dep, F)
+
     def stream_of_frames(k, every=0):
-        """k frames through the pipelined driver; every > 0: the field launches of every `every`-th frame are timed in place."""
-        # instrumented frames: the first (and in a long stream the last) frame is rendered with nothing else in flight -- the
-        # pipeline is empty / draining there anyway -- and its launch durations are the kernel's own (the roofline figure); every
-        # `every`-th frame in between is instrumented while it overlaps like all the others (a launch while it shares the device)
+        """The first k loops (frames, or frame groups) of the sequence through the pipelined driver; every > 0: the field launches of
+        every `every`-th loop are timed in place."""
+        # instrumented loops: the first (and in a long stream the last) is rendered with nothing else in flight -- the pipeline is
+        # empty / draining there anyway -- and its launch durations are the kernel's own (the roofline figure); every `every`-th loop
+        # in between is instrumented while it overlaps like all the others (a launch while it shares the device)
         excl_set = exclusive_frames(k)
         marked = sorted(set(range(0, k, every)) | excl_set) if every else []
         timing = make_timing(len(marked))
@@ -441,17 +481,17 @@ def main():
             per_frame[f] = next(it)
             exclusive[f] = f in excl_set
         outputs = None
-        if world > 1:  # every frame keeps its own shard output until it has been gathered
-            outputs = [(torch.empty(n_local, 3, dtype=torch.float32, device=dev), torch.empty(n_local, dtype=torch.float32, device=dev))
+        if world > 1:  # every loop keeps its own shard output until it has been gathered
+            outputs = [(torch.empty(n_loop, 3, dtype=torch.float32, device=dev), torch.empty(n_loop, dtype=torch.float32, device=dev))
                        for _ in range(k)]
         barrier()
         t0 = time.perf_counter()
-        outs, iters = ploop.render_frames([rays_o] * k, [rays_d] * k, sc.time, outputs=outputs,
+        outs, iters = ploop.render_frames(grp_o[:k], grp_d[:k], grp_t[:k], outputs=outputs,
                                           timing=[p[0] if p else None for p in per_frame] if every else None,
                                           exclusive=exclusive if every else None)
         if world > 1:
             for img, dep in outs:
-                gather(img, dep)  # one RCCL all-gather per frame + local un-permute, issued behind the renders
+                gather_outputs(img, dep)  # issued behind the renders
         t1 = time.perf_counter()
         barrier()
         elapsed = time.perf_counter() - t0
@@ -463,24 +503,33 @@ def main():
                 timers.records.setdefault(key, []).extend(p[1][: min(DeviceLoop.MAX_TIMED, iters[f])])
         return elapsed, outs
 
-    def step(count=False, timed=False):
+    def time_tensor(t):
+        return torch.tensor([[t]], dtype=torch.float32, device=dev)
+
+    def step(g=0, count=False, timed=False):
+        """Loop g of the sequence, one at a time."""
         sdn_backend.timers = timers if timed else None  # HIP events around the tracked launches, timed steps only
-        if dloop is not None and args.groups > 1:
-            out = dloop.render(sc.time, want_stats=count)
-        elif dloop is not None:
-            out = dloop.render(rays_o, rays_d, sc.time, want_stats=count)
+        if dloop is not None:
+            out = dloop.render(grp_o[g], grp_d[g], grp_t[g], want_stats=count)
         else:
-            out = render_frame(sc.model, rays_o, rays_d, sc.time, fp16=fp16, workspace=ws, field=field, count_samples=count)
+            out = render_frame(sc.model, grp_o[g], grp_d[g], time_tensor(grp_t[g]), fp16=fp16, workspace=ws, field=field, count_samples=count)
         sdn_backend.timers = None
         if world > 1:
-            gather(out["image"], out["depth"])  # one RCCL all-gather per frame + local un-permute
+            gather_outputs(out["image"], out["depth"])
         return out
 
-    # untimed: sample count of this rank's shard (deterministic), then warm-up
-    first = step(count=True)
-    n_samples_local, n_iters = first["n_samples"], len(first["trace"])
-    for _ in range(args.warmup):
-        step()
+    # untimed: the whole sequence once, one loop at a time, with statistics: this rank's sample counts (deterministic); also a warm-up
+    n_samples_local, n_iters_sum, distinct = 0, 0, {}
+    for g in range(n_groups):
+        key = tuple(frame_cam[g * F:(g + 1) * F])
+        if key not in distinct:
+            st = step(g, count=True)
+            distinct[key] = (st["n_samples"], len(st["trace"]))
+        n_samples_local += distinct[key][0]
+        n_iters_sum += distinct[key][1]
+    n_iters = n_iters_sum / n_groups
+    for i in range(args.warmup):
+        step(i % n_groups)
 
     def barrier():
         if world > 1:
@@ -488,7 +537,7 @@ def main():
         torch.cuda.synchronize()
 
     every = max(1, args.time_every)
-    n_instrumented = len(range(0, args.steps, every))
+    n_instrumented = len(range(0, n_groups, every))
     # A generation-2 pass of CPython's cyclic collector costs tens of milliseconds with torch + numpy loaded and fires on allocation
     # counts, i.e. inside the timed region for some argument combinations and not for others (seen: 20 frames in 14 ms of driver
     # time reported as 50-78 ms).  Collect now and keep the collector off while the clock runs, as `timeit` does.
@@ -496,17 +545,28 @@ def main():
     gc.collect()
     gc.disable()
     if ploop is not None:
-        stream_of_frames(max(args.contexts, args.warmup))           # warm every context
-        elapsed, _ = stream_of_frames(args.steps, every)
+        stream_of_frames(min(n_groups, max(args.contexts, args.warmup)))           # warm every context
+        elapsed, _ = stream_of_frames(n_groups, every)
     else:
         if dloop is not None:
             dloop.prepare_timing(n_instrumented)  # event pairs for the in-place timing of the fused-field launches, created up front
         barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(timed=(i % every == 0))
+        for i in range(n_groups):
+            step(i, timed=(i % every == 0))
         barrier()
         elapsed = time.perf_counter() - t0
+    # latency of ONE loop with nothing else in flight (what --pipeline 0 reports as ms_per_step), same sequence, after the timed region
+    latency_ms = None
+    if dloop is not None:
+        lat = []
+        for g in range(min(n_groups, 8)):
+            barrier()
+            t0 = time.perf_counter()
+            step(g)
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t0) * 1e3)
+        latency_ms = sorted(lat)[len(lat) // 2]
     gc.enable()
     if world > 1:
         cdev = "cpu" if rehearse else dev
@@ -518,36 +578,49 @@ def main():
         n_samples = int(ns.item())
     else:
         n_samples = n_samples_local
-    ms_per_step = elapsed / args.steps * 1e3
-    points_per_s = n_samples * args.steps / elapsed
-    rays_per_s = n_total * args.steps / elapsed
+    ms_per_step = elapsed / K * 1e3
+    points_per_s = n_samples / elapsed
+    n_rays_frame = n_total if args.emulate_rank_of <= 1 else n_local
+    rays_per_s = n_rays_frame * K / elapsed
 
+    seq = ("one camera at t = 0.5, repeated" if args.static_frame else
+           f"test sequence of {n_cams} frames (camera orbit, one time stamp per frame, t = 0 .. 1: every frame selects its own occupancy "
+           f"slice, time encoding and the t == 0 canonical rule)")
     result = {
         "metric": METRIC, "value": points_per_s, "unit": "sampled-points/s", "rays_per_s": rays_per_s,
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f16" if fp16 else "f32", "data": "synthetic",
+        "latency_ms_one_loop_at_a_time": latency_ms,
         "config": {"workload": f"dnerf {args.scene}-like {args.size}x{args.size} full-frame inference render, "
-                               f"{'-O (fp16 field network, fp16 grid table)' if fp16 else 'fp32'}, 1 timestep (t=0.5), "
+                               f"{'-O (fp16 field network, fp16 grid table)' if fp16 else 'fp32'}, {seq}, "
                                f"T_thresh 1e-2, max_steps 1024, dt_gamma 0",
-                   "rays": n_total, "sampled_points_per_frame": n_samples, "loop_iterations": n_iters,
-                   "field": field_kind, "loop": loop_kind, "ray_groups": args.groups,
-                   "frames_in_flight": ("%d (the next frame starts when the newest one is down to rays/%d alive)" % (args.contexts, args.pipeline)) if ploop is not None else 1, "parallelism": (f"ray-tiles x{world}" + (" (ONE-GPU REHEARSAL, numbers invalid)" if rehearse else "")) if world > 1 else "single GPU"},
+                   "rays": n_total, "sampled_points_per_frame": n_samples / K, "loop_iterations": n_iters,
+                   "field": field_kind, "loop": loop_kind, "frames_per_loop": F,
+                   "rays_per_loop_on_this_gpu": n_loop,
+                   "frames_in_flight": ("%d loops of %d frame(s) (the next starts when the newest is down to rays/%d alive)" % (args.contexts, F, args.pipeline)) if ploop is not None else F,
+                   "parallelism": (f"ray-tiles x{world}, {F} frames per loop, one all_gather_into_tensor per frame" + (" (ONE-GPU REHEARSAL, numbers invalid)" if rehearse else "")) if world > 1
+                                  else ("single GPU" + (f" rendering rank 0's shard of a {args.emulate_rank_of}-way ray split (NOT a whole-frame figure)" if args.emulate_rank_of > 1 else ""))},
     }
     if rank == 0:
         if ploop is not None:
-            marked = sorted(set(range(0, args.steps, every)) | exclusive_frames(args.steps))
-            n_instrumented, n_excl = len(marked), len(exclusive_frames(args.steps))
+            marked = sorted(set(range(0, n_groups, every)) | exclusive_frames(n_groups))
+            n_instrumented, n_excl = len(marked), len(exclusive_frames(n_groups))
+            excl_samples = sum(distinct[tuple(frame_cam[g * F:(g + 1) * F])][0] for g in exclusive_frames(n_groups))
+            over_samples = sum(distinct[tuple(frame_cam[g * F:(g + 1) * F])][0] for g in marked if g not in exclusive_frames(n_groups))
         else:
+            marked = list(range(0, n_groups, every))
             n_excl = n_instrumented
-        result["roofline"], result["kernel_times"] = roofline(timers, fp16, n_samples_local, n_iters, n_excl, n_instrumented - n_excl)
+            excl_samples = sum(distinct[tuple(frame_cam[g * F:(g + 1) * F])][0] for g in marked)
+            over_samples = 0
+        result["roofline"], result["kernel_times"] = roofline(timers, fp16, excl_samples, over_samples)
         if result["roofline"]:
             result["roofline"]["instrumented_steps"] = (
-                f"{n_instrumented} of {args.steps} timed steps (every {every}th" + (", plus the last" if ploop is not None else "") + ")"
+                f"{n_instrumented} of {n_groups} timed loops (every {every}th" + (", plus the last" if ploop is not None else "") + ")"
                 + (f"; {n_excl} of them (the first" + (" and the last" if n_excl > 1 else "") + ") rendered with nothing else in flight -- their launches give achieved / frac -- and "
-                   f"{n_instrumented - n_excl} overlapped like the uninstrumented steps (the `overlapped` entry)" if ploop is not None else ""))
+                   f"{n_instrumented - n_excl} overlapped like the uninstrumented ones (the `overlapped` entry)" if ploop is not None else ""))
             # field FLOPs of the whole timed region over its wall time: a lower bound of the kernel's rate that no overlap can inflate
-            result["roofline"]["whole_job_mfma_frac"] = FIELD_FLOP_PER_POINT * n_samples * args.steps / elapsed / 1e12 / MFMA_F16_PEAK_TFLOPS
+            result["roofline"]["whole_job_mfma_frac"] = FIELD_FLOP_PER_POINT * n_samples / elapsed / 1e12 / MFMA_F16_PEAK_TFLOPS
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sc, args.cpu_baseline_side)
         print(json.dumps(result))
@@ -561,19 +634,19 @@ def exclusive_frames(k):
     return {0, k - 1} if k >= 16 else {0}
 
 
-def roofline(timers, fp16, n_samples, n_iters, steps, steps_overlapped=0):
+def roofline(timers, fp16, points_exclusive, points_overlapped=0):
     """Roofline entry of the dominant TRACKED kernel: achieved = algorithmic bytes (or flops) per launch / average launch
     duration, both from the HIP events recorded around the launches inside the timed region.  The fused field kernel
-    evaluates only the live samples of each iteration (device-side list), so its units per launch are the frame's sampled
-    points / loop iterations, not the padded slot count the launch is sized for."""
+    evaluates only the live samples of each iteration (device-side list), so its units per launch are the sampled points of the
+    instrumented loops / their launches, not the padded slot count the launch is sized for.  points_exclusive / _overlapped: sampled
+    points of the instrumented loops that ran alone / while sharing the device."""
     summ = timers.summary()
     if not summ:
         return None, {}
     if "field_forward_f16" in summ:
-        # every timed frame evaluates n_samples points in total; the device-driven loop also launches (and times) one trailing
-        # no-op iteration per frame, which is counted as a launch with zero units
+        # the device-driven loop also launches (and times) one trailing no-op iteration per loop, counted as a launch with zero units
         f = summ["field_forward_f16"]
-        f["units"] = int(n_samples * steps)
+        f["units"] = int(points_exclusive)
         f["avg_units"] = f["units"] / f["launches"]
     over = summ.pop("field_forward_f16_overlapped", None)
     name = max(summ, key=lambda k: summ[k]["total_ms"])
@@ -589,17 +662,18 @@ def roofline(timers, fp16, n_samples, n_iters, steps, steps_overlapped=0):
         roof = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": None, "flop_per_point": FIELD_FLOP_PER_POINT,
                 "avg_launch_ms": s["avg_ms"], "avg_points_per_launch": s["avg_units"]}
-        pmc = os.path.join(ROOT, "profiles", "r01_field_pmc_summary.json")
-        if os.path.exists(pmc):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, raw)
+        pmc = os.path.join(ROOT, "profiles", PMC_SUMMARY)
+        if os.path.exists(pmc):  # HBM bytes per point from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE), NOT measured in this run
             f = json.load(open(pmc))["field_forward_f16"]
-            roof["traffic"] = (f["fetch_bytes_per_frame_raw"] + f["write_bytes_per_frame"]) * steps / s["launches"]
-            roof["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/r01_field_pmc_summary.json)"
-        if over and steps_overlapped:  # the same launches while other frames' kernels share the device: durations are not the kernel's own
-            units = n_samples * steps_overlapped / over["launches"]
+            roof["traffic"] = f["hbm_bytes_per_point"] * s["avg_units"]
+            roof["traffic_static"] = True
+            roof["traffic_unit"] = f"HBM bytes per launch = bytes per point of profiles/{PMC_SUMMARY} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command) x points per launch; static, not measured in this run"
+        if over and points_overlapped:  # the same launches while other loops' kernels share the device: durations are not the kernel's own
+            units = points_overlapped / over["launches"]
             ach = FIELD_FLOP_PER_POINT * units / (over["avg_ms"] * 1e-3) / 1e12
             roof["overlapped"] = {"avg_launch_ms": over["avg_ms"], "launches": over["launches"], "achieved": ach,
                                   "frac": ach / MFMA_F16_PEAK_TFLOPS,
-                                  "note": "frames in flight share the CUs: this is the figure rocprofv3 --stats of the default command averages towards"}
+                                  "note": "loops in flight share the CUs: this is the figure rocprofv3 --stats of the default command averages towards"}
             summ["field_forward_f16_overlapped"] = over
     return roof, summ
 

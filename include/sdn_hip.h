@@ -279,6 +279,20 @@ typedef struct SdnSealBox {
     int32_t modify_hsv;        /* 0 = leave colours alone */
 } SdnSealBox;
 
+/* Several frames may be rendered TOGETHER by one loop ("frame group": the shards of consecutive frames of a camera path / of
+ * successive time steps on one GPU of a ray-sharded job).  The rays are frame-major -- ray r belongs to frame r / rays_per_frame --
+ * and everything that depends on a frame's time is selected per ray: the occupancy slice (dnerf/renderer.py:285), the
+ * time-encoding bias of the first deformation layer and the t == 0 rule (dnerf/network.py:130-141).  Per-ray results do not
+ * depend on which rays share a loop, so each frame of a group is bit-identical to the frame rendered alone. */
+#define SDN_MAX_GROUP_FRAMES 16
+
+/* The time-dependent constants of one frame (entry 0 / bit 0), or of each frame of a group. */
+typedef struct SdnFrameTime {
+    const uint8_t *bitfield[SDN_MAX_GROUP_FRAMES];   /* occupancy slice per frame */
+    const float *field_bias0;                         /* device, [frames][128] */
+    uint32_t zero_deform;                             /* bit f: frame f renders the canonical field (time == 0) */
+} SdnFrameTime;
+
 typedef struct SdnRenderCtx {
     const float *rays_o, *rays_d, *nears, *fars;
     const uint8_t *bitfield;
@@ -310,6 +324,13 @@ typedef struct SdnRenderCtx {
      * network (sdn_seal_bbox_map) and to the colours of the mapped samples after it (sdn_seal_modify_hsv); NULL = no edit */
     const struct SdnSealBox *seal;
     uint8_t *seal_mask;        /* [M_cap] scratch, required with `seal` */
+    /* optional frame group (n_group_frames > 1; N = n_group_frames * rays_per_frame): frame f marches frame_bitfield[f], its field
+     * constants are field_bias0 + 128 f and bit f of zero_deform; cull_bits then holds n_group_frames cull grids and slot_frame
+     * [M_cap] (scratch, required) receives the frame of every emitted sample.  With n_group_frames <= 1 `bitfield`,
+     * `field_bias0` [128] and bit 0 of `zero_deform` describe the one frame. */
+    uint32_t n_group_frames, rays_per_frame;
+    const uint8_t *frame_bitfield[SDN_MAX_GROUP_FRAMES];
+    uint8_t *slot_frame;
 } SdnRenderCtx;
 
 /* Resets per-ray state (alive = 0..N-1, rays_t = nears, accumulators = 0), the loop record and the counters, and builds
@@ -337,13 +358,16 @@ int sdn_render_frame_f16(const SdnRenderCtx *ctx, float bg_color, float *image_o
  * throughput-bound kernels of another.  Per-frame pointers come from rays_o / rays_d / image_outs / depth_outs [n_frames]; the
  * contexts supply everything else (aabb must be set: the driver computes nears / fars per frame).  ev_field_frames: NULL, or per
  * frame a pointer (may be NULL) to 2 * max_field_events timing events for that frame's field launches.  exclusive_frames: NULL or
- * [n_frames] flags; a flagged frame runs with nothing else in flight (to time its kernels undisturbed).  Every frame is
- * bit-identical to sdn_render_frame_f16's; iterations_out [n_frames] or NULL. */
+ * [n_frames] flags; a flagged frame runs with nothing else in flight (to time its kernels undisturbed).  frame_times: NULL (every
+ * frame uses its context's time constants) or [n_frames] records: frame i (a frame group when the contexts are group contexts)
+ * is rendered at ITS time -- a D-NeRF test set carries one time per frame (dnerf/utils.py:151-161).  Every frame is
+ * bit-identical to sdn_render_frame_f16's; iterations_out [n_frames] or NULL.  Returns SDN_E_TIMEOUT when no iteration of any
+ * frame in flight completes within 20 s (all streams are synchronised before any error return). */
 int sdn_render_frames_pipelined_f16(const SdnRenderCtx *const *ctxs, uint32_t n_ctx, uint32_t n_frames, const float *const *rays_o,
                                     const float *const *rays_d, float *const *image_outs, float *const *depth_outs, float bg_color,
                                     uint32_t overlap_div, void *const *streams, void *const *side_streams, void **ev_main,
                                     void **ev_copy, int32_t *host_snap, void *const *ev_field_frames, uint32_t max_field_events,
-                                    const uint8_t *exclusive_frames, uint32_t *iterations_out);
+                                    const uint8_t *exclusive_frames, const SdnFrameTime *frame_times, uint32_t *iterations_out);
 /* ---------------------------------------------------------------------------
  * SealD-NeRF bounding-box seal mapper on the sample stream  (reference: SealNeRF/seal_utils.py:132-153 map_mask, :245-286
  * SealBBoxMapper.map_to_origin, :638-693 moller_trumbore / points_in_mesh, :747-758 modify_hsv; torch boolean-mask code there)
@@ -365,13 +389,6 @@ int sdn_seal_modify_hsv(float *rgbs, const uint8_t *mask, uint32_t M, float dh, 
  * copy path described above.  Returns NULL on failure. */
 void *sdn_host_mailbox_alloc(uint32_t groups);
 int sdn_host_mailbox_free(void *mailbox);
-/* The same for `groups` (<= 16) disjoint groups of a frame's rays, each with its own context / output / stream / side
- * stream, driven round-robin by the calling thread so that the groups' kernels overlap on the device.  ev_main / ev_copy:
- * 4 events per group (group g uses [4g, 4g+4)); host_snap: 8 pinned ints per group; iterations_out: one per group or NULL.
- * The caller orders the group streams after its own work and joins them afterwards. */
-int sdn_render_frame_groups_f16(const SdnRenderCtx *const *ctxs, uint32_t groups, float bg_color, float *const *image_outs,
-                                float *const *depth_outs, void *const *streams, void *const *side_streams, void **ev_main,
-                                void **ev_copy, int32_t *host_snap, uint32_t *iterations_out);
 /* image_out [N,3] = image + (1 - weights_sum) * bg; depth_out [N] = clamp(depth - nears, 0) / (fars - nears). */
 int sdn_render_finish(const SdnRenderCtx *ctx, float bg_color, float *image_out, float *depth_out, void *stream);
 

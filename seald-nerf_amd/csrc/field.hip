@@ -85,7 +85,8 @@ struct FieldArgs {
     float *rgbs;              // [M,3]
     float bound;
     float density_scale;
-    int zero_deform;          // t == 0: canonical frame (dnerf/network.py:140-141)
+    int zero_deform;          // bit f: frame f is at t == 0, the canonical frame (dnerf/network.py:140-141); a single frame uses bit 0
+    const uint8_t *slot_frame;  // frame group: frame of every sample slot (selects bias0 + 128 f and bit f of zero_deform), or nullptr
     // density-grid query (CELLS variant): the points are jittered centres of occupancy-grid cells, built in the kernel
     const float *cell_noise;  // [count,3] uniform [0,1) by list position, or nullptr = counter-based generator on cell_seed
     uint32_t cell_seed;
@@ -295,10 +296,14 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
         }
     }
     f32x16 acc[4];
-    #pragma unroll
-    for (int mt = 0; mt < 4; mt++) {
+    const uint32_t frame = P.slot_frame ? P.slot_frame[p] : 0u;   // kernel-uniform condition
+    {
+        const float *__restrict__ b0 = P.bias0 + 128u * frame;
         #pragma unroll
-        for (int r = 0; r < 16; r++) acc[mt][r] = P.bias0[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h];
+        for (int mt = 0; mt < 4; mt++) {
+            #pragma unroll
+            for (int r = 0; r < 16; r++) acc[mt][r] = b0[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h];
+        }
     }
     SDN_TS();   // 1: features done
     // Wave priority follows the phase.  All vector instructions of a SIMD share one issue port and the arbiter prefers the oldest
@@ -380,7 +385,7 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
         const float xs[3] = {x0, x1, x2};
         #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const float xd = P.zero_deform ? xs[c] : xs[c] + df[c];
+            const float xd = ((P.zero_deform >> frame) & 1) ? xs[c] : xs[c] + df[c];
             u[c] = (xd + P.bound) / (2 * P.bound);  // GridEncoder.forward (grid.py:149)
         }
     }
@@ -622,7 +627,8 @@ namespace sdn_int {
 // launch used by both the C entry point and the device-driven render loop (render.hip)
 int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count, const int32_t *state,
                       uint32_t M, const void *weights, const float *bias0, const void *table, const int32_t *offsets_host, float S,
-                      uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, uint32_t expect_points, hipStream_t st) {
+                      uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, uint32_t expect_points,
+                      const uint8_t *slot_frame, hipStream_t st) {
     TiledLevels lv;
     int rc = fill_tiled_levels(lv, offsets_host, S, H);
     if (rc) return rc;
@@ -630,6 +636,7 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
     a.xyzs = xyzs; a.dirs = dirs; a.live_idx = live_idx; a.live_count = live_count; a.state = state; a.M = M;
     a.weights = (const unsigned char *)weights; a.bias0 = bias0; a.table = (const __half *)table;
     a.sigmas = sigmas; a.rgbs = rgbs; a.bound = bound; a.density_scale = density_scale; a.zero_deform = zero_deform;
+    a.slot_frame = slot_frame;
     a.cell_noise = nullptr; a.cell_seed = 0; a.cell_inv = a.cell_span = a.cell_half = 0;
     const uint32_t wgs = sdn_div_up(M, (uint32_t)kPointsPerWG);
     static int cus = 0;
@@ -657,7 +664,8 @@ int field_cells_f16(const int32_t *cells, const uint32_t *cell_count, uint32_t n
     FieldArgs a;
     a.xyzs = nullptr; a.dirs = nullptr; a.live_idx = (const uint32_t *)cells; a.live_count = cell_count; a.state = nullptr; a.M = n;
     a.weights = (const unsigned char *)weights; a.bias0 = bias0; a.table = (const __half *)table;
-    a.sigmas = tmp_slice; a.rgbs = nullptr; a.bound = bound; a.density_scale = density_scale; a.zero_deform = zero_deform;
+    a.sigmas = tmp_slice; a.rgbs = nullptr; a.bound = bound; a.density_scale = density_scale; a.zero_deform = zero_deform ? 1 : 0;
+    a.slot_frame = nullptr;
     a.cell_noise = noise; a.cell_seed = seed;
     const float half_grid = cas_bound / (float)grid_size;
     a.cell_inv = 1.0f / (float)(grid_size - 1); a.cell_span = cas_bound - half_grid; a.cell_half = half_grid;
@@ -685,7 +693,7 @@ int sdn_field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *
     if ((live_idx == nullptr) != (live_count == nullptr)) return SDN_E_BADARG;
     if (((uintptr_t)weights & 15u) != 0 || ((uintptr_t)table & 3u) != 0) return SDN_E_BADARG;
     return sdn_int::field_forward_f16(xyzs, dirs, live_idx, live_count, nullptr, M, weights, bias0, table, offsets_host, S, H, bound,
-                                      density_scale, zero_deform, sigmas, rgbs, 0u, (hipStream_t)stream);
+                                      density_scale, zero_deform ? 1 : 0, sigmas, rgbs, 0u, nullptr, (hipStream_t)stream);
 }
 
 }  // extern "C"

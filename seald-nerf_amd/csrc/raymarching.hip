@@ -14,8 +14,10 @@
 // (stable compaction), so a wave's 64 rays are neighbouring pixels and take
 // similar trip counts.
 #include "sdn_common.h"
+#include "sdn_internal.h"
 
 namespace {
+using sdn_int::FrameSel;
 
 constexpr float kSqrt3 = 1.7320508075688772f;
 constexpr float kRPi = 0.3183098861837907f;
@@ -203,8 +205,15 @@ static inline bool fast_config(float bound, uint32_t C, uint32_t H) {
 // is exact, not an approximation.  Rays that may hit take the full reference chain from their own t.
 // ---------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(256) k_build_cull_grid(const uint8_t *__restrict__ bitfield, uint32_t *__restrict__ cull_bits) {
-    const uint32_t c = threadIdx.x + blockIdx.x * blockDim.x;  // grid is exactly 32^3 threads
+__device__ __forceinline__ const uint8_t *frame_grid_uniform_y(const sdn_int::FrameSel &fs) { return fs.grid[blockIdx.y]; }
+
+__global__ void __launch_bounds__(256) k_build_cull_grid(const uint8_t *__restrict__ bitfield, uint32_t *__restrict__ cull_bits,
+                                                         sdn_int::FrameSel fs) {
+    if (fs.n_frames > 1) {   // frame group: blockIdx.y = frame
+        bitfield = frame_grid_uniform_y(fs);
+        cull_bits += (size_t)blockIdx.y * fs.cull_stride;
+    }
+    const uint32_t c = threadIdx.x + blockIdx.x * blockDim.x;  // grid.x is exactly 32^3 threads
     const int cx = c & 31, cy = (c >> 5) & 31, cz = c >> 10;
     const unsigned long long *__restrict__ blocks = reinterpret_cast<const unsigned long long *>(bitfield);
     bool any = false;
@@ -228,9 +237,9 @@ __global__ void __launch_bounds__(256) k_build_cull_grid(const uint8_t *__restri
     }
 }
 
-__global__ void k_cull_meta_init(uint32_t *__restrict__ cull_bits) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int *meta = reinterpret_cast<int *>(cull_bits + kCullWords);
+__global__ void k_cull_meta_init(uint32_t *__restrict__ cull_bits, uint32_t n_frames, uint32_t cull_stride) {
+    if (threadIdx.x < n_frames && blockIdx.x == 0) {
+        int *meta = reinterpret_cast<int *>(cull_bits + (size_t)threadIdx.x * cull_stride + kCullWords);
         meta[0] = meta[1] = meta[2] = (int)kCullRes;
         meta[3] = meta[4] = meta[5] = -1;
         meta[6] = meta[7] = 0;
@@ -640,7 +649,7 @@ __device__ __forceinline__ float *state_tend(const int32_t *__restrict__ state) 
 }
 template <bool FAST>
 __device__ __forceinline__ uint32_t march_ray(MarcherT<FAST> &m, const OccCache &oc, float t, float far, uint32_t n_step, float *px, float *pd,
-                                              float *pl, float *tend = nullptr) {
+                                              float *pl, float *tend = nullptr, uint8_t *psf = nullptr, uint32_t frame = 0) {
     m.fine = oc.fine; m.fx0 = oc.fx0; m.fy0 = oc.fy0; m.fz0 = oc.fz0; m.fnx = oc.fnx; m.fny = oc.fny; m.fnz = oc.fnz;
     uint32_t step = 0;
     float last_t = t, x, y, z, dt;
@@ -666,6 +675,7 @@ __device__ __forceinline__ uint32_t march_ray(MarcherT<FAST> &m, const OccCache 
                 pl[1] = t - last_t;
                 last_t = t;
                 px += 3; pd += 3; pl += 2;
+                if (psf) psf[step] = (uint8_t)frame;   // frame group: which frame's time constants the field network applies
                 step++;
             }
         }
@@ -677,6 +687,25 @@ __device__ __forceinline__ uint32_t march_ray(MarcherT<FAST> &m, const OccCache 
         px += 3; pd += 3; pl += 2;
     }
     return step;
+}
+
+// ---- frame groups (FrameSel::n_frames > 1) -------------------------------------------------------------------------------------
+// The alive list is ordered by ray id (stable compaction; the steady mode's frozen list keeps that order) and rays are
+// frame-major, so a 256-entry workgroup sees one frame, or two at a frame boundary.  A marching workgroup therefore loops over the
+// frames present among its live entries (ascending; one round in all but the <= n_frames - 1 boundary workgroups of a launch):
+// per round it loads the LDS occupancy caches of that frame and the lanes of that frame march.  Same code, same LDS address
+// space, no per-lane indexing of the kernel-argument record (fs.grid[] is only ever indexed with a workgroup-uniform value).
+__device__ __forceinline__ uint32_t block_min_256(uint32_t v, uint32_t *lds4) {
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, off, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) lds4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return min(min(lds4[0], lds4[1]), min(lds4[2], lds4[3]));
+}
+constexpr uint32_t kNoFrame = 0xFFFFFFFFu;
+__device__ __forceinline__ const uint8_t *frame_grid_uniform(const FrameSel &fs, uint32_t frame_uniform) {
+    return fs.grid[__builtin_amdgcn_readfirstlane(frame_uniform)];
 }
 
 // Appends the slots n*n_step .. +step of every lane to the live list: one atomicAdd per wave, prefix by wave shuffles.
@@ -769,7 +798,7 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
                                                     float *__restrict__ deltas, const float *__restrict__ noises, uint32_t M_pad,
                                                     const uint32_t *__restrict__ cull, uint32_t *__restrict__ live_idx,
                                                     uint32_t *__restrict__ live_count, const int32_t *__restrict__ state,
-                                                    const int32_t *__restrict__ rays_alive_b) {
+                                                    const int32_t *__restrict__ rays_alive_b, FrameSel fs) {
     if (state) {  // device-driven loop: sizes, ping-pong side and the iteration's live counter come from the loop state
         n_alive = (uint32_t)state[0];
         n_step = (uint32_t)state[1];
@@ -781,21 +810,32 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
     }
     __shared__ uint4 s_cull4[FAST ? 256 : 1];  // 32^3 bits = 4 KiB
     __shared__ unsigned long long s_fine[FAST ? kFineCacheCells : 1];  // <= 32 KiB
-    OccCache oc;
-    occ_cache_load<FAST>(cull, grid, s_cull4, s_fine, oc);
+    __shared__ uint32_t s_min4[4];
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    const int index = n < n_alive ? rays_alive[n] : -1;
+    const bool grouped = fs.n_frames > 1;  // kernel-uniform
+    const uint32_t frame = (grouped && index >= 0) ? (uint32_t)index / fs.rays_per_frame : (grouped ? kNoFrame : 0u);
     uint32_t step = 0;
-    if (n < n_alive) {
-        const int index = rays_alive[n];
-        MarcherT<FAST> m;
-        m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid);
-        float t = rays_t[index];
-        t += m.step_size(t) * (noises ? noises[n] : 0.0f);
-        float *tend = state ? state_tend(state) : nullptr;
-        if (tend) tend += index;
-        step = march_ray<FAST>(m, oc, t, fars[index], n_step, xyzs + (size_t)n * n_step * 3, dirs + (size_t)n * n_step * 3,
-                               deltas + (size_t)n * n_step * 2, tend);
-    } else {
+    uint32_t fcur = grouped ? block_min_256(frame, s_min4) : 0u;
+    while (fcur != kNoFrame) {   // one round per frame present in this workgroup (exactly one without a frame group)
+        const uint8_t *grid_f = grouped ? frame_grid_uniform(fs, fcur) : grid;
+        const uint32_t *cull_f = (grouped && cull) ? cull + (size_t)fcur * fs.cull_stride : cull;
+        OccCache oc;
+        occ_cache_load<FAST>(cull_f, grid_f, s_cull4, s_fine, oc);
+        if (index >= 0 && frame == fcur) {
+            MarcherT<FAST> m;
+            m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid_f);
+            float t = rays_t[index];
+            t += m.step_size(t) * (noises ? noises[n] : 0.0f);
+            float *tend = state ? state_tend(state) : nullptr;
+            if (tend) tend += index;
+            step = march_ray<FAST>(m, oc, t, fars[index], n_step, xyzs + (size_t)n * n_step * 3, dirs + (size_t)n * n_step * 3,
+                                   deltas + (size_t)n * n_step * 2, tend, grouped ? fs.slot_frame + (size_t)n * n_step : nullptr, frame);
+        }
+        if (!grouped) break;
+        fcur = block_min_256((frame != kNoFrame && frame > fcur) ? frame : kNoFrame, s_min4);   // (the barriers inside also fence the LDS caches)
+    }
+    if (n >= n_alive) {
         const uint32_t slot = n_alive * n_step + (n - n_alive);  // spare lanes of the last blocks clear the alignment tail
         if (slot < M_pad) {
             xyzs[(size_t)slot * 3] = 0; xyzs[(size_t)slot * 3 + 1] = 0; xyzs[(size_t)slot * 3 + 2] = 0;
@@ -1066,10 +1106,11 @@ __global__ void __launch_bounds__(256) k_composite_march(float T_thresh, int32_t
                                                          float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image,
                                                          const uint32_t *__restrict__ cull, uint32_t *__restrict__ live_idx,
                                                          uint32_t *__restrict__ live_counts, int32_t *__restrict__ state,
-                                                         int32_t *__restrict__ ticket, int32_t *__restrict__ trace, int32_t *__restrict__ snap) {
+                                                         int32_t *__restrict__ ticket, int32_t *__restrict__ trace, int32_t *__restrict__ snap,
+                                                         FrameSel fs) {
     __shared__ uint4 s_cull4[FAST ? 256 : 1];
     __shared__ unsigned long long s_fine[FAST ? kFineCacheCells : 1];
-    __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_cnt[4], s_min4[4];
     __shared__ int s_last;
     const uint32_t n_alive = (uint32_t)state[0], n_step = (uint32_t)state[1], list_len = (uint32_t)state[8];
     const int32_t it = state[3];
@@ -1079,22 +1120,33 @@ __global__ void __launch_bounds__(256) k_composite_march(float T_thresh, int32_t
     bool survives = false;
     uint32_t emitted = 0;
     if (n_alive > 0 && blockIdx.x * 256u < list_len) {  // workgroup-uniform
-        OccCache oc;
-        occ_cache_load<FAST>(cull, grid, s_cull4, s_fine, oc);
         const int index = n < list_len ? alive[n] : -1;
+        // composite iteration `it` of this ray; survivors march iteration it + 1 below
         if (index >= 0) {
-            float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3, *pl = deltas + (size_t)n * n_step * 2;
-            survives = composite_ray(index, n_step, T_thresh, sigmas + (size_t)n * n_step, rgbs + (size_t)n * n_step * 3, pl, rays_t,
-                                     weights_sum, depth, image);
-            if (!survives) {
-                alive[n] = -1;
-            } else if (march_next) {
+            survives = composite_ray(index, n_step, T_thresh, sigmas + (size_t)n * n_step, rgbs + (size_t)n * n_step * 3,
+                                     deltas + (size_t)n * n_step * 2, rays_t, weights_sum, depth, image);
+            if (!survives) alive[n] = -1;
+        }
+        const bool marches = survives && march_next;
+        const bool grouped = fs.n_frames > 1;  // kernel-uniform
+        const uint32_t frame = (grouped && marches) ? (uint32_t)index / fs.rays_per_frame : (grouped ? kNoFrame : 0u);
+        uint32_t fcur = grouped ? block_min_256(frame, s_min4) : 0u;
+        while (fcur != kNoFrame) {   // one round per frame present among this workgroup's marching rays (see block_min_256)
+            const uint8_t *grid_f = grouped ? frame_grid_uniform(fs, fcur) : grid;
+            const uint32_t *cull_f = (grouped && cull) ? cull + (size_t)fcur * fs.cull_stride : cull;
+            OccCache oc;
+            occ_cache_load<FAST>(cull_f, grid_f, s_cull4, s_fine, oc);
+            if (marches && frame == fcur) {
+                float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3, *pl = deltas + (size_t)n * n_step * 2;
                 MarcherT<FAST> m;
-                m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid);
+                m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid_f);
                 float *tend = state_tend(state);
                 if (tend) tend += index;
-                emitted = march_ray<FAST>(m, oc, rays_t[index], fars[index], n_step, px, pd, pl, tend);
+                emitted = march_ray<FAST>(m, oc, rays_t[index], fars[index], n_step, px, pd, pl, tend,
+                                          grouped ? fs.slot_frame + (size_t)n * n_step : nullptr, frame);
             }
+            if (!grouped) break;
+            fcur = block_min_256((frame != kNoFrame && frame > fcur) ? frame : kNoFrame, s_min4);
         }
         live_append(emitted, n, n_step, live_idx, live_counts + it + 1);
     }
@@ -1157,15 +1209,15 @@ int loop_begin(uint32_t N, uint32_t max_steps, const float *nears, int32_t *aliv
 int loop_march(uint32_t bound_alive, const int32_t *alive_a, const int32_t *alive_b, const float *rays_t, const float *rays_o,
                const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
                const float *fars, float *xyzs, float *dirs, float *deltas, const uint32_t *cull, uint32_t *live_idx,
-               uint32_t *live_counts, const int32_t *state, hipStream_t st) {
+               uint32_t *live_counts, const int32_t *state, const FrameSel &fs, hipStream_t st) {
     const dim3 g(sdn_div_up(bound_alive + 128u, 256u)), b(256);
     if (fast_config(bound, C, H)) {
         if (cull && H != 128) cull = nullptr;
         hipLaunchKernelGGL(k_march_rays<true>, g, b, 0, st, 0u, 0u, alive_a, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars,
-                           xyzs, dirs, deltas, (const float *)nullptr, 0u, cull, live_idx, live_counts, state, alive_b);
+                           xyzs, dirs, deltas, (const float *)nullptr, 0u, cull, live_idx, live_counts, state, alive_b, fs);
     } else {
         hipLaunchKernelGGL(k_march_rays<false>, g, b, 0, st, 0u, 0u, alive_a, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars,
-                           xyzs, dirs, deltas, (const float *)nullptr, 0u, (const uint32_t *)nullptr, live_idx, live_counts, state, alive_b);
+                           xyzs, dirs, deltas, (const float *)nullptr, 0u, (const uint32_t *)nullptr, live_idx, live_counts, state, alive_b, fs);
     }
     return sdn_launch_status();
 }
@@ -1198,27 +1250,27 @@ int loop_composite_compact(uint32_t bound_alive, float T_thresh, int32_t *alive_
 int loop_steady_begin(uint32_t bound_alive, const int32_t *alive_a, const int32_t *alive_b, const float *rays_t, const float *rays_o,
                       const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
                       const float *fars, float *xyzs, float *dirs, float *deltas, const uint32_t *cull, uint32_t *live_idx,
-                      uint32_t *live_counts, int32_t *state, hipStream_t st) {
+                      uint32_t *live_counts, int32_t *state, const FrameSel &fs, hipStream_t st) {
     hipLaunchKernelGGL(k_steady_begin, dim3(1), dim3(64), 0, st, state);
     return loop_march(bound_alive, alive_a, alive_b, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas,
-                      cull, live_idx, live_counts, state, st);
+                      cull, live_idx, live_counts, state, fs, st);
 }
 
 int loop_composite_march(uint32_t bound_list, float T_thresh, int32_t *alive_a, int32_t *alive_b, float *rays_t, const float *rays_o,
                          const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
                          const float *fars, const float *sigmas, const float *rgbs, float *xyzs, float *dirs, float *deltas,
                          float *weights_sum, float *depth, float *image, const uint32_t *cull, uint32_t *live_idx, uint32_t *live_counts,
-                         int32_t *state, int32_t *ticket, int32_t *trace, int32_t *snap, hipStream_t st) {
+                         int32_t *state, int32_t *ticket, int32_t *trace, int32_t *snap, const FrameSel &fs, hipStream_t st) {
     const dim3 g(sdn_div_up(bound_list, 256u)), b(256);
     if (fast_config(bound, C, H)) {
         if (cull && H != 128) cull = nullptr;
         hipLaunchKernelGGL(k_composite_march<true>, g, b, 0, st, T_thresh, alive_a, alive_b, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
                            grid, fars, sigmas, rgbs, xyzs, dirs, deltas, weights_sum, depth, image, cull, live_idx, live_counts, state, ticket,
-                           trace, snap);
+                           trace, snap, fs);
     } else {
         hipLaunchKernelGGL(k_composite_march<false>, g, b, 0, st, T_thresh, alive_a, alive_b, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C,
                            H, grid, fars, sigmas, rgbs, xyzs, dirs, deltas, weights_sum, depth, image, (const uint32_t *)nullptr, live_idx,
-                           live_counts, state, ticket, trace, snap);
+                           live_counts, state, ticket, trace, snap, fs);
     }
     return sdn_launch_status();
 }
@@ -1231,9 +1283,28 @@ int loop_finish(uint32_t N, const float *nears, const float *fars, const float *
 }
 
 int build_cull(const uint8_t *bitfield, uint32_t *cull_bits, hipStream_t st) {
-    hipLaunchKernelGGL(k_cull_meta_init, dim3(1), dim3(64), 0, st, cull_bits);
-    hipLaunchKernelGGL(k_build_cull_grid, dim3(kCullRes * kCullRes * kCullRes / 256), dim3(256), 0, st, bitfield, cull_bits);
+    hipLaunchKernelGGL(k_cull_meta_init, dim3(1), dim3(64), 0, st, cull_bits, 1u, 0u);
+    hipLaunchKernelGGL(k_build_cull_grid, dim3(kCullRes * kCullRes * kCullRes / 256), dim3(256), 0, st, bitfield, cull_bits, FrameSel());
     return sdn_launch_status();
+}
+
+int build_cull_group(const FrameSel &fs, uint32_t *cull_bits, hipStream_t st) {
+    hipLaunchKernelGGL(k_cull_meta_init, dim3(1), dim3(64), 0, st, cull_bits, fs.n_frames, fs.cull_stride);
+    hipLaunchKernelGGL(k_build_cull_grid, dim3(kCullRes * kCullRes * kCullRes / 256, fs.n_frames), dim3(256), 0, st, (const uint8_t *)nullptr,
+                       cull_bits, fs);
+    return sdn_launch_status();
+}
+
+FrameSel frame_sel(const SdnRenderCtx *c) {
+    FrameSel fs;
+    if (c->n_group_frames > 1) {
+        fs.n_frames = c->n_group_frames;
+        fs.rays_per_frame = c->rays_per_frame;
+        fs.cull_stride = sdn_cull_grid_bytes() / 4u;
+        for (uint32_t f = 0; f < c->n_group_frames && f < SDN_MAX_GROUP_FRAMES; f++) fs.grid[f] = c->frame_bitfield[f];
+        fs.slot_frame = c->slot_frame;
+    }
+    return fs;
 }
 
 }  // namespace sdn_int
@@ -1369,11 +1440,11 @@ static int launch_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *r
         if (cull && H != 128) cull = nullptr;  // the cull grid is built for the 128^3 grid only
         hipLaunchKernelGGL(k_march_rays<true>, g, b, 0, st, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
                            grid, fars, xyzs, dirs, deltas, noises, M_pad, cull, live_idx, live_count, (const int32_t *)nullptr,
-                           (const int32_t *)nullptr);
+                           (const int32_t *)nullptr, FrameSel());
     } else {
         hipLaunchKernelGGL(k_march_rays<false>, g, b, 0, st, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
                            grid, fars, xyzs, dirs, deltas, noises, M_pad, (const uint32_t *)nullptr, live_idx, live_count,
-                           (const int32_t *)nullptr, (const int32_t *)nullptr);
+                           (const int32_t *)nullptr, (const int32_t *)nullptr, FrameSel());
     }
     return sdn_launch_status();
 }
@@ -1401,9 +1472,9 @@ int sdn_build_cull_grid(const uint8_t *bitfield, uint32_t H, uint8_t *cull_grid,
     if (!bitfield || !cull_grid) return SDN_E_BADARG;
     if (H != 128) return SDN_E_UNSUPPORTED;
     if (((uintptr_t)bitfield & 7u) != 0 || ((uintptr_t)cull_grid & 15u) != 0) return SDN_E_BADARG;
-    hipLaunchKernelGGL(k_cull_meta_init, dim3(1), dim3(64), 0, (hipStream_t)stream, (uint32_t *)cull_grid);
+    hipLaunchKernelGGL(k_cull_meta_init, dim3(1), dim3(64), 0, (hipStream_t)stream, (uint32_t *)cull_grid, 1u, 0u);
     hipLaunchKernelGGL(k_build_cull_grid, dim3(kCullRes * kCullRes * kCullRes / 256), dim3(256), 0, (hipStream_t)stream, bitfield,
-                       (uint32_t *)cull_grid);
+                       (uint32_t *)cull_grid, FrameSel());
     return sdn_launch_status();
 }
 

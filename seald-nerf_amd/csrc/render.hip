@@ -25,7 +25,8 @@ int render_begin(const SdnRenderCtx *c, void *mailbox, uint32_t frame_tag, hipSt
     int rc = loop_begin(c->N, c->max_steps, c->nears, c->alive_a, c->rays_t, c->weights_sum, c->depth, c->image, c->state, c->live_counts,
                         c->n_counters, mailbox, frame_tag, c->rays_tend, st);
     if (rc) return rc;
-    if (c->H == 128 && c->C == 1) rc = build_cull(c->bitfield, (uint32_t *)c->cull_bits, st);
+    if (c->H == 128 && c->C == 1)
+        rc = c->n_group_frames > 1 ? build_cull_group(frame_sel(c), (uint32_t *)c->cull_bits, st) : build_cull(c->bitfield, (uint32_t *)c->cull_bits, st);
     return rc;
 }
 }  // namespace sdn_int
@@ -51,8 +52,18 @@ static int seal_color(const SdnRenderCtx *c, uint32_t m_slots, hipStream_t st) {
 }
 
 static bool ctx_ok(const SdnRenderCtx *c) {
-    return c && c->rays_o && c->rays_d && c->nears && c->fars && c->bitfield && c->alive_a && c->alive_b && c->rays_t && c->weights_sum &&
-           c->depth && c->image && c->state && c->live_counts && c->cull_bits;
+    if (!(c && c->rays_o && c->rays_d && c->nears && c->fars && c->alive_a && c->alive_b && c->rays_t && c->weights_sum &&
+          c->depth && c->image && c->state && c->live_counts && c->cull_bits))
+        return false;
+    if (c->n_group_frames > 1) {   // frame group: one occupancy slice per frame, rays split evenly, the per-slot frame scratch
+        if (c->n_group_frames > SDN_MAX_GROUP_FRAMES || !c->slot_frame || c->rays_per_frame == 0 ||
+            (uint64_t)c->n_group_frames * c->rays_per_frame != c->N)
+            return false;
+        for (uint32_t f = 0; f < c->n_group_frames; f++)
+            if (!c->frame_bitfield[f]) return false;
+        return true;
+    }
+    return c->bitfield != nullptr;
 }
 
 int sdn_render_begin(const SdnRenderCtx *c, void *stream) {
@@ -71,7 +82,7 @@ int sdn_render_step_f16_ev(const SdnRenderCtx *c, uint32_t bound_alive, void *ev
     const uint32_t *cull = (c->H == 128 && c->C == 1) ? (const uint32_t *)c->cull_bits : nullptr;
     int rc = sdn_int::loop_march(bound_alive, c->alive_a, c->alive_b, c->rays_t, c->rays_o, c->rays_d, c->bound, c->dt_gamma, c->max_steps,
                                  c->C, c->H, c->bitfield, c->fars, c->xyzs, c->dirs, c->deltas, cull, c->live_idx,
-                                 (uint32_t *)c->live_counts, c->state, st);
+                                 (uint32_t *)c->live_counts, c->state, sdn_int::frame_sel(c), st);
     if (rc) return rc;
     // n_alive * n_step <= N always (n_step <= N / n_alive), and <= 8 * bound_alive
     uint64_t m_bound = (uint64_t)bound_alive * 8u;
@@ -81,7 +92,7 @@ int sdn_render_step_f16_ev(const SdnRenderCtx *c, uint32_t bound_alive, void *ev
     if (ev_field_begin) (void)hipEventRecord((hipEvent_t)ev_field_begin, st);
     rc = sdn_int::field_forward_f16(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, (uint32_t)m_bound,
                                     c->field_weights, c->field_bias0, c->grid_table, c->grid_offsets, c->grid_S, c->grid_H, c->bound,
-                                    c->density_scale, c->zero_deform, c->sigmas, c->rgbs, 0u, st);
+                                    c->density_scale, c->zero_deform, c->sigmas, c->rgbs, 0u, c->n_group_frames > 1 ? c->slot_frame : nullptr, st);
     if (ev_field_end) (void)hipEventRecord((hipEvent_t)ev_field_end, st);
     if (rc) return rc;
     rc = seal_color(c, (uint32_t)m_bound, st);
@@ -102,6 +113,8 @@ int sdn_render_step_f16_ev(const SdnRenderCtx *c, uint32_t bound_alive, void *ev
 }  // extern "C"
 
 namespace {
+
+constexpr int kDriverTimeoutSeconds = 20;   // no iteration of any frame in flight completes for this long: SDN_E_TIMEOUT
 
 // One ray group's loop as a two-phase state machine, so that one host thread can drive several groups round-robin.
 struct FrameRun {
@@ -153,14 +166,15 @@ struct FrameRun {
             if (e0) (void)hipEventRecord((hipEvent_t)e0, st);
             rc = sdn_int::field_forward_f16(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, (uint32_t)m_bound,
                                             c->field_weights, c->field_bias0, c->grid_table, c->grid_offsets, c->grid_S, c->grid_H, c->bound,
-                                            c->density_scale, c->zero_deform, c->sigmas, c->rgbs, last_alive * 8u, st);
+                                            c->density_scale, c->zero_deform, c->sigmas, c->rgbs, last_alive * 8u,
+                                            c->n_group_frames > 1 ? c->slot_frame : nullptr, st);
             if (e1) (void)hipEventRecord((hipEvent_t)e1, st);
             if (!rc) rc = seal_color(c, (uint32_t)m_bound, st);
             if (!rc)
                 rc = sdn_int::loop_composite_march(bound, c->T_thresh, c->alive_a, c->alive_b, c->rays_t, c->rays_o, c->rays_d, c->bound,
                                                    c->dt_gamma, c->max_steps, c->C, c->H, c->bitfield, c->fars, c->sigmas, c->rgbs, c->xyzs,
                                                    c->dirs, c->deltas, c->weights_sum, c->depth, c->image, cull(), c->live_idx,
-                                                   (uint32_t *)c->live_counts, c->state, c->n_out, c->trace, snap_dev, st);
+                                                   (uint32_t *)c->live_counts, c->state, c->n_out, c->trace, snap_dev, sdn_int::frame_sel(c), st);
         }
         if (rc) return rc;
         if (mail_dev) return 0;
@@ -196,7 +210,7 @@ struct FrameRun {
                 auto t0 = std::chrono::steady_clock::now();
                 while (((v = __atomic_load_n(word, __ATOMIC_ACQUIRE)) >> 32) != want) {
                     if ((++spins & 0xFFFFu) == 0) {
-                        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return SDN_E_TIMEOUT;
+                        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(kDriverTimeoutSeconds)) return SDN_E_TIMEOUT;
                         hipError_t q = hipStreamQuery(st);             // a faulted kernel never publishes: surface the error
                         if (q != hipSuccess && q != hipErrorNotReady) return (int)q;
                     }
@@ -216,7 +230,7 @@ struct FrameRun {
                     // iteration `it` (enqueued, normal mode) ends with a compacted list; freeze it and march iteration it+1
                     int rc = sdn_int::loop_steady_begin(bound, c->alive_a, c->alive_b, c->rays_t, c->rays_o, c->rays_d, c->bound, c->dt_gamma,
                                                         c->max_steps, c->C, c->H, c->bitfield, c->fars, c->xyzs, c->dirs, c->deltas, cull(),
-                                                        c->live_idx, (uint32_t *)c->live_counts, c->state, st);
+                                                        c->live_idx, (uint32_t *)c->live_counts, c->state, sdn_int::frame_sel(c), st);
                     if (rc) return rc;
                     steady = true;
                 }
@@ -247,45 +261,6 @@ int sdn_render_frame_f16(const SdnRenderCtx *c, float bg_color, float *image_out
     return sdn_render_finish(c, bg_color, image_out, depth_out, stream);
 }
 
-// The same loop for G disjoint groups of a frame's rays, each with its own context, stream and read-back ring, driven
-// round-robin by this one host thread: every group's next iteration is enqueued before any read-back is waited for, so the
-// latency-bound kernels of one group (marching chains, the small compositing / bookkeeping launches, launch gaps) run
-// under the throughput-bound field kernel of another, and two half-size field kernels that share the CUs run out of phase
-// instead of in lock-step.  Per-ray results do not depend on the grouping.  Arrays are indexed by group;
-// ev_main / ev_copy hold 4 events per group (group g uses [4g, 4g+4)), host_snap 8 ints per group.
-int sdn_render_frame_groups_f16(const SdnRenderCtx *const *ctxs, uint32_t groups, float bg_color, float *const *image_outs,
-                                float *const *depth_outs, void *const *streams, void *const *side_streams, void **ev_main, void **ev_copy,
-                                int32_t *host_snap, uint32_t *iterations_out) {
-    constexpr uint32_t kMaxGroups = 16;
-    if (!ctxs || groups == 0 || groups > kMaxGroups || !image_outs || !depth_outs || !streams || !side_streams || !ev_main || !ev_copy ||
-        !host_snap)
-        return SDN_E_BADARG;
-    FrameRun runs[kMaxGroups];
-    for (uint32_t g = 0; g < groups; g++) {
-        if (!ctxs[g] || !image_outs[g] || !depth_outs[g] || !side_streams[g]) return SDN_E_BADARG;
-        runs[g] = FrameRun{ctxs[g], (hipStream_t)streams[g], (hipStream_t)side_streams[g], ev_main + 4 * g, ev_copy + 4 * g, nullptr,
-                           host_snap + 8 * g, 0, 0, 0, false, false};
-        int rc = runs[g].begin();
-        if (rc) return rc;
-    }
-    for (uint32_t active = groups; active;) {
-        for (uint32_t g = 0; g < groups; g++)
-            if (!runs[g].done) { int rc = runs[g].enqueue(); if (rc) return rc; }
-        for (uint32_t g = 0; g < groups; g++) {
-            if (runs[g].done) continue;
-            int rc = runs[g].settle();
-            if (rc) return rc;
-            if (runs[g].done) {
-                active--;
-                rc = sdn_render_finish(runs[g].c, bg_color, image_outs[g], depth_outs[g], streams[g]);
-                if (rc) return rc;
-                if (iterations_out) iterations_out[g] = runs[g].it + 1;
-            }
-        }
-    }
-    return 0;
-}
-
 // A stream of frames (camera path / time steps) through n_ctx loop contexts used in turn, each on its own stream: the next frame
 // begins as soon as a context is free and the alive rays of the newest frame in flight have dropped to N / overlap_div
 // (1 = at once), so that the latency-bound parts of one frame -- marching chains, the tail iterations with a few thousand
@@ -299,7 +274,7 @@ int sdn_render_frames_pipelined_f16(const SdnRenderCtx *const *ctxs, uint32_t n_
                                     const float *const *rays_d, float *const *image_outs, float *const *depth_outs, float bg_color,
                                     uint32_t overlap_div, void *const *streams, void *const *side_streams, void **ev_main, void **ev_copy,
                                     int32_t *host_snap, void *const *ev_field_frames, uint32_t max_field_events, const uint8_t *exclusive_frames,
-                                    uint32_t *iterations_out) {
+                                    const SdnFrameTime *frame_times, uint32_t *iterations_out) {
     constexpr uint32_t kMaxCtx = 8;
     if (!ctxs || n_ctx == 0 || n_ctx > kMaxCtx || !rays_o || !rays_d || !image_outs || !depth_outs || !streams || !side_streams ||
         !ev_main || !ev_copy || !host_snap)
@@ -317,6 +292,14 @@ int sdn_render_frames_pipelined_f16(const SdnRenderCtx *const *ctxs, uint32_t n_
         if (!rays_o[next] || !rays_d[next] || !image_outs[next] || !depth_outs[next]) return SDN_E_BADARG;
         local[slot].rays_o = rays_o[next];
         local[slot].rays_d = rays_d[next];
+        if (frame_times) {   // this frame's (frame group's) own time: occupancy slice(s), time-encoding bias, canonical-frame flag(s)
+            const SdnFrameTime &ft = frame_times[next];
+            if (!ft.field_bias0 || !ft.bitfield[0]) return SDN_E_BADARG;
+            local[slot].bitfield = ft.bitfield[0];
+            for (uint32_t f = 0; f < SDN_MAX_GROUP_FRAMES; f++) local[slot].frame_bitfield[f] = ft.bitfield[f];
+            local[slot].field_bias0 = ft.field_bias0;
+            local[slot].zero_deform = (int32_t)ft.zero_deform;
+        }
         void **evf = ev_field_frames ? (void **)ev_field_frames[next] : nullptr;   // timing events of this frame's field launches, or none
         runs[slot] = FrameRun{&local[slot], (hipStream_t)streams[slot], (hipStream_t)side_streams[slot], ev_main + 4 * slot, ev_copy + 4 * slot,
                               evf, host_snap + 8 * slot, evf ? max_field_events : 0u, 0, 0, false, false};
@@ -351,10 +334,17 @@ int sdn_render_frames_pipelined_f16(const SdnRenderCtx *const *ctxs, uint32_t n_
         if (!r) r = runs[slot].enqueue();
         return r;
     };
+    // every error return first waits for all streams: the caller must never reuse buffers that kernels still write
+    auto fail = [&](int code) -> int {
+        for (uint32_t c = 0; c < n_ctx; c++) { (void)hipStreamSynchronize((hipStream_t)streams[c]); (void)hipStreamSynchronize((hipStream_t)side_streams[c]); }
+        (void)hipGetLastError();
+        return code;
+    };
     int rc = launch_next();
-    if (rc) return rc;
+    if (rc) return fail(rc);
     auto t_last = stats ? now() : 0.0;
     uint32_t idle_spins = 0;
+    auto t_progress = std::chrono::steady_clock::now();
     while (finished < n_frames) {
         n_loops++;
         bool progress = false;
@@ -369,30 +359,34 @@ int sdn_render_frames_pipelined_f16(const SdnRenderCtx *const *ctxs, uint32_t n_
             if (!runs[s2].ready()) continue;
             progress = true;
             rc = runs[s2].settle();
-            if (rc) return rc;
+            if (rc) return fail(rc);
             if (runs[s2].done) {
                 const int f = frame_of[s2];
                 rc = sdn_render_finish(&local[s2], bg_color, image_outs[f], depth_outs[f], streams[s2]);
-                if (rc) return rc;
+                if (rc) return fail(rc);
                 if (iterations_out) iterations_out[f] = runs[s2].it + 1;
                 frame_of[s2] = -1;
                 finished++;
             } else {
                 rc = runs[s2].enqueue();
-                if (rc) return rc;
+                if (rc) return fail(rc);
             }
             rc = launch_next();
-            if (rc) return rc;
+            if (rc) return fail(rc);
         }
         if (!progress) {
             rc = launch_next();
-            if (rc) return rc;
-            if ((++idle_spins & 0xFFFFFu) == 0) {   // nothing arrives for a long time: surface a device error instead of spinning for ever
+            if (rc) return fail(rc);
+            if ((++idle_spins & 0xFFFFu) == 0) {
+                // nothing has arrived for a while: surface a device error, and give up after 20 s without any iteration completing
+                // (a hung kernel never publishes its mailbox word and hipStreamQuery keeps answering "not ready")
                 for (uint32_t c = 0; c < n_ctx; c++)
-                    if (frame_of[c] >= 0) { hipError_t q = hipStreamQuery((hipStream_t)streams[c]); if (q != hipSuccess && q != hipErrorNotReady) return (int)q; }
+                    if (frame_of[c] >= 0) { hipError_t q = hipStreamQuery((hipStream_t)streams[c]); if (q != hipSuccess && q != hipErrorNotReady) return fail((int)q); }
+                if (std::chrono::steady_clock::now() - t_progress > std::chrono::seconds(kDriverTimeoutSeconds)) return SDN_E_TIMEOUT;
             }
         } else {
             idle_spins = 0;
+            t_progress = std::chrono::steady_clock::now();
         }
         if (stats) { const double t = now(); (progress ? t_work : t_idle) += t - t_last; t_last = t; }
     }

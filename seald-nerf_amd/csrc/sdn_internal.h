@@ -4,32 +4,46 @@
 
 namespace sdn_int {
 
+// Frame group selection handed (by value) to the loop kernels: with n_frames > 1 ray r belongs to frame r / rays_per_frame,
+// marches grid[frame] with the cull grid cull + frame * cull_stride, and every emitted sample's frame goes to slot_frame.
+struct FrameSel {
+    uint32_t n_frames = 0;        // <= 1: a single frame, the kernels' own grid / cull arguments are used as they are
+    uint32_t rays_per_frame = 0;
+    uint32_t cull_stride = 0;     // uint32 words between the cull grids of consecutive frames
+    uint32_t pad_ = 0;
+    const uint8_t *grid[SDN_MAX_GROUP_FRAMES] = {};
+    uint8_t *slot_frame = nullptr;
+};
+FrameSel frame_sel(const SdnRenderCtx *c);
+
 int loop_begin(uint32_t N, uint32_t max_steps, const float *nears, int32_t *alive_a, float *rays_t, float *weights_sum, float *depth,
                float *image, int32_t *state, int32_t *live_counts, uint32_t n_counters, void *mailbox, uint32_t frame_tag, float *rays_tend,
                hipStream_t st);
 int loop_march(uint32_t bound_alive, const int32_t *alive_a, const int32_t *alive_b, const float *rays_t, const float *rays_o,
                const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
                const float *fars, float *xyzs, float *dirs, float *deltas, const uint32_t *cull, uint32_t *live_idx,
-               uint32_t *live_counts, const int32_t *state, hipStream_t st);
+               uint32_t *live_counts, const int32_t *state, const FrameSel &fs, hipStream_t st);
 int loop_composite_compact(uint32_t bound_alive, float T_thresh, int32_t *alive_a, int32_t *alive_b, float *rays_t, const float *sigmas,
                            const float *rgbs, const float *deltas, float *weights_sum, float *depth, float *image, int32_t *state,
                            uint32_t *block_totals, int32_t *n_out, int32_t *trace, int32_t *snap, hipStream_t st);
 int loop_steady_begin(uint32_t bound_alive, const int32_t *alive_a, const int32_t *alive_b, const float *rays_t, const float *rays_o,
                       const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
                       const float *fars, float *xyzs, float *dirs, float *deltas, const uint32_t *cull, uint32_t *live_idx,
-                      uint32_t *live_counts, int32_t *state, hipStream_t st);
+                      uint32_t *live_counts, int32_t *state, const FrameSel &fs, hipStream_t st);
 int loop_composite_march(uint32_t bound_list, float T_thresh, int32_t *alive_a, int32_t *alive_b, float *rays_t, const float *rays_o,
                          const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
                          const float *fars, const float *sigmas, const float *rgbs, float *xyzs, float *dirs, float *deltas,
                          float *weights_sum, float *depth, float *image, const uint32_t *cull, uint32_t *live_idx, uint32_t *live_counts,
-                         int32_t *state, int32_t *ticket, int32_t *trace, int32_t *snap, hipStream_t st);
+                         int32_t *state, int32_t *ticket, int32_t *trace, int32_t *snap, const FrameSel &fs, hipStream_t st);
 int loop_finish(uint32_t N, const float *nears, const float *fars, const float *weights_sum, const float *depth, const float *image, float bg,
                 float *image_out, float *depth_out, hipStream_t st);
 int render_begin(const SdnRenderCtx *c, void *mailbox, uint32_t frame_tag, hipStream_t st);
 int build_cull(const uint8_t *bitfield, uint32_t *cull_bits, hipStream_t st);
+int build_cull_group(const FrameSel &fs, uint32_t *cull_bits, hipStream_t st);   // one cull grid per frame of the group
 int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count, const int32_t *state,
                       uint32_t M, const void *weights, const float *bias0, const void *table, const int32_t *offsets_host, float S,
-                      uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, uint32_t expect_points, hipStream_t st);
+                      uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, uint32_t expect_points,
+                      const uint8_t *slot_frame, hipStream_t st);
 
 int field_cells_f16(const int32_t *cells, const uint32_t *cell_count, uint32_t n, const float *noise, uint32_t seed, uint32_t grid_size,
                     float cas_bound, const void *weights, const float *bias0, const void *table, const int32_t *offsets_host, float S,

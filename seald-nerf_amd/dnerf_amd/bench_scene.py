@@ -2,7 +2,7 @@
 
   * rays: 800x800 (or HxW) camera of `scene.py`, time = 0.5 (density-grid slice 32)
   * occupancy: the capsule figure ("jumpingjacks-like") or the studded box ("lego-like"), one Morton
-    bitfield per time slice (only the slices asked for are rasterised; the rest stay empty)
+    bitfield per time slice
   * network: `NeRFNetwork` initialised under torch.manual_seed(seed) on the CPU (so the weights are
     the same on every box), then, deterministically:
       - grid embeddings U(-1e-4, 1e-4) (grid.py:138-140) scaled by 1e3;
@@ -72,11 +72,27 @@ def calibrate_density(model, bitfield_slice, time, seed=0, max_steps=1024):
 def build_scene(H=800, W=800, device="cuda", seed=0, kind="jumpingjacks", time=0.5, azimuth=30.0, elevation=30.0):
     model = build_model(seed, device)
     t_idx = int(min(max(math.floor(time * model.time_size), 0), model.time_size - 1))
-    bits = scene.density_bitfield_all_times(model.time_size, model.grid_size, kind, times={t_idx})
+    bits = scene.density_bitfield_all_times(model.time_size, model.grid_size, kind)   # every time slice (a second for all 64)
     model.density_bitfield.copy_(torch.from_numpy(bits))
     time_t = torch.tensor([[time]], dtype=torch.float32, device=device)
     calibrate_density(model, bits[t_idx], time_t, seed)
     pose = scene.look_at_pose(azimuth, elevation)
     ro, rd = scene.get_rays(pose, scene.intrinsics(H, W), H, W)
     return SimpleNamespace(model=model, rays_o=torch.from_numpy(ro).to(device), rays_d=torch.from_numpy(rd).to(device), time=time_t,
-                           H=H, W=W, kind=kind, t_idx=t_idx, bitfield=bits[t_idx], pose=pose)
+                           H=H, W=W, kind=kind, t_idx=t_idx, bitfield=bits[t_idx], bitfields=bits, pose=pose)
+
+
+def camera_path(sc, n_frames, device=None, elevation=30.0):
+    """A D-NeRF test sequence of `n_frames` frames of the scene `sc`: the camera orbits once (azimuth 30 + 360 f / n) while the time
+    runs from 0 to 1 (frame 0 is the canonical frame t == 0, the last one t == 1) -- what the reference's test set is: one pose and
+    one time stamp per frame (dnerf/provider.py test split, dnerf/utils.py:151-161).  -> (rays_o list, rays_d list, times list)."""
+    device = device if device is not None else sc.rays_o.device
+    ros, rds, times = [], [], []
+    intr = scene.intrinsics(sc.H, sc.W)
+    for f in range(n_frames):
+        pose = scene.look_at_pose(30.0 + 360.0 * f / n_frames, elevation)
+        ro, rd = scene.get_rays(pose, intr, sc.H, sc.W)
+        ros.append(torch.from_numpy(ro).to(device))
+        rds.append(torch.from_numpy(rd).to(device))
+        times.append(float(f) / max(n_frames - 1, 1))
+    return ros, rds, times

@@ -54,6 +54,20 @@ class FrameGather:
         self.frame[self.all_idx] = self.gathered  # padding rows rewrite a pixel with its own value
         return self.frame
 
+    def gather_group(self, image_local, depth_local, frames, keep=False):
+        """A frame group's shard output (image_local [frames * per, 3], depth_local [frames * per], frame-major: what a
+        `DeviceLoop(frames=F)` renders on this rank) -> the `frames` full frames [n_rays, 4], with ONE all_gather_into_tensor per frame
+        exactly as for single frames.  keep=False: only the last assembled frame is returned (a consumer -- display, encoder,
+        metric -- takes each frame as it is assembled; the buffer is reused); keep=True: a list of copies."""
+        per = self.per
+        assert image_local.shape[0] == frames * per and depth_local.shape[0] == frames * per
+        out = []
+        for f in range(frames):
+            full = self(image_local[f * per:(f + 1) * per], depth_local[f * per:(f + 1) * per])
+            if keep:
+                out.append(full.clone())
+        return out if keep else full
+
 
 class GradSync:
     """Data-parallel training: every rank trains on its own ray batch with a full replica, gradients are averaged

@@ -119,18 +119,59 @@ class FusedField:
         self.H = int(enc.base_resolution)
         self.bound = float(model.bound)
         self.density_scale = float(model.density_scale)
+        self._time_cache, self._group_cache = {}, {}
         self.set_time(time)
         self._buf = None
         if max_points:
             self._alloc(max_points)
 
+    @staticmethod
+    def time_value(time):
+        """`time` (python number, or the reference's [B,1] tensor: one host read) as the float32 value the network sees."""
+        v = float(time.reshape(-1)[0]) if isinstance(time, torch.Tensor) else float(time)
+        return float(np.float32(v))
+
+    def time_constants(self, time):
+        """The constants one time stamp contributes to a frame, cached by VALUE: (bias0 [128] f32 -- the time encoding's
+        contribution W0[:,63:76] . freq(t, 6) to the first deform layer, fp16 operands, fp32 sum --, zero_deform flag (t == 0: the
+        canonical frame, dnerf/network.py:139-141), index of the occupancy-grid time slice (dnerf/renderer.py:285))."""
+        t = self.time_value(time)
+        hit = self._time_cache.get(t)
+        if hit is None:
+            dev = self.weights.device
+            with torch.no_grad(), torch.autocast("cuda", enabled=False):
+                enc_t = freq_encode(torch.tensor([[t]], dtype=torch.float32, device=dev), 6, 13).reshape(13)
+                w = self.model.deform_net[0].weight.detach()[:, 63:76]
+                bias0 = (w.to(torch.float16).float() @ enc_t.to(torch.float16).float()).contiguous()
+            T = self.model.time_size
+            t_idx = int(min(max(np.floor(np.float32(t) * np.float32(T)), 0), T - 1))
+            hit = (bias0, int(t == 0.0), t_idx)
+            if len(self._time_cache) >= 4096:
+                self._time_cache.clear()
+            self._time_cache[t] = hit
+        return hit
+
+    def invalidate_time_cache(self):
+        """Call after the first deform layer's weights changed (training): cached biases were computed from the old weights."""
+        self._time_cache.clear()
+
     def set_time(self, time):
-        """Per-frame constants: the time encoding's contribution to the first deform layer (fp16 operands, fp32 sum)."""
-        with torch.no_grad():
-            enc_t = freq_encode(time.reshape(1, 1).float(), 6, 13).reshape(13)
-            w = self.model.deform_net[0].weight.detach()[:, 63:76]
-            self.bias0 = (w.to(torch.float16).float() @ enc_t.to(torch.float16).float()).contiguous()
-        self.zero_deform = int(float(time.reshape(-1)[0]) == 0.0)
+        """Selects the time stamp `__call__` evaluates at (a frame loop passes times per frame instead)."""
+        self.bias0, self.zero_deform, self.t_idx = self.time_constants(time)
+
+    def group_constants(self, times):
+        """(bias0 [F,128] contiguous, zero_deform bit mask, slice indices) for the F frames of a frame group; cached by value."""
+        key = tuple(self.time_value(t) for t in times)
+        hit = self._group_cache.get(key)
+        if hit is None:
+            parts = [self.time_constants(t) for t in key]
+            bias = torch.stack([p[0] for p in parts]).contiguous()
+            mask = sum(p[1] << f for f, p in enumerate(parts))
+            hit = (bias, mask, [p[2] for p in parts])
+            if len(self._group_cache) >= 1024:
+                self._group_cache.clear()
+            self._group_cache[key] = hit
+        return hit
 
     def _alloc(self, M):
         dev = self.weights.device
@@ -175,6 +216,8 @@ class DensityGridUpdater:
         f, enc = self.field, self.model.encoder
         f.weights.copy_(torch.from_numpy(pack_weights(self.model)))
         f.table.copy_(enc.embeddings.detach())
+        f.invalidate_time_cache()
+        f._group_cache.clear()
 
     def time_bias(self, times):
         """[T] (perturbed) times -> bias0 [T,128], the expression of FusedField.set_time for every slice at once."""

@@ -457,11 +457,18 @@ class DeviceLoop:
     RING = 4
     MAX_TIMED = 24  # iterations whose fused-field launch can be timed in place (the headline frame has 11 + 1)
 
-    def __init__(self, model, field, N, device, max_steps=1024, T_thresh=1e-2, dt_gamma=0.0, mailbox=True, mapper=None):
+    def __init__(self, model, field, N, device, max_steps=1024, T_thresh=1e-2, dt_gamma=0.0, mailbox=True, mapper=None, frames=1):
+        """frames > 1: a FRAME GROUP -- the N rays are `frames` equal, frame-major blocks (the shards of consecutive frames of a camera
+        path / of successive time steps) rendered together by one loop, each at its own time (`bind(..., time=[t_0, ..., t_F-1])`):
+        the chain of ~30 dependent launches of a loop is paid once per group instead of once per frame.  Per-ray results do not
+        depend on which rays share a loop, so every frame of the group is bit-identical to the frame rendered alone."""
         import ctypes
-        from sdn_backend import lib, SdnRenderCtx
+        from sdn_backend import lib, SdnRenderCtx, MAX_GROUP_FRAMES
         f32, i32 = torch.float32, torch.int32
         self.model, self.field, self.N = model, field, N
+        self.frames = int(frames)
+        if not 1 <= self.frames <= MAX_GROUP_FRAMES or N % self.frames:
+            raise ValueError(f"a frame group holds 1..{MAX_GROUP_FRAMES} frames of equal ray count (N = {N}, frames = {frames})")
         M = N + 128 + 8 * 128
         n_counters = max_steps + 8
         z = lambda *shape, dt=f32: torch.empty(*shape, dtype=dt, device=device)  # noqa: E731
@@ -470,7 +477,9 @@ class DeviceLoop:
                         live_counts=torch.zeros(n_counters, dtype=i32, device=device), state=torch.zeros(16, dtype=i32, device=device),
                         trace=torch.zeros(2 * n_counters + 16, dtype=i32, device=device), n_out=torch.zeros(1, dtype=i32, device=device),
                         block_totals=z((N + 255) // 256 + 1, dt=i32), nears=z(N), fars=z(N), rays_tend=z(N),
-                        cull_bits=torch.empty(int(lib.sdn_cull_grid_bytes()), dtype=torch.uint8, device=device))
+                        cull_bits=torch.empty(self.frames * int(lib.sdn_cull_grid_bytes()), dtype=torch.uint8, device=device))
+        if self.frames > 1:
+            self.buf["slot_frame"] = torch.zeros(M, dtype=torch.uint8, device=device)
         self.image_out, self.depth_out = z(N, 3), z(N)
         self.snap = self.buf["trace"][2 * n_counters: 2 * n_counters + 8].view(4, 2)  # device ring written by the advance
         from sdn_backend import HostMailbox
@@ -490,6 +499,7 @@ class DeviceLoop:
         c.grid_S, c.grid_H = field.S, field.H
         c.N, c.M_cap, c.n_counters, c.max_steps, c.C, c.H = N, M, n_counters, int(max_steps), int(model.cascade), int(model.grid_size)
         c.bound, c.dt_gamma, c.T_thresh, c.density_scale = float(model.bound), float(dt_gamma), float(T_thresh), float(model.density_scale)
+        c.n_group_frames, c.rays_per_frame = (self.frames, N // self.frames) if self.frames > 1 else (0, 0)
         self.ctx = c
         self.max_steps = int(max_steps)
         self.set_mapper(mapper)
@@ -539,8 +549,27 @@ class DeviceLoop:
             self._timing_queue.append((arr, recs))
         torch.cuda.synchronize()
 
+    def frame_time(self, time):
+        """`SdnFrameTime` record (+ the tensors it points into) for `time`: one time stamp, or -- for a frame group -- one per
+        frame.  Everything is derived from the VALUE of the time stamp(s): the occupancy slice (dnerf/renderer.py:285), the
+        time-encoding bias of the first deform layer and the canonical-frame rule t == 0 (dnerf/network.py:130-141)."""
+        from sdn_backend import SdnFrameTime
+        model = self.model
+        times = list(time) if isinstance(time, (list, tuple)) else [time]
+        if len(times) == 1 and self.frames > 1:
+            times = times * self.frames
+        if len(times) != self.frames:
+            raise ValueError(f"{self.frames} frame(s) in this loop, {len(times)} time stamp(s) given")
+        bias, mask, slices = self.field.group_constants(times)
+        ft = SdnFrameTime()
+        bits = [model.density_bitfield[s_] for s_ in slices]          # views (no host sync: python int index)
+        for f, b_ in enumerate(bits):
+            ft.bitfield[f] = b_.data_ptr()
+        ft.field_bias0, ft.zero_deform = bias.data_ptr(), mask
+        return ft, (bias, bits)
+
     def bind(self, rays_o, rays_d, time):
-        """Points the context at this frame's rays / time slice (launches near_far_from_aabb on the current stream)."""
+        """Points the context at this frame's rays and time constants (the native driver launches near_far_from_aabb itself)."""
         import ctypes
         from sdn_backend import ptr
         c, model = self.ctx, self.model
@@ -549,15 +578,12 @@ class DeviceLoop:
         assert rays_o.shape[0] == self.N
         nears, fars = self.buf["nears"], self.buf["fars"]  # filled by the native driver (ctx.aabb / ctx.min_near)
         c.aabb, c.min_near = ptr(model.aabb_infer, torch.float32, "aabb_infer"), float(model.min_near)
-        # the time slice of the occupancy grid is a per-timestep constant like the field's time bias: resolved once per distinct
-        # `time` tensor state (the reference indexes with a device scalar every frame, dnerf/renderer.py:285, a host sync)
-        key = (time.data_ptr(), time._version, model.density_bitfield.data_ptr())
-        if getattr(self, "_slice_key", None) != key:
-            self._slice_key, self._slice = key, model.density_bitfield[model.time_slice(time)]
-        bitfield = self._slice
-        c.rays_o, c.rays_d, c.bitfield = ptr(rays_o, torch.float32, "rays_o"), ptr(rays_d, torch.float32, "rays_d"), ptr(bitfield)
-        c.field_bias0, c.zero_deform = self.field.bias0.data_ptr(), int(self.field.zero_deform)
-        self._frame_refs = (rays_o, rays_d, nears, fars, bitfield)  # keep the tensors alive while the frame is in flight
+        ft, refs = self.frame_time(time)
+        c.rays_o, c.rays_d = ptr(rays_o, torch.float32, "rays_o"), ptr(rays_d, torch.float32, "rays_d")
+        c.bitfield, c.field_bias0, c.zero_deform = ft.bitfield[0], ft.field_bias0, int(ft.zero_deform)
+        for f in range(self.frames):
+            c.frame_bitfield[f] = ft.bitfield[f]
+        self._frame_refs = (rays_o, rays_d, nears, fars, refs)  # keep the tensors alive while the frame is in flight
         cur = torch.cuda.current_stream()
         if self._handles is None:  # materialise raw hipEvent_t / hipStream_t handles once
             for e in self.events + self.copy_events:
@@ -597,79 +623,6 @@ class DeviceLoop:
         return self.collect(nears, fars, want_stats)
 
 
-class GroupedDeviceLoop:
-    """G independent device-driven loops over disjoint, interleaved subsets of the frame's rays, each on its own HIP stream,
-    all driven round-robin by ONE host thread inside `sdn_render_frame_groups_f16`, so that the latency-bound phases of one
-    group (the marcher's dependent probe chains, the small bookkeeping launches, launch / read-back gaps) run under the
-    throughput-bound field kernel of another, and the half-size field kernels that share the CUs run out of phase.
-    Exact by construction: per-ray results do not depend on which rays share a launch; only the
-    per-group n_step schedule -- hence the number of samples marched past a ray's termination -- can differ from the
-    one-group schedule when N_g // n_alive_g falls on the other side of an integer than N // n_alive."""
-
-    def __init__(self, model, field, rays_o, rays_d, groups, W, device, **kw):
-        import ctypes
-        from .dist import shard_rays
-        from sdn_backend import SdnRenderCtx
-        N = rays_o.shape[0]
-        self.N, self.G, self.device = N, groups, device
-        self.idx, self.rays, self.loops, self.streams = [], [], [], []
-        for g in range(groups):
-            idx, _ = shard_rays(N, W, g, groups)
-            idx = torch.from_numpy(np.unique(idx)).to(device)  # no padding needed on one GPU
-            self.idx.append(idx)
-            self.rays.append((rays_o[idx].contiguous(), rays_d[idx].contiguous()))
-            self.loops.append(DeviceLoop(model, field, idx.shape[0], device, **kw))
-            self.streams.append(torch.cuda.Stream(device=device))
-        self.image = torch.empty(N, 3, dtype=torch.float32, device=device)
-        self.depth = torch.empty(N, dtype=torch.float32, device=device)
-        from sdn_backend import HostMailbox
-        self.host_state = HostMailbox(groups)
-        self._ctxs = (ctypes.POINTER(SdnRenderCtx) * groups)(*[ctypes.pointer(lp.ctx) for lp in self.loops])
-        self._iters = (ctypes.c_uint32 * groups)()
-        self._arrays = None
-
-    def prepare_timing(self, frames):
-        """The grouped driver does not time individual launches (its kernels overlap; a per-launch duration is not a rate)."""
-
-    @torch.no_grad()
-    def render(self, time, bg_color=1.0, want_stats=True):
-        import ctypes
-        from sdn_backend import lib, check
-        cur = torch.cuda.current_stream()
-        bound = []
-        for g, lp in enumerate(self.loops):
-            self.streams[g].wait_stream(cur)
-            with torch.cuda.stream(self.streams[g]):
-                bound.append(lp.bind(self.rays[g][0], self.rays[g][1], time))
-                lp.side.wait_stream(self.streams[g])
-        if self._arrays is None:
-            vp = ctypes.c_void_p
-            G = self.G
-            self._arrays = dict(
-                images=(vp * G)(*[lp.image_out.data_ptr() for lp in self.loops]),
-                depths=(vp * G)(*[lp.depth_out.data_ptr() for lp in self.loops]),
-                streams=(vp * G)(*[s.cuda_stream for s in self.streams]),
-                sides=(vp * G)(*[lp.side.cuda_stream for lp in self.loops]),
-                ev_main=(vp * (4 * G))(*[e.cuda_event for lp in self.loops for e in lp.events]),
-                ev_copy=(vp * (4 * G))(*[e.cuda_event for lp in self.loops for e in lp.copy_events]))
-        a = self._arrays
-        check(lib.sdn_render_frame_groups_f16(self._ctxs, self.G, float(bg_color), a["images"], a["depths"], a["streams"], a["sides"],
-                                              a["ev_main"], a["ev_copy"], self.host_state.data_ptr(), self._iters), "render_frame_groups_f16")
-        outs = []
-        for g, lp in enumerate(self.loops):
-            with torch.cuda.stream(self.streams[g]):
-                self.image[self.idx[g]] = lp.image_out
-                self.depth[self.idx[g]] = lp.depth_out
-            cur.wait_stream(self.streams[g])
-        res = {"image": self.image, "depth": self.depth}
-        if want_stats:
-            outs = [lp.collect(bound[g][0], bound[g][1], True) for g, lp in enumerate(self.loops)]
-            res["n_samples"] = sum(o["n_samples"] for o in outs)
-            res["trace"] = max((o["trace"] for o in outs), key=len)
-            res["group_traces"] = [o["trace"] for o in outs]
-        return res
-
-
 class PipelinedDeviceLoop:
     """A stream of frames (camera path / time steps of one model) through `contexts` `DeviceLoop` contexts used in turn, each on its
     own HIP stream, all driven by one host thread in `sdn_render_frames_pipelined_f16`: the next frame starts as soon as a
@@ -690,7 +643,10 @@ class PipelinedDeviceLoop:
 
     @torch.no_grad()
     def render_frames(self, rays_o, rays_d, time, bg_color=1.0, outputs=None, timing=None, exclusive=None):
-        """rays_o / rays_d: lists of [N,3] tensors, one per frame (entries may repeat).  outputs: optional list of (image [N,3],
+        """rays_o / rays_d: lists of [N,3] tensors, one per frame (entries may repeat).  time: ONE time stamp for the whole stream
+        (number or the reference's [1,1] tensor), or a list with one entry per frame -- a D-NeRF test set carries its own time for
+        every frame (dnerf/utils.py:151-161); with frame-group contexts (`frames=F`) an entry is itself a list of F times.
+        outputs: optional list of (image [N,3],
         depth [N]) tensors per frame; by default frame f lands in the output buffers of context f % contexts.  timing: optional list
         (per frame, None allowed) of ctypes arrays of 2 * DeviceLoop.MAX_TIMED hipEvent_t for that frame's field launches.
         exclusive: optional list of bools per frame; a flagged frame is rendered with nothing else in flight.
@@ -704,10 +660,20 @@ class PipelinedDeviceLoop:
         cur = torch.cuda.current_stream()
         ro = [r.contiguous().view(-1, 3) for r in rays_o]
         rd = [r.contiguous().view(-1, 3) for r in rays_d]
+        from sdn_backend import SdnFrameTime
+        times = list(time) if isinstance(time, (list, tuple)) else [time] * n     # a list is ALWAYS one entry per frame
+        if len(times) != n:
+            raise ValueError(f"{n} frames, {len(times)} time entries")
+        a_ft = (SdnFrameTime * n)()
+        ft_refs = []
+        for f in range(n):
+            rec, refs = self.loops[0].frame_time(times[f])
+            a_ft[f] = rec
+            ft_refs.append(refs)
         for s, lp in enumerate(self.loops):
             self.streams[s].wait_stream(cur)
             with torch.cuda.stream(self.streams[s]):
-                lp.bind(ro[min(s, n - 1)], rd[min(s, n - 1)], time)     # time slice, aabb, field constants; rays are set per frame
+                lp.bind(ro[min(s, n - 1)], rd[min(s, n - 1)], times[min(s, n - 1)])     # aabb, handles; rays and time constants are set per frame
                 lp.side.wait_stream(self.streams[s])
         if outputs is None:
             outputs = [(self.loops[f % self.K].image_out, self.loops[f % self.K].depth_out) for f in range(n)]
@@ -733,8 +699,10 @@ class PipelinedDeviceLoop:
         _t0 = _t.perf_counter()
         check(lib.sdn_render_frames_pipelined_f16(self._ctxs, self.K, n, a_ro, a_rd, a_img, a_dep, float(bg_color), self.overlap_div, fx["streams"],
                                                   fx["sides"], fx["ev_main"], fx["ev_copy"], self.host_state.data_ptr(), a_ev, n_ev,
-                                                  (ctypes.c_uint8 * n)(*[1 if e else 0 for e in exclusive]) if exclusive is not None else None, iters),
+                                                  (ctypes.c_uint8 * n)(*[1 if e else 0 for e in exclusive]) if exclusive is not None else None,
+                                                  a_ft, iters),
               "render_frames_pipelined_f16")
+        self._ft_refs = ft_refs    # the per-frame constants stay alive until the next stream of frames
         _t1 = _t.perf_counter()
         for s in self.streams:
             cur.wait_stream(s)

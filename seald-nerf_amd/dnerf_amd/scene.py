@@ -12,6 +12,7 @@ gives the specification this follows.
     bitfield layout the marching kernels read (bit i%8 of byte i/8, raymarching.cu:378-379).
   * "lego-like" occupancy: a 0.6-side box with a 4x4 stud pattern on top.
 """
+import functools
 import math
 
 import numpy as np
@@ -73,23 +74,34 @@ def _capsule_dist(p, a, b):
     return np.linalg.norm(pa - h[:, None] * ba, axis=1)
 
 
-def _cell_centres(H):
+@functools.lru_cache(maxsize=4)
+def _grid_cache(H):
+    """(cell-centre coordinate per index [H] float64, Morton index of every cell in (ix, iy, iz) C order [H^3] uint32)."""
     c = (np.arange(H, dtype=np.float64) + 0.5) * 2.0 / H - 1.0
     ix, iy, iz = np.meshgrid(np.arange(H), np.arange(H), np.arange(H), indexing="ij")
-    pts = np.stack([c[ix.reshape(-1)], c[iy.reshape(-1)], c[iz.reshape(-1)]], -1)
-    return pts, ix.reshape(-1), iy.reshape(-1), iz.reshape(-1)
+    return c, morton3d(ix.reshape(-1), iy.reshape(-1), iz.reshape(-1))
 
 
-def _occupancy_to_bitfield(occ, ix, iy, iz, H):
-    idx = morton3d(ix, iy, iz)
+def _index_range(c, lo, hi):
+    """[i0, i1) of the cell centres c (ascending) inside [lo, hi]."""
+    return int(np.searchsorted(c, lo, side="left")), int(np.searchsorted(c, hi, side="right"))
+
+
+def _block_points(c, lo, hi):
+    """Cell centres inside the axis-aligned box [lo, hi] as ([n,3] points, the three index ranges)."""
+    r = [_index_range(c, lo[a], hi[a]) for a in range(3)]
+    gx, gy, gz = np.meshgrid(c[r[0][0]:r[0][1]], c[r[1][0]:r[1][1]], c[r[2][0]:r[2][1]], indexing="ij")
+    return np.stack([gx.reshape(-1), gy.reshape(-1), gz.reshape(-1)], -1), r
+
+
+def _occupancy_to_bitfield(occ3, H):
+    """occ3 [H,H,H] bool in (ix, iy, iz) order -> Morton-ordered bitfield (bit i%8 of byte i/8)."""
     flat = np.zeros(H * H * H, dtype=np.uint8)
-    flat[idx[occ]] = 1
+    flat[_grid_cache(H)[1]] = occ3.reshape(-1)
     return np.packbits(flat.reshape(-1, 8), axis=1, bitorder="little").reshape(-1)
 
 
-def jumpingjacks_occupancy(t, H=128):
-    """uint8 [H^3/8] Morton bitfield of the capsule figure at time t in [0,1] (cascade 0, bound 1)."""
-    pts, ix, iy, iz = _cell_centres(H)
+def _capsule_parts(t):
     ang = math.radians(40.0) * math.sin(2 * math.pi * t)
     parts = []
     parts.append((np.array([0.0, -0.15, 0.0]), np.array([0.0, 0.30, 0.0]), 0.11))          # torso
@@ -103,34 +115,58 @@ def jumpingjacks_occupancy(t, H=128):
     la = 0.5 * abs(ang)
     parts.append((hip_l, hip_l + leg * np.array([-math.sin(la), -math.cos(la), 0.0]), 0.055))  # legs
     parts.append((hip_r, hip_r + leg * np.array([math.sin(la), -math.cos(la), 0.0]), 0.055))
-    occ = np.zeros(pts.shape[0], dtype=bool)
-    for a, b, r in parts:
-        lo = np.minimum(a, b) - r - 2.0 / H
-        hi = np.maximum(a, b) + r + 2.0 / H
-        m = np.all((pts >= lo) & (pts <= hi), axis=1)
-        sel = np.nonzero(m)[0]
-        occ[sel] |= _capsule_dist(pts[sel], a, b) < r
-    return _occupancy_to_bitfield(occ, ix, iy, iz, H)
+    return parts
 
 
-def lego_occupancy(H=128):
+def jumpingjacks_occupancy(t, H=128, half_extent=1.0):
+    """uint8 [H^3/8] Morton bitfield of the capsule figure at time t in [0,1]; the grid spans [-half_extent, half_extent]^3
+    (1 = cascade 0 of a bound-1 scene; 2 = the second cascade of a bound-2 scene)."""
+    c = _grid_cache(H)[0] * half_extent
+    occ = np.zeros((H, H, H), dtype=bool)
+    for a, b, r in _capsule_parts(t):
+        lo = np.minimum(a, b) - r - 2.0 * half_extent / H
+        hi = np.maximum(a, b) + r + 2.0 * half_extent / H
+        pts, rg = _block_points(c, lo, hi)
+        if pts.shape[0]:
+            hit = (_capsule_dist(pts, a, b) < r).reshape(rg[0][1] - rg[0][0], rg[1][1] - rg[1][0], rg[2][1] - rg[2][0])
+            occ[rg[0][0]:rg[0][1], rg[1][0]:rg[1][1], rg[2][0]:rg[2][1]] |= hit
+    return _occupancy_to_bitfield(occ, H)
+
+
+def lego_occupancy(H=128, half_extent=1.0):
     """uint8 [H^3/8] Morton bitfield: 0.6-side box with a 4x4 stud pattern on its top face."""
-    pts, ix, iy, iz = _cell_centres(H)
-    occ = np.all(np.abs(pts) <= np.array([0.3, 0.15, 0.3]), axis=1)
+    c = _grid_cache(H)[0] * half_extent
+    X, Y, Z = c[:, None, None], c[None, :, None], c[None, None, :]
+    occ = (np.abs(X) <= 0.3) & (np.abs(Y) <= 0.15) & (np.abs(Z) <= 0.3)
     for sx in range(4):
         for sz in range(4):
             cx, cz = -0.225 + 0.15 * sx, -0.225 + 0.15 * sz
-            r2 = (pts[:, 0] - cx) ** 2 + (pts[:, 2] - cz) ** 2
-            occ |= (r2 < 0.045 ** 2) & (pts[:, 1] > 0.15) & (pts[:, 1] < 0.21)
-    return _occupancy_to_bitfield(occ, ix, iy, iz, H)
+            r2 = (X - cx) ** 2 + (Z - cz) ** 2
+            occ = occ | ((r2 < 0.045 ** 2) & (Y > 0.15) & (Y < 0.21))
+    return _occupancy_to_bitfield(occ, H)
 
 
 def density_bitfield_all_times(time_size=64, H=128, kind="jumpingjacks", times=None):
     """[time_size, H^3/8] uint8, one slice per density-grid time stamp (dnerf/renderer.py:93,99)."""
-    out = np.zeros((time_size, H * H * H // 8), dtype=np.uint8)
+    return density_bitfield_cascades(time_size, H, 1, 1.0, kind, times)
+
+
+def density_bitfield_cascades(time_size=64, H=128, cascade=1, bound=1.0, kind="jumpingjacks", times=None):
+    """[time_size, cascade * H^3/8] uint8: per time stamp the `cascade` Morton grids back to back (dnerf/renderer.py:92-93);
+    cascade c spans [-min(2^c, bound), +min(2^c, bound)]^3 (raymarching.cu:371-379)."""
+    per = H * H * H // 8
+    out = np.zeros((time_size, cascade * per), dtype=np.uint8)
+    lego = {}
     for k in range(time_size):
         if times is not None and k not in times:
             continue
         t = (k + 0.5) / time_size
-        out[k] = jumpingjacks_occupancy(t, H) if kind == "jumpingjacks" else lego_occupancy(H)
+        for cas in range(cascade):
+            ext = min(float(2 ** cas), float(bound))
+            if kind == "jumpingjacks":
+                out[k, cas * per:(cas + 1) * per] = jumpingjacks_occupancy(t, H, ext)
+            else:
+                if cas not in lego:
+                    lego[cas] = lego_occupancy(H, ext)
+                out[k, cas * per:(cas + 1) * per] = lego[cas]
     return out

@@ -26,17 +26,13 @@ class EditTrainStep:
     def __init__(self, teacher, student, mapper, optimizer, scaler, n_rays, device, time, **render_kw):
         self.teacher, self.student = teacher, student
         self.field = fused.FusedField(teacher, time, fp16=True)
-        self._time_key = None
         self.loop = DeviceLoop(teacher, self.field, n_rays, device, T_thresh=1e-4, mapper=mapper)
         self.step = GraphedTrainStep(student, optimizer, scaler, n_rays, device, **render_kw)
 
     @torch.no_grad()
     def proxy_truth(self, rays_o, rays_d, time, bg_color=1.0):
         """Teacher colours [n_rays, 3] for these rays (the edited scene)."""
-        key = (time.data_ptr(), time._version)
-        if key != self._time_key:            # the time bias of the fused kernel is a per-timestep constant
-            self.field.set_time(time)
-            self._time_key = key
+        # (the loop derives the time slice / time bias / canonical-frame flag from the VALUE of `time`, cached per value)
         return self.loop.render(rays_o, rays_d, time, bg_color=bg_color, want_stats=False)["image"]
 
     def __call__(self, rays_o, rays_d, time):

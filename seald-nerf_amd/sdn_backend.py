@@ -45,8 +45,7 @@ PROTOTYPES = {
     "sdn_render_step_f16_ev": [_vp, _u32, _vp, _vp, _vp],
     "sdn_render_finish": [_vp, _f32, _vp, _vp, _vp],
     "sdn_render_frame_f16": [_vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
-    "sdn_render_frame_groups_f16": [_vp, _u32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "sdn_render_frames_pipelined_f16": [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp],
+    "sdn_render_frames_pipelined_f16": [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp],
     "sdn_host_mailbox_free": [_vp],
     "sdn_seal_bbox_map": [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sdn_seal_modify_hsv": [_vp, _vp, _u32, _f32, _f32, _f32, _vp],
@@ -58,6 +57,14 @@ PROTOTYPES = {
     "sdn_ffmlp_inference": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     "sdn_ffmlp_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp],
 }
+MAX_GROUP_FRAMES = 16   # SDN_MAX_GROUP_FRAMES
+
+
+class SdnFrameTime(ctypes.Structure):
+    """Mirror of `SdnFrameTime` in include/sdn_hip.h: the time-dependent constants of one frame (or of each frame of a group)."""
+    _fields_ = [("bitfield", _vp * MAX_GROUP_FRAMES), ("field_bias0", _vp), ("zero_deform", _u32)]
+
+
 class SdnRenderCtx(ctypes.Structure):
     """Mirror of `SdnRenderCtx` in include/sdn_hip.h (field order and types must match)."""
     _fields_ = ([(n, _vp) for n in ("rays_o", "rays_d", "nears", "fars", "bitfield", "cull_bits", "alive_a", "alive_b", "rays_t",
@@ -67,7 +74,8 @@ class SdnRenderCtx(ctypes.Structure):
                 + [("grid_offsets", ctypes.c_int32 * 17), ("grid_S", _f32), ("grid_H", _u32)]
                 + [(n, _u32) for n in ("N", "M_cap", "n_counters", "max_steps", "C", "H")]
                 + [(n, _f32) for n in ("bound", "dt_gamma", "T_thresh", "density_scale")]
-                + [("zero_deform", ctypes.c_int32), ("aabb", _vp), ("min_near", _f32), ("reserved_", ctypes.c_int32), ("rays_tend", _vp), ("seal", _vp), ("seal_mask", _vp)])
+                + [("zero_deform", ctypes.c_int32), ("aabb", _vp), ("min_near", _f32), ("reserved_", ctypes.c_int32), ("rays_tend", _vp), ("seal", _vp), ("seal_mask", _vp),
+                   ("n_group_frames", _u32), ("rays_per_frame", _u32), ("frame_bitfield", _vp * MAX_GROUP_FRAMES), ("slot_frame", _vp)])
 
 
 class SdnSealBox(ctypes.Structure):

@@ -252,21 +252,6 @@ def test_seald_teacher_render_matches_native_loop(small_scene):
     assert torch.isfinite(c["image"]).all() and not torch.equal(c["image"], a["image"])
 
 
-def test_grouped_device_loop_matches_single_loop(small_scene):
-    """G ray groups on G streams / host threads assemble the same image bit for bit as one device loop."""
-    from dnerf_amd import fused
-    from dnerf_amd.renderer import DeviceLoop, GroupedDeviceLoop
-    sc = small_scene
-    f = fused.FusedField(sc.model, sc.time, fp16=True)
-    a = DeviceLoop(sc.model, f, sc.rays_o.shape[0], sc.rays_o.device).render(sc.rays_o, sc.rays_d, sc.time)
-    img_a, dep_a = a["image"].clone(), a["depth"].clone()
-    for G in (2, 3):
-        b = GroupedDeviceLoop(sc.model, f, sc.rays_o, sc.rays_d, G, sc.W, sc.rays_o.device).render(sc.time)
-        torch.cuda.synchronize()
-        assert torch.equal(img_a, b["image"])
-        assert torch.equal(torch.nan_to_num(dep_a), torch.nan_to_num(b["depth"]))
-
-
 def test_device_loop_readback_paths_agree_and_repeat(small_scene):
     """The two read-back mechanisms of the frame driver -- host mailbox polled by the host (coherent mapped memory, one
     64-bit store per iteration) and event + side-stream copy (ordinary pinned memory) -- drive the same loop: identical
