@@ -195,7 +195,10 @@ uint32_t sdn_field_weight_blocks(void);
 /* sigma [M], rgb [M,3] of sample points xyzs/dirs [M,3] for the dnerf field network (freq(10) ++ time bias -> 8x128
  * deform MLP -> tiled grid 16x2 (fp16 table) -> 64,16 sigma MLP; SH(4) ++ geo_feat -> 64,64,3 colour MLP), with the
  * reference's autocast numerics.  live_idx/live_count (both or neither): evaluate only the listed slots; the count is read
- * on the device.  bias0 [128] f32: W0[:,63:76] . freq(t, 6).  offsets_host [17]: level row offsets. */
+ * on the device.  bias0 [128] f32: W0[:,63:76] . freq(t, 6).  offsets_host [17]: level row offsets.  The table may be in the
+ * reference's layout (level sizes multiples of 8 rows, grid.py:124) or PADDED -- every level followed by one extra row that
+ * repeats the level's row 0 (level sizes == 1 mod 8; the layout is recognised from the offsets) -- which takes the wrap
+ * bookkeeping of `(index + 1) % hashmap_size` out of the gather path (dnerf_amd/fused.py builds this layout). */
 int sdn_field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count,
                           uint32_t M, const void *weights, const float *bias0, const void *table,
                           const int32_t *offsets_host, float S, uint32_t H, float bound, float density_scale,

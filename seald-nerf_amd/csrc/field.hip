@@ -187,6 +187,28 @@ __device__ __forceinline__ float fast_sin(float a) {
     return __int_as_float(__float_as_int(s) ^ ((ki & 1) << 31));
 }
 
+// sin(a) and cos(a) with one shared Cody-Waite reduction by pi: r = a - k pi in [-pi/2, pi/2], sin(a) = (-1)^k sin(r),
+// cos(a) = (-1)^k cos(r); odd degree-9 / even degree-10 minimax polynomials (~1e-7 absolute for |a| < ~1e4).
+__device__ __forceinline__ void fast_sincos(float a, float &sn, float &cs) {
+    const float k = rintf(a * 0.31830988618379067f);
+    float r = __builtin_fmaf(-k, 3.140625f, a);
+    r = __builtin_fmaf(-k, 9.67502593994140625e-4f, r);
+    r = __builtin_fmaf(-k, 1.509957990978376e-7f, r);
+    const float r2 = r * r;
+    float p = __builtin_fmaf(r2, 2.6083159809786593e-6f, -1.9810690719168633e-4f);
+    p = __builtin_fmaf(p, r2, 8.3330785855650902e-3f);
+    p = __builtin_fmaf(p, r2, -1.6666659712791443e-1f);
+    const float s = __builtin_fmaf(r * r2, p, r);
+    float q = __builtin_fmaf(r2, -2.6051615e-07f, 2.4760495e-05f);
+    q = __builtin_fmaf(q, r2, -1.3888378e-03f);
+    q = __builtin_fmaf(q, r2, 4.1666638e-02f);
+    q = __builtin_fmaf(q, r2, -0.5f);
+    const float c = __builtin_fmaf(q, r2, 1.0f);
+    const int sign = ((int)k & 1) << 31;
+    sn = __int_as_float(__float_as_int(s) ^ sign);
+    cs = __int_as_float(__float_as_int(c) ^ sign);
+}
+
 // Stage `nbytes` (multiple of 4 KiB) of packed weights global -> LDS, all 256 threads, 16 B per lane per instruction.
 // One wave-instruction moves 1 KiB to a wave-uniform LDS base + lane * 16 (global_load_lds_dwordx4).
 __device__ __forceinline__ void stage_load(const unsigned char *__restrict__ g, unsigned char *lds, int nbytes, uint32_t wave, uint32_t lane) {
@@ -216,7 +238,9 @@ __device__ __forceinline__ half8 lds_frag(const unsigned char *buf, int blk, uin
 //           fragments is read ahead (256-VGPR budget).
 // CELLS: the density-grid query of update_extra_state (dnerf/renderer.py:453-555): slot p is a Morton cell index, the point is
 //   that cell's jittered centre, only sigma is evaluated and it is stored at sigmas[p] (a slice of tmp_grid).
-template <int OCC, int LA, bool CELLS>
+// PAD: the table is the PADDED layout (every level followed by one extra row that repeats the level's row 0): the (x, x+1) row
+//   pair of a gather is then always two consecutive rows -- no clamp, no wrap bookkeeping, no patch path.
+template <int OCC, int LA, bool CELLS, bool PAD>
 __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, TiledLevels lv) {
     constexpr int kGridBatch = OCC >= 4 ? 4 : 8;   // grid levels (per lane-half) whose gathers are in flight together (register budget)
     __shared__ __attribute__((aligned(16))) unsigned char s_w[2][kStageBytes];
@@ -266,11 +290,32 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     }
 
     // ---------------- deform layer 0: freq features as B fragments ----------------
-    // lane-half h owns (freq, dim) pairs 15h .. 15h+14 (sin and cos) plus x0,x1 (h = 0) / x2,pad (h = 1)
+    // lane-half h owns (freq, dim) pairs 15h .. 15h+14 (sin and cos) plus x0,x1 (h = 0) / x2,pad (h = 1), i.e. the five octaves
+    // 2^(5h) .. 2^(5h+4) of every coordinate.  One sine / cosine pair per coordinate at the lane-half's base octave (shared range
+    // reduction, two short polynomials), the four higher octaves by angle doubling in fp32:  s' = 2 s c,  c' = 1 - 2 s^2  -- 6
+    // polynomial evaluations + 48 multiply-adds per lane instead of 30 sine evaluations.  The doubling error (<= 2^4 x 1e-7) is two
+    // orders of magnitude below the fp16 rounding the features get as MFMA operands; kernel_freq (freqencoder.cu:52-56) evaluates
+    // cos as sin(x 2^f + float(pi/2)), which is itself off by up to 3e-5 at 2^9 -- the values here are the closer to the exact ones.
     half8 bf[8];
     {
         const float xs[3] = {x0, x1, x2};
-        const float fscale = h ? 32.0f : 1.0f;  // pair index 15h + q/2  ->  freq = 5h + (q/2)/3
+        const float fscale = h ? 32.0f : 1.0f;
+        float sv[5][3], cv[5][3];
+        #pragma unroll
+        for (int dd = 0; dd < 3; dd++) {
+#if SDN_ABL == 1
+            sv[0][dd] = xs[dd] * fscale; cv[0][dd] = xs[dd];
+#else
+            fast_sincos(xs[dd] * fscale, sv[0][dd], cv[0][dd]);
+#endif
+            #pragma unroll
+            for (int f = 1; f < 5; f++) {
+                const float sp = sv[f - 1][dd], cp = cv[f - 1][dd];
+                const float t = sp * cp;
+                sv[f][dd] = t + t;
+                cv[f][dd] = __builtin_fmaf(sp * -2.0f, sp, 1.0f);
+            }
+        }
         #pragma unroll
         for (int s = 0; s < 4; s++) {
             #pragma unroll
@@ -279,13 +324,7 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
                 float v;
                 if (q < 30) {
                     const int pr = q >> 1, f = pr / 3, dd = pr % 3;
-                    // kernel_freq (freqencoder.cu:52-56): sin(x * 2^f + (col % 2) * pi/2), same float argument as encoders.hip
-                    const float arg = scalbnf(xs[dd], f) * fscale + (float)(q & 1) * (3.141592653589793f / 2);
-#if SDN_ABL == 1
-                    v = arg;
-#else
-                    v = fast_sin(arg);
-#endif
+                    v = (q & 1) ? cv[f][dd] : sv[f][dd];
                 } else if (q == 30) {
                     v = h ? x2 : x0;
                 } else {
@@ -440,20 +479,21 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
                 for (uint32_t c = 0; c < 4; c++) {
                     uint32_t tab, row0, mask, hsize;
                     corner(lq, c, tab, row0, mask, hsize, pos[lq]);
-                    const uint32_t rl = min(row0, hsize - 2u);          // the pair (rl, rl + 1) is always inside the level
+                    // the pair (rl, rl + 1) is always inside the level (PAD: row hsize exists and repeats row 0)
+                    const uint32_t rl = PAD ? row0 : min(row0, hsize - 2u);
 #if SDN_ABL == 2
                     pairs[lq][c] = make_uint2(rl, rl + 1u);
 #else
                     __builtin_memcpy(&pairs[lq][c], table_bytes + ((tab + rl) << 2), 8);   // 4-byte aligned 8-byte gather
 #endif
-                    if (row0 > rl) wrapbits |= 1u << (4 * lq + (int)c);
+                    if (!PAD && row0 > rl) wrapbits |= 1u << (4 * lq + (int)c);
                 }
             }
 #if SDN_ABL != 2
             // On a capped level the x corner may be the LAST row: it is then the second row of the pair that was fetched and the
             // x+1 corner is row 0.  Patched after every gather of the batch has been issued (a branch per gather would make each
             // wait for its own data); practically never taken (1 row in 2^19).
-            if (__builtin_expect(wrapbits != 0u, 0)) {
+            if (!PAD && __builtin_expect(wrapbits != 0u, 0)) {
                 #pragma unroll
                 for (int lq = 0; lq < kGridBatch; lq++) {
                     #pragma unroll
@@ -594,9 +634,18 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     }
 }
 
+// The reference sizes every level to a multiple of 8 rows (grid.py:124); a PADDED table (one extra row per level repeating the
+// level's row 0, built by dnerf_amd/fused.py) has level sizes == 1 mod 8, so the layout is self-describing.
+bool table_is_padded(const int32_t *offsets_host) {
+    for (uint32_t l = 0; l < 16; l++)
+        if (((uint32_t)(offsets_host[l + 1] - offsets_host[l]) & 7u) != 1u) return false;
+    return true;
+}
+
 int fill_tiled_levels(TiledLevels &lv, const int32_t *offsets_host, float S, uint32_t H) {
+    const bool padded = table_is_padded(offsets_host);
     for (uint32_t l = 0; l < 16; l++) {
-        const uint32_t hsize = (uint32_t)(offsets_host[l + 1] - offsets_host[l]);
+        const uint32_t hsize = (uint32_t)(offsets_host[l + 1] - offsets_host[l]) - (padded ? 1u : 0u);
         if (hsize == 0) return SDN_E_BADARG;
         const float scale = exp2f((float)l * S) * (float)H - 1.0f;  // gridencoder.cu:138
         const uint32_t res = (uint32_t)ceil((double)scale) + 1;      // gridencoder.cu:139
@@ -647,10 +696,14 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
     }
     // expect_points (0 = unknown): the caller's estimate of the live points when M is only a loose bound of them
     const uint32_t busy = expect_points ? sdn_div_up(expect_points < M ? expect_points : M, (uint32_t)kPointsPerWG) : wgs;
-    if (busy <= (uint32_t)cus)
-        hipLaunchKernelGGL((k_field_f16<2, 8, false>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
-    else
-        hipLaunchKernelGGL((k_field_f16<4, 2, false>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+    const bool small = busy <= (uint32_t)cus;
+    if (table_is_padded(offsets_host)) {
+        if (small) hipLaunchKernelGGL((k_field_f16<2, 8, false, true>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+        else hipLaunchKernelGGL((k_field_f16<4, 2, false, true>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+    } else {
+        if (small) hipLaunchKernelGGL((k_field_f16<2, 8, false, false>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+        else hipLaunchKernelGGL((k_field_f16<4, 2, false, false>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+    }
     return sdn_launch_status();
 }
 
@@ -670,10 +723,11 @@ int field_cells_f16(const int32_t *cells, const uint32_t *cell_count, uint32_t n
     const float half_grid = cas_bound / (float)grid_size;
     a.cell_inv = 1.0f / (float)(grid_size - 1); a.cell_span = cas_bound - half_grid; a.cell_half = half_grid;
     const uint32_t wgs = sdn_div_up(n, (uint32_t)kPointsPerWG);
+    if (!table_is_padded(offsets_host)) return SDN_E_UNSUPPORTED;   // the density query is only built for the padded layout
     if (wgs <= 256u)
-        hipLaunchKernelGGL((k_field_f16<2, 8, true>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+        hipLaunchKernelGGL((k_field_f16<2, 8, true, true>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
     else
-        hipLaunchKernelGGL((k_field_f16<4, 2, true>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+        hipLaunchKernelGGL((k_field_f16<4, 2, true, true>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
     return sdn_launch_status();
 }
 

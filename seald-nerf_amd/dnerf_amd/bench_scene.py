@@ -43,9 +43,9 @@ def _probe_points(bitfield_slice, n, seed):
     return ((c + 0.5) * (2.0 / 128) - 1.0).astype(np.float32)
 
 
-def build_model(seed=0, device="cuda"):
+def build_model(seed=0, device="cuda", bound=1, bg_radius=-1):
     torch.manual_seed(seed)
-    model = NeRFNetwork(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1)
+    model = NeRFNetwork(bound=bound, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=bg_radius)
     with torch.no_grad():
         model.encoder.embeddings.mul_(1e3)
         model.deform_net[-1].weight.mul_(0.05)
@@ -69,13 +69,14 @@ def calibrate_density(model, bitfield_slice, time, seed=0, max_steps=1024):
     return med
 
 
-def build_scene(H=800, W=800, device="cuda", seed=0, kind="jumpingjacks", time=0.5, azimuth=30.0, elevation=30.0):
-    model = build_model(seed, device)
+def build_scene(H=800, W=800, device="cuda", seed=0, kind="jumpingjacks", time=0.5, azimuth=30.0, elevation=30.0, bound=1):
+    """bound > 1 (main_dnerf.py --bound 2): cascade = 1 + ceil(log2(bound)) occupancy grids per time slice, the same figure."""
+    model = build_model(seed, device, bound)
     t_idx = int(min(max(math.floor(time * model.time_size), 0), model.time_size - 1))
-    bits = scene.density_bitfield_all_times(model.time_size, model.grid_size, kind)   # every time slice (a second for all 64)
+    bits = scene.density_bitfield_cascades(model.time_size, model.grid_size, model.cascade, float(bound), kind)   # every time slice
     model.density_bitfield.copy_(torch.from_numpy(bits))
     time_t = torch.tensor([[time]], dtype=torch.float32, device=device)
-    calibrate_density(model, bits[t_idx], time_t, seed)
+    calibrate_density(model, bits[t_idx][: model.grid_size ** 3 // 8], time_t, seed)
     pose = scene.look_at_pose(azimuth, elevation)
     ro, rd = scene.get_rays(pose, scene.intrinsics(H, W), H, W)
     return SimpleNamespace(model=model, rays_o=torch.from_numpy(ro).to(device), rays_d=torch.from_numpy(rd).to(device), time=time_t,

@@ -113,8 +113,15 @@ class FusedField:
         dev = enc.embeddings.device
         self.model = model
         self.weights = torch.from_numpy(pack_weights(model)).to(dev).contiguous()
-        self.table = enc.embeddings.detach().to(torch.float16).contiguous()   # grid.py:43-44 under autocast
-        self.offsets_host = np.ascontiguousarray(enc.offsets.cpu().numpy().astype(np.int32))
+        # fp16 copy of the table (grid.py:43-44 under autocast) in the PADDED layout: level l moves down by l rows and is followed by
+        # one extra row that repeats its row 0, so that the (x, x+1) row pair of every gather is two consecutive rows even when x is
+        # the level's last row (`(index + 1) % hashmap_size` == 0, gridencoder.cu:66-84) -- the kernel's gather path then needs no
+        # clamp / wrap bookkeeping (csrc/field.hip, PAD variants)
+        off = enc.offsets.cpu().numpy().astype(np.int64)
+        self._level_rows = [(int(off[l]), int(off[l + 1])) for l in range(16)]
+        self.offsets_host = np.ascontiguousarray((off + np.arange(17)).astype(np.int32))
+        self.table = torch.empty(int(self.offsets_host[-1]), 2, dtype=torch.float16, device=dev)
+        self.load_table(enc.embeddings)
         self.S = float(np.log2(enc.per_level_scale))
         self.H = int(enc.base_resolution)
         self.bound = float(model.bound)
@@ -124,6 +131,14 @@ class FusedField:
         self._buf = None
         if max_points:
             self._alloc(max_points)
+
+    @torch.no_grad()
+    def load_table(self, embeddings):
+        """(Re)fills the padded fp16 table from the network's embeddings [rows, 2] (any float dtype)."""
+        for l, (a, b) in enumerate(self._level_rows):
+            dst = int(self.offsets_host[l])
+            self.table[dst:dst + (b - a)].copy_(embeddings[a:b])
+            self.table[dst + (b - a)].copy_(embeddings[a])
 
     @staticmethod
     def time_value(time):
@@ -215,7 +230,7 @@ class DensityGridUpdater:
         """Re-pack the (trained) weights and the fp16 table; call after optimizer steps."""
         f, enc = self.field, self.model.encoder
         f.weights.copy_(torch.from_numpy(pack_weights(self.model)))
-        f.table.copy_(enc.embeddings.detach())
+        f.load_table(enc.embeddings.detach())
         f.invalidate_time_cache()
         f._group_cache.clear()
 

@@ -231,6 +231,49 @@ def gen_train(model, ro, rd, out):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+def gen_bound2(out):
+    """main_dnerf.py --bound 2: cascade 2 (dnerf/renderer.py:73), two occupancy grids per time slice, the marcher's mip-level
+    selection (raymarching.cu:42-54,371-379) and a 4096-wide finest grid level (desired_resolution = 2048 * bound); plus one render
+    with dt_gamma > 0 (step size growing with t, raymarching.cu:365)."""
+    import dnerf.network as ref_network
+    model, bits = build_reference_model(ref_network.NeRFNetwork, bound=2)
+    digests = state_digests(model)
+    b = dict(sigma_last_row0=model.sigma_net[-1].weight[0].numpy().copy(), digest_keys=np.array(sorted(digests)),
+             digest_vals=np.array([digests[k] for k in sorted(digests)]), bitfield_sha=np.array([sha(bits[32]), sha(bits[0])]))
+    ro, rd, _ = camera_rays(64, 64)
+    for name, t, kw in (("t0.5", 0.5, {}), ("t0.0", 0.0, {}), ("gamma", 0.5, dict(dt_gamma=1.0 / 256))):
+        r = run_infer(model, ro, rd, t, **kw)
+        for k, v in r.items():
+            b[f"{name}_{k}"] = v
+        print(f"[bound2 {name}] iterations {len(r['trace'])}, first rows {r['trace'][:3].tolist()}, image mean {r['image'].mean():.6f}")
+    # training march at bound 2 (counts + per-ray table + image)
+    model.train()
+    g = torch.Generator().manual_seed(6)
+    sel = torch.randint(0, ro.shape[1], (1024,), generator=g)
+    noises = torch.rand(1024, generator=g).numpy().astype(np.float32)
+    RM.NOISES["train"] = noises
+    captured = {}
+    orig = RM.march_rays_train
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        captured["rays"], captured["M"] = r[3].numpy().copy(), r[0].shape[0]
+        return r
+    RM.march_rays_train = spy
+    try:
+        res = model.render(ro[:, sel].contiguous(), rd[:, sel].contiguous(), torch.tensor([[0.5]]), staged=False, bg_color=1, perturb=True,
+                           force_all_rays=False, dt_gamma=1.0 / 256)
+    finally:
+        RM.march_rays_train = orig
+        RM.NOISES["train"] = None
+    model.eval()
+    b.update(train_sel=sel.numpy().astype(np.int32), train_noises=noises, train_rays=captured["rays"], train_M=np.int32(captured["M"]),
+             train_counter=model.step_counter[0].numpy().copy(), train_image=res["image"][0].numpy().copy())
+    print(f"[bound2 train] samples {int(b['train_counter'][0])}, M {captured['M']}")
+    out["bound2"] = b
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 SEAL_CONFIG = dict(type="bbox", boundType="to", scale=[1.0, 1.0, 1.0], hsv=[0.33, 0.0, 0.0],
                    raw=[[-0.13, 0.34, -0.13], [0.13, 0.34, -0.13], [-0.13, 0.62, -0.13], [0.13, 0.62, -0.13],
                         [-0.13, 0.34, 0.13], [0.13, 0.34, 0.13], [-0.13, 0.62, 0.13], [0.13, 0.62, 0.13]],
@@ -387,7 +430,7 @@ def gen_get_rays(out):
 
 # ----------------------------------------------------------------------------------------------------------------------
 def main():
-    which = set(sys.argv[1:]) or {"dnerf", "seald", "get_rays"}
+    which = set(sys.argv[1:]) or {"dnerf", "seald", "get_rays", "bound2"}
     out = {}
     if "dnerf" in which:
         gen_dnerf(out)
@@ -395,6 +438,8 @@ def main():
         gen_seald(out)
     if "get_rays" in which:
         gen_get_rays(out)
+    if "bound2" in which:
+        gen_bound2(out)
     for name, d in out.items():
         path = os.path.join(HERE, f"caller_{name}.npz")
         np.savez_compressed(path, **d)

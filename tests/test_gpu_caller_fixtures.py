@@ -191,3 +191,52 @@ def test_training_branch_reproduces_reference(model_bits, name, perturb, monkeyp
         model.zero_grad(set_to_none=True)
         model.eval()
         model.mean_count, model.local_step = 0, 0
+
+
+# ------------------------------------------------------------------------------------------------
+# --bound 2: the GENERIC marcher (MarcherT<false>: cascade 2, mip_from_pos / mip_from_dt, the double-typed index expression, no
+# cull grid / LDS caches) on the device, in every loop form; dt_gamma > 0 exercises the non-constant step
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def model_bits_b2():
+    return fixture_model("cuda", bound=2)
+
+
+@pytest.mark.parametrize("case,t,dt_gamma", [("t0.5", 0.5, 0.0), ("t0.0", 0.0, 0.0), ("gamma", 0.5, 1.0 / 256)])
+def test_bound2_loops_reproduce_reference(model_bits_b2, case, t, dt_gamma):
+    from dnerf_amd.fused import FusedField
+    from dnerf_amd.renderer import DeviceLoop, render_frame
+    fx = load("bound2")
+    sc = fixture_scene("cuda", model_bits=model_bits_b2, time=t)
+    assert sc.model.cascade == 2
+    out = render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=False, dt_gamma=dt_gamma)
+    _cmp_frame(out, fx, case, 1e-4)
+    with torch.no_grad():
+        a = sc.model.render(sc.rays_o[None], sc.rays_d[None], sc.time, staged=False, perturb=False, bg_color=None, dt_gamma=dt_gamma)
+    np.testing.assert_allclose(a["image"][0].cpu().numpy(), fx[f"{case}_image"], rtol=0, atol=1e-4)
+    field = FusedField(sc.model, sc.time)
+    fast = DeviceLoop(sc.model, field, sc.rays_o.shape[0], "cuda", dt_gamma=dt_gamma).render(sc.rays_o, sc.rays_d, sc.time)
+    torch.cuda.synchronize()
+    img = fast["image"].cpu().numpy()
+    assert np.abs(img - fx[f"{case}_image"]).max() < 2e-2 and np.abs(img - fx[f"{case}_image"]).mean() < 2e-4
+    assert tuple(fast["trace"][0]) == tuple(fx[f"{case}_trace"][0]) and abs(len(fast["trace"]) - len(fx[f"{case}_trace"])) <= 1
+
+
+def test_bound2_training_march_reproduces_reference(model_bits_b2, monkeypatch):
+    import raymarching
+    import raymarching.raymarching as rm_mod
+    fx = load("bound2")
+    model, bits = model_bits_b2
+    sc = fixture_scene("cuda", model_bits=model_bits_b2)
+    sel = torch.from_numpy(fx["train_sel"]).long().cuda()
+    ro, rd = sc.rays_o[sel].contiguous(), sc.rays_d[sel].contiguous()
+    noises = torch.from_numpy(fx["train_noises"]).cuda()
+    real_rand = torch.rand
+    monkeypatch.setattr(rm_mod.torch, "rand", lambda *a, **k: noises.clone() if a == (noises.shape[0],) else real_rand(*a, **k))
+    nears, fars = raymarching.near_far_from_aabb(ro, rd, model.aabb_train, model.min_near)
+    counter = torch.zeros(2, dtype=torch.int32, device="cuda")
+    xyzs, dirs, deltas, rays = raymarching.march_rays_train(ro, rd, model.bound, model.density_bitfield[32], model.cascade, model.grid_size, nears,
+                                                            fars, counter, 0, True, 128, False, 1.0 / 256, 1024)
+    monkeypatch.undo()
+    assert counter.cpu().numpy().tolist() == fx["train_counter"].tolist() and xyzs.shape[0] == int(fx["train_M"])
+    assert np.array_equal(rays.cpu().numpy(), fx["train_rays"])
