@@ -472,7 +472,7 @@ def main():
         # instrumented loops: the first (and in a long stream the last) is rendered with nothing else in flight -- the pipeline is
         # empty / draining there anyway -- and its launch durations are the kernel's own (the roofline figure); every `every`-th loop
         # in between is instrumented while it overlaps like all the others (a launch while it shares the device)
-        excl_set = exclusive_frames(k)
+        excl_set = exclusive_frames(k) if every else set()
         marked = sorted(set(range(0, k, every)) | excl_set) if every else []
         timing = make_timing(len(marked))
         per_frame, it = [None] * k, iter(timing)
@@ -537,7 +537,10 @@ def main():
         torch.cuda.synchronize()
 
     every = max(1, args.time_every)
-    n_instrumented = len(range(0, n_groups, every))
+    if world > 1 or (ploop is not None and n_groups < 8):
+        every = 0    # multi-GPU runs and very short streams are not instrumented: an exclusive (alone-on-the-device) loop would be a
+                     # large part of the stream, and the roofline figure is a one-GPU quantity
+    n_instrumented = len(range(0, n_groups, every)) if every else 0
     # A generation-2 pass of CPython's cyclic collector costs tens of milliseconds with torch + numpy loaded and fires on allocation
     # counts, i.e. inside the timed region for some argument combinations and not for others (seen: 20 frames in 14 ms of driver
     # time reported as 50-78 ms).  Collect now and keep the collector off while the clock runs, as `timeit` does.
@@ -553,7 +556,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for i in range(n_groups):
-            step(i, timed=(i % every == 0))
+            step(i, timed=bool(every) and (i % every == 0))
         barrier()
         elapsed = time.perf_counter() - t0
     # latency of ONE loop with nothing else in flight (what --pipeline 0 reports as ms_per_step), same sequence, after the timed region
@@ -603,7 +606,9 @@ def main():
                                   else ("single GPU" + (f" rendering rank 0's shard of a {args.emulate_rank_of}-way ray split (NOT a whole-frame figure)" if args.emulate_rank_of > 1 else ""))},
     }
     if rank == 0:
-        if ploop is not None:
+        if not every:
+            marked, n_excl, excl_samples, over_samples = [], 0, 0, 0
+        elif ploop is not None:
             marked = sorted(set(range(0, n_groups, every)) | exclusive_frames(n_groups))
             n_instrumented, n_excl = len(marked), len(exclusive_frames(n_groups))
             excl_samples = sum(distinct[tuple(frame_cam[g * F:(g + 1) * F])][0] for g in exclusive_frames(n_groups))
@@ -613,7 +618,7 @@ def main():
             n_excl = n_instrumented
             excl_samples = sum(distinct[tuple(frame_cam[g * F:(g + 1) * F])][0] for g in marked)
             over_samples = 0
-        result["roofline"], result["kernel_times"] = roofline(timers, fp16, excl_samples, over_samples)
+        result["roofline"], result["kernel_times"] = roofline(timers, fp16, excl_samples, over_samples) if every else (None, {})
         if result["roofline"]:
             result["roofline"]["instrumented_steps"] = (
                 f"{n_instrumented} of {n_groups} timed loops (every {every}th" + (", plus the last" if ploop is not None else "") + ")"

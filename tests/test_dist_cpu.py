@@ -67,6 +67,39 @@ def test_shards_partition_the_image_and_are_balanced():
     assert len(set(owners[centre])) == 8
 
 
+def _group_worker(rank, world, port, H, W, frames, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dnerf_amd.dist import shard_rays, FrameGather
+        n = H * W
+        idx, per = shard_rays(n, W, rank, world)
+        # what a rank's frame-group loop hands over: `frames` shard outputs back to back (frame-major); the stand-in renderer makes
+        # every value a function of (frame, ray) so that a mix-up of frames or of shards is visible
+        ridx = torch.from_numpy(idx).float()
+        image = torch.cat([torch.stack([ridx + 1000 * f, ridx * 2, ridx * 3 + f], 1) for f in range(frames)])
+        depth = torch.cat([ridx * 0.5 + f for f in range(frames)])
+        fg = FrameGather(n, W, world, "cpu")
+        full = fg.gather_group(image, depth, frames, keep=True)        # one all_gather_into_tensor per frame
+        ref = torch.arange(n).float()
+        ok = len(full) == frames
+        for f in range(frames):
+            ok = ok and torch.equal(full[f], torch.stack([ref + 1000 * f, ref * 2, ref * 3 + f, ref * 0.5 + f], 1))
+        last = fg.gather_group(image, depth, frames)                   # streaming form: the buffer holds the last frame
+        ok = ok and torch.equal(last, full[-1])
+        np.save(os.path.join(out_dir, f"grp_{rank}.npy"), np.array([ok]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H,W,frames", [(2, 64, 64, 4), (3, 40, 56, 3)])
+def test_frame_group_gather_gloo(tmp_path, world, H, W, frames):
+    """bench.py --gpus N renders N frames' shards per loop (frame group) and assembles each frame with its own all-gather."""
+    mp.spawn(_group_worker, args=(world, _free_port(), H, W, frames, str(tmp_path)), nprocs=world, join=True)
+    assert all(bool(np.load(tmp_path / f"grp_{r}.npy")[0]) for r in range(world))
+
+
 class _ToyField(torch.nn.Module):
     """Stand-in with the parameter layout GradSync distinguishes: a big table named `encoder.embeddings` + small MLP weights."""
 
