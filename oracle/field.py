@@ -50,6 +50,12 @@ class FieldOracle:
         L = self.offsets.shape[0] - 1
         self.pls = per_level_scale if per_level_scale is not None else np.exp2(np.log2(2048 * bound / base_resolution) / (L - 1))
         self._emb16 = self.emb.astype(np.float16) if mode == "fp16" else None
+        # optional background-sphere model (dnerf/network.py:99-121): 2-D hash grid (4 levels, 16 -> 2048) ++ SH(dir) -> bg_net
+        self.bg = _weights(state, "bg_net") if any(k.startswith("bg_net.") for k in state) else None
+        if self.bg is not None:
+            self.bg_emb = np.asarray(state["encoder_bg.embeddings"], np.float32)
+            self.bg_offsets = np.asarray(state["encoder_bg.offsets"], np.int32)
+            self.bg_pls = np.exp2(np.log2(2048 / 16) / (self.bg_offsets.shape[0] - 2))
 
     def deform_of(self, x, t):
         enc_x = O.freq_encode_forward(x, 10)
@@ -73,6 +79,15 @@ class FieldOracle:
         if self.mode == "fp16":
             rgb = rgb.astype(np.float16).astype(np.float32)
         return rgb
+
+    def background(self, sph, d):
+        """dnerf/network.py:208-223: sph [N,2] in [-1,1] (raymarching.sph_from_ray), d [N,3] -> rgb [N,3]."""
+        u = ((np.asarray(sph, np.float32) + np.float32(1)) / np.float32(2)).astype(np.float32)
+        table = self.bg_emb.astype(np.float16) if self.mode == "fp16" else self.bg_emb
+        enc, _ = O.grid_encode_forward(u, table, self.bg_offsets, self.bg_pls, 16, False, 0, False, 0)      # gridtype 0 = hash
+        sh, _ = O.sh_encode_forward(np.asarray(d, np.float32), 4)
+        h = _mlp(np.concatenate([sh, enc.astype(np.float32)], axis=1), self.bg, self.mode).astype(np.float32)
+        return (1.0 / (1.0 + np.exp(-h.astype(np.float64)))).astype(np.float32)
 
     def forward(self, x, d, t):
         """-> sigma [M] f32 (already times density_scale), rgb [M,3] f32, deform [M,3]."""

@@ -64,6 +64,8 @@ def render_frame_oracle(sc, mode="fp32", T_thresh=1e-2, max_steps=1024, dt_gamma
         trace.append((n_alive, n_step, xyzs.shape[0]))
         alive = alive[alive >= 0]
         step += n_step
+    if getattr(model, "bg_radius", -1) > 0:      # background-sphere model (dnerf/renderer.py:277-279)
+        bg_color = field.background(O.sph_from_ray(ro, rd, float(model.bg_radius)), rd)
     image = im + (1 - ws)[:, None] * np.float32(bg_color)
     depth = np.clip(dp - nears, 0, None) / (fars - nears) if normalize_depth else dp
     return {"image": image.astype(np.float32), "depth": depth.astype(np.float32), "weights_sum": ws, "trace": trace, "n_samples": n_samples}

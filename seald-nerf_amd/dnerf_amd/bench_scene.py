@@ -50,6 +50,8 @@ def build_model(seed=0, device="cuda", bound=1, bg_radius=-1):
         model.encoder.embeddings.mul_(1e3)
         model.deform_net[-1].weight.mul_(0.05)
         model.sigma_net[-1].weight[0].abs_()
+        if bg_radius > 0:
+            model.encoder_bg.embeddings.mul_(1e3)      # as for the density grid: U(-1e-4, 1e-4) features would give a constant grey
     return model.to(device).eval()
 
 

@@ -57,10 +57,8 @@ def _run_mlp(layers, h):
 
 class NeRFNetwork(NeRFRenderer):
     def __init__(self, num_layers=2, hidden_dim=64, geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64,
-                 num_layers_deform=8, hidden_dim_deform=128, bound=1, **kwargs):
+                 num_layers_bg=2, hidden_dim_bg=64, num_layers_deform=8, hidden_dim_deform=128, bound=1, **kwargs):
         super().__init__(bound, **kwargs)
-        if self.bg_radius > 0:
-            raise NotImplementedError("background sphere model (bg_radius > 0) is outside the dnerf jumpingjacks path")
         self.num_layers, self.hidden_dim, self.geo_feat_dim = num_layers, hidden_dim, geo_feat_dim
         self.num_layers_color, self.hidden_dim_color = num_layers_color, hidden_dim_color
         self.num_layers_deform, self.hidden_dim_deform = num_layers_deform, hidden_dim_deform
@@ -81,7 +79,16 @@ class NeRFNetwork(NeRFRenderer):
         self.encoder_dir = SHEncoder(input_dim=3, degree=4)
         self.in_dim_dir = self.encoder_dir.output_dim
         self.color_net = _mlp([self.in_dim_dir + geo_feat_dim] + [hidden_dim_color] * (num_layers_color - 1) + [3])
-        self.bg_net = None
+
+        # background sphere (bg_radius > 0): 2-D hash grid over (theta, phi) ++ SH(dir) -> 64 -> 3        (network.py:99-121)
+        if self.bg_radius > 0:
+            self.num_layers_bg, self.hidden_dim_bg = num_layers_bg, hidden_dim_bg
+            self.encoder_bg = GridEncoder(input_dim=2, num_levels=4, level_dim=2, base_resolution=16, log2_hashmap_size=19,
+                                          desired_resolution=2048, gridtype="hash", align_corners=False)
+            self.in_dim_bg = self.encoder_bg.output_dim
+            self.bg_net = _mlp([self.in_dim_bg + self.in_dim_dir] + [hidden_dim_bg] * (num_layers_bg - 1) + [3])
+        else:
+            self.bg_net = None
 
     # ------------------------------------------------------------------------------------------
     def _deform(self, x, t):
@@ -116,6 +123,11 @@ class NeRFNetwork(NeRFRenderer):
         sigma, geo_feat = self._sigma(x)
         return {"deform": deform, "sigma": sigma, "geo_feat": geo_feat}
 
+    def background(self, x, d):
+        """x [N,2] in [-1,1] (theta, phi on the background sphere: raymarching.sph_from_ray), d [N,3] -> rgb [N,3]   (network.py:208-223)."""
+        h = torch.cat([self.encoder_dir(d), self.encoder_bg(x)], dim=-1)
+        return torch.sigmoid(_run_mlp(self.bg_net, h))
+
     def color(self, x, d, mask=None, geo_feat=None, **kwargs):
         """network.py:225-257 (masked colour query used by the non-cuda-ray sampler)."""
         if mask is not None:
@@ -139,4 +151,4 @@ class NeRFNetwork(NeRFRenderer):
             {"params": self.encoder_deform.parameters(), "lr": lr},
             {"params": self.encoder_time.parameters(), "lr": lr},
             {"params": self.deform_net.parameters(), "lr": lr_net},
-        ]
+        ] + ([{"params": self.encoder_bg.parameters(), "lr": lr}, {"params": self.bg_net.parameters(), "lr": lr_net}] if self.bg_radius > 0 else [])

@@ -108,6 +108,14 @@ class NeRFRenderer(nn.Module):
         self.mean_count = 0
         self.local_step = 0
 
+    def _bg(self, rays_o, rays_d, bg_color):
+        """Background colour the rays end on: the background-sphere model when bg_radius > 0 (dnerf/renderer.py:237-239,277-279),
+        else the caller's colour, else white."""
+        if self.bg_radius > 0:
+            sph = raymarching.sph_from_ray(rays_o, rays_d, self.bg_radius)        # [N,2] in [-1,1]
+            return self.background(sph, rays_d)
+        return 1 if bg_color is None else bg_color
+
     def time_slice(self, time):
         """Index of the density-grid time slice for `time` [B,1] (dnerf/renderer.py:285)."""
         return torch.floor(time[0][0] * self.time_size).clamp(min=0, max=self.time_size - 1).long()
@@ -123,8 +131,7 @@ class NeRFRenderer(nn.Module):
         N = rays_o.shape[0]
         device = rays_o.device
         nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
-        if bg_color is None:
-            bg_color = 1
+        bg_color = self._bg(rays_o, rays_d, bg_color)
         t = self.time_slice(time)
         results = {}
         if self.training:
@@ -223,8 +230,7 @@ class NeRFRenderer(nn.Module):
         ori_z = ((z_vals - nears) / (fars - nears)).clamp(0, 1)
         depth = torch.sum(weights * ori_z, dim=-1)
         image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2)
-        if bg_color is None:
-            bg_color = 1
+        bg_color = self._bg(rays_o, rays_d, bg_color)
         image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
         return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "deform": dens["deform"]}
 
@@ -423,6 +429,8 @@ def render_frame(model, rays_o, rays_d, time, fp16=False, dt_gamma=0.0, max_step
         cur = 1 - cur
         step += n_step
         it += 1
+    if getattr(model, "bg_radius", -1) > 0:
+        bg_color = model._bg(rays_o, rays_d, None).float()
     image = ws.image + (1 - ws.weights_sum).unsqueeze(-1) * bg_color
     depth = torch.clamp(ws.depth - nears, min=0) / (fars - nears)
     if count_samples:
@@ -609,6 +617,9 @@ class DeviceLoop:
         from sdn_backend import lib, check, ptr, stream
         import sdn_backend
         nears, fars = self.bind(rays_o, rays_d, time)
+        bg_model = getattr(self.model, "bg_radius", -1) > 0
+        if bg_model:         # the background-sphere colours are mixed in after the loop (the native finish takes one scalar colour)
+            bg_color = 0.0
         cur = torch.cuda.current_stream()
         ev_field, n_ev, recs = None, 0, None
         if sdn_backend.timers is not None and self._timing_queue:  # bench: time the fused-field launches in place
@@ -620,6 +631,9 @@ class DeviceLoop:
                                        ctypes.byref(self._iters)), "render_frame_f16")
         if recs is not None:  # keep the pairs of the iterations that ran
             sdn_backend.timers.records.setdefault("field_forward_f16", []).extend(recs[: min(n_ev, int(self._iters.value))])
+        if bg_model:
+            ro, rd = self._frame_refs[0], self._frame_refs[1]
+            self.image_out += (1 - self.buf["weights_sum"]).unsqueeze(-1) * self.model._bg(ro, rd, None).float()
         return self.collect(nears, fars, want_stats)
 
 

@@ -19,15 +19,16 @@ def _sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def fixture_model(device="cpu", check=True, bound=1):
+def fixture_model(device="cpu", check=True, bound=1, bg_radius=-1):
     """The mirror network with the fixture's weights: bench_scene.build_model(seed 0) + the calibrated sigma row stored by the
     generator; occupancy slices of the three fixture times.  With `check`, every state-dict entry must hash to the digest the
     generator recorded from the REFERENCE's NeRFNetwork (same names, same shapes, same values)."""
     from dnerf_amd import scene
     from dnerf_amd.bench_scene import build_model
     fx0 = load("scene")
-    fx = fx0 if bound == 1 else load(f"bound{bound}")      # the bound-2 model (cascade 2) has its own digests / calibrated row
-    model = build_model(int(fx0["seed"]), "cpu", bound)
+    # the bound-2 model (cascade 2) and the model with a background sphere have their own digests / calibrated rows
+    fx = load("bg") if bg_radius > 0 else (fx0 if bound == 1 else load(f"bound{bound}"))
+    model = build_model(int(fx0["seed"]), "cpu", bound, bg_radius)
     slices = {int(min(max(math.floor(float(t) * model.time_size), 0), model.time_size - 1)) for t in fx0["times"]}
     bits = scene.density_bitfield_cascades(model.time_size, model.grid_size, model.cascade, float(bound), "jumpingjacks", times=slices)
     with torch.no_grad():

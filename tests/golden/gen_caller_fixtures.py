@@ -77,6 +77,8 @@ def build_reference_model(cls, bound=1, kind="jumpingjacks", bg_radius=-1, **kw)
     model.encoder.embeddings.mul_(1e3)
     model.deform_net[-1].weight.mul_(0.05)
     model.sigma_net[-1].weight[0].abs_()
+    if bg_radius > 0:
+        model.encoder_bg.embeddings.mul_(1e3)
     model.eval()
     slices = {int(min(max(math.floor(t * model.time_size), 0), model.time_size - 1)) for t in TIMES}
     if model.cascade == 1:
@@ -274,6 +276,31 @@ def gen_bound2(out):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+def gen_bg(out):
+    """bg_radius > 0: the background-sphere model (dnerf/network.py:99-121,208-223) and its mixing in run_cuda / run
+    (dnerf/renderer.py:237-239,277-279): 2-D hash grid over the sphere coordinates of sph_from_ray ++ SH(dir) -> bg_net."""
+    import dnerf.network as ref_network
+    model, bits = build_reference_model(ref_network.NeRFNetwork, bg_radius=4.0)
+    digests = state_digests(model)
+    b = dict(sigma_last_row0=model.sigma_net[-1].weight[0].numpy().copy(), digest_keys=np.array(sorted(digests)),
+             digest_vals=np.array([digests[k] for k in sorted(digests)]))
+    ro, rd, _ = camera_rays(64, 64)
+    r = run_infer(model, ro, rd, 0.5)
+    for k, v in r.items():
+        b[f"infer_{k}"] = v
+    g = torch.Generator().manual_seed(31)
+    sph = torch.rand(2048, 2, generator=g) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(2048, 3, generator=g), dim=-1)
+    b["sph"], b["d"], b["background"] = sph.numpy(), d.numpy(), model.background(sph, d).numpy().copy()
+    b["sph_from_ray"] = RM.sph_from_ray(ro[0], rd[0], 4.0).numpy().copy()
+    model.cuda_ray = False
+    u = model.render(ro, rd, torch.tensor([[0.5]]), staged=True, max_ray_batch=4096, bg_color=None, perturb=False, num_steps=64, upsample_steps=0)
+    b["uniform_image"] = u["image"][0].numpy().copy()
+    print(f"[bg] image mean {b['infer_image'].mean():.5f}, background colour spread {b['background'].std(0).tolist()}")
+    out["bg"] = b
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 SEAL_CONFIG = dict(type="bbox", boundType="to", scale=[1.0, 1.0, 1.0], hsv=[0.33, 0.0, 0.0],
                    raw=[[-0.13, 0.34, -0.13], [0.13, 0.34, -0.13], [-0.13, 0.62, -0.13], [0.13, 0.62, -0.13],
                         [-0.13, 0.34, 0.13], [0.13, 0.34, 0.13], [-0.13, 0.62, 0.13], [0.13, 0.62, 0.13]],
@@ -430,7 +457,7 @@ def gen_get_rays(out):
 
 # ----------------------------------------------------------------------------------------------------------------------
 def main():
-    which = set(sys.argv[1:]) or {"dnerf", "seald", "get_rays", "bound2"}
+    which = set(sys.argv[1:]) or {"dnerf", "seald", "get_rays", "bound2", "bg"}
     out = {}
     if "dnerf" in which:
         gen_dnerf(out)
@@ -440,6 +467,8 @@ def main():
         gen_get_rays(out)
     if "bound2" in which:
         gen_bound2(out)
+    if "bg" in which:
+        gen_bg(out)
     for name, d in out.items():
         path = os.path.join(HERE, f"caller_{name}.npz")
         np.savez_compressed(path, **d)

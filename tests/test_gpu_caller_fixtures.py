@@ -240,3 +240,32 @@ def test_bound2_training_march_reproduces_reference(model_bits_b2, monkeypatch):
     monkeypatch.undo()
     assert counter.cpu().numpy().tolist() == fx["train_counter"].tolist() and xyzs.shape[0] == int(fx["train_M"])
     assert np.array_equal(rays.cpu().numpy(), fx["train_rays"])
+
+
+def test_background_sphere_model_reproduces_reference():
+    """bg_radius > 0 (dnerf/network.py:99-121,208-223): sph_from_ray + 2-D hash grid + SH -> bg_net, mixed in by every loop form."""
+    from dnerf_amd.fused import FusedField
+    from dnerf_amd.renderer import DeviceLoop, render_frame
+    import raymarching
+    fx = load("bg")
+    mb = fixture_model("cuda", bg_radius=4.0)
+    model, _ = mb
+    sph, d = torch.from_numpy(fx["sph"]).cuda(), torch.from_numpy(fx["d"]).cuda()
+    with torch.no_grad():
+        np.testing.assert_allclose(model.background(sph, d).cpu().numpy(), fx["background"], rtol=1e-4, atol=1e-6)
+    sc = fixture_scene("cuda", model_bits=mb)
+    np.testing.assert_allclose(raymarching.sph_from_ray(sc.rays_o, sc.rays_d, 4.0).cpu().numpy(), fx["sph_from_ray"], rtol=0, atol=2e-6)
+    out = render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=False)
+    assert fx["infer_trace"].tolist() == [list(r) for r in out["trace"]]
+    np.testing.assert_allclose(out["image"].cpu().numpy(), fx["infer_image"], rtol=0, atol=1e-4)
+    with torch.no_grad():
+        a = sc.model.render(sc.rays_o[None], sc.rays_d[None], sc.time, staged=False, perturb=False, bg_color=None)
+        sc.model.cuda_ray = False
+        u = sc.model.render(sc.rays_o[None], sc.rays_d[None], sc.time, staged=True, max_ray_batch=4096, bg_color=None, perturb=False,
+                            num_steps=64, upsample_steps=0)
+        sc.model.cuda_ray = True
+    np.testing.assert_allclose(a["image"][0].cpu().numpy(), fx["infer_image"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(u["image"][0].cpu().numpy(), fx["uniform_image"], rtol=0, atol=1e-4)
+    fast = DeviceLoop(sc.model, FusedField(sc.model, sc.time), sc.rays_o.shape[0], "cuda").render(sc.rays_o, sc.rays_d, sc.time)
+    torch.cuda.synchronize()
+    assert np.abs(fast["image"].cpu().numpy() - fx["infer_image"]).max() < 2e-2
