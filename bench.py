@@ -486,12 +486,12 @@ def main():
                        for _ in range(k)]
         barrier()
         t0 = time.perf_counter()
+        # multi-GPU: a helper thread issues the per-frame all-gathers of a loop the moment that loop's last kernel is enqueued, on its
+        # own stream, while the later loops still render (the driver call itself only returns when every loop has finished)
         outs, iters = ploop.render_frames(grp_o[:k], grp_d[:k], grp_t[:k], outputs=outputs,
                                           timing=[p[0] if p else None for p in per_frame] if every else None,
-                                          exclusive=exclusive if every else None)
-        if world > 1:
-            for img, dep in outs:
-                gather_outputs(img, dep)  # issued behind the renders
+                                          exclusive=exclusive if every else None,
+                                          on_done=(lambda f, img, dep: gather_outputs(img, dep)) if world > 1 else None)
         t1 = time.perf_counter()
         barrier()
         elapsed = time.perf_counter() - t0

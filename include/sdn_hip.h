@@ -364,13 +364,17 @@ int sdn_render_frame_f16(const SdnRenderCtx *ctx, float bg_color, float *image_o
  * [n_frames] flags; a flagged frame runs with nothing else in flight (to time its kernels undisturbed).  frame_times: NULL (every
  * frame uses its context's time constants) or [n_frames] records: frame i (a frame group when the contexts are group contexts)
  * is rendered at ITS time -- a D-NeRF test set carries one time per frame (dnerf/utils.py:151-161).  Every frame is
- * bit-identical to sdn_render_frame_f16's; iterations_out [n_frames] or NULL.  Returns SDN_E_TIMEOUT when no iteration of any
+ * bit-identical to sdn_render_frame_f16's; iterations_out [n_frames] or NULL.  done_events: NULL or [n_frames] hipEvent_t: event i is
+ * recorded on frame i's stream behind its last kernel, and only THEN iterations_out[i] becomes non-zero (release store) -- a second
+ * host thread can poll iterations_out and hand finished frames on (e.g. to the per-frame all-gather) while later frames still
+ * render.  Returns SDN_E_TIMEOUT when no iteration of any
  * frame in flight completes within 20 s (all streams are synchronised before any error return). */
 int sdn_render_frames_pipelined_f16(const SdnRenderCtx *const *ctxs, uint32_t n_ctx, uint32_t n_frames, const float *const *rays_o,
                                     const float *const *rays_d, float *const *image_outs, float *const *depth_outs, float bg_color,
                                     uint32_t overlap_div, void *const *streams, void *const *side_streams, void **ev_main,
                                     void **ev_copy, int32_t *host_snap, void *const *ev_field_frames, uint32_t max_field_events,
-                                    const uint8_t *exclusive_frames, const SdnFrameTime *frame_times, uint32_t *iterations_out);
+                                    const uint8_t *exclusive_frames, const SdnFrameTime *frame_times, void *const *done_events,
+                                    uint32_t *iterations_out);
 /* ---------------------------------------------------------------------------
  * SealD-NeRF bounding-box seal mapper on the sample stream  (reference: SealNeRF/seal_utils.py:132-153 map_mask, :245-286
  * SealBBoxMapper.map_to_origin, :638-693 moller_trumbore / points_in_mesh, :747-758 modify_hsv; torch boolean-mask code there)

@@ -274,7 +274,7 @@ int sdn_render_frames_pipelined_f16(const SdnRenderCtx *const *ctxs, uint32_t n_
                                     const float *const *rays_d, float *const *image_outs, float *const *depth_outs, float bg_color,
                                     uint32_t overlap_div, void *const *streams, void *const *side_streams, void **ev_main, void **ev_copy,
                                     int32_t *host_snap, void *const *ev_field_frames, uint32_t max_field_events, const uint8_t *exclusive_frames,
-                                    const SdnFrameTime *frame_times, uint32_t *iterations_out) {
+                                    const SdnFrameTime *frame_times, void *const *done_events, uint32_t *iterations_out) {
     constexpr uint32_t kMaxCtx = 8;
     if (!ctxs || n_ctx == 0 || n_ctx > kMaxCtx || !rays_o || !rays_d || !image_outs || !depth_outs || !streams || !side_streams ||
         !ev_main || !ev_copy || !host_snap)
@@ -364,7 +364,11 @@ int sdn_render_frames_pipelined_f16(const SdnRenderCtx *const *ctxs, uint32_t n_
                 const int f = frame_of[s2];
                 rc = sdn_render_finish(&local[s2], bg_color, image_outs[f], depth_outs[f], streams[s2]);
                 if (rc) return fail(rc);
-                if (iterations_out) iterations_out[f] = runs[s2].it + 1;
+                if (done_events && done_events[f]) {
+                    hipError_t e = hipEventRecord((hipEvent_t)done_events[f], (hipStream_t)streams[s2]);
+                    if (e != hipSuccess) return fail((int)e);
+                }
+                if (iterations_out) __atomic_store_n(&iterations_out[f], runs[s2].it + 1, __ATOMIC_RELEASE);
                 frame_of[s2] = -1;
                 finished++;
             } else {

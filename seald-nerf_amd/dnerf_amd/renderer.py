@@ -655,8 +655,17 @@ class PipelinedDeviceLoop:
         self._ctxs = (ctypes.POINTER(SdnRenderCtx) * self.K)(*[ctypes.pointer(lp.ctx) for lp in self.loops])
         self._fixed = None
 
+    def _drive(self, lib, n, a_ro, a_rd, a_img, a_dep, bg_color, fx, a_ev, n_ev, exclusive, a_ft, a_done, iters):
+        import ctypes
+        from sdn_backend import check
+        check(lib.sdn_render_frames_pipelined_f16(self._ctxs, self.K, n, a_ro, a_rd, a_img, a_dep, float(bg_color), self.overlap_div, fx["streams"],
+                                                  fx["sides"], fx["ev_main"], fx["ev_copy"], self.host_state.data_ptr(), a_ev, n_ev,
+                                                  (ctypes.c_uint8 * n)(*[1 if e else 0 for e in exclusive]) if exclusive is not None else None,
+                                                  a_ft, a_done, iters),
+              "render_frames_pipelined_f16")
+
     @torch.no_grad()
-    def render_frames(self, rays_o, rays_d, time, bg_color=1.0, outputs=None, timing=None, exclusive=None):
+    def render_frames(self, rays_o, rays_d, time, bg_color=1.0, outputs=None, timing=None, exclusive=None, on_done=None):
         """rays_o / rays_d: lists of [N,3] tensors, one per frame (entries may repeat).  time: ONE time stamp for the whole stream
         (number or the reference's [1,1] tensor), or a list with one entry per frame -- a D-NeRF test set carries its own time for
         every frame (dnerf/utils.py:151-161); with frame-group contexts (`frames=F`) an entry is itself a list of F times.
@@ -664,6 +673,9 @@ class PipelinedDeviceLoop:
         depth [N]) tensors per frame; by default frame f lands in the output buffers of context f % contexts.  timing: optional list
         (per frame, None allowed) of ctypes arrays of 2 * DeviceLoop.MAX_TIMED hipEvent_t for that frame's field launches.
         exclusive: optional list of bools per frame; a flagged frame is rendered with nothing else in flight.
+        on_done: optional callable (frame index, image, depth) run on a helper thread, in frame order, as soon as a frame's last
+        kernel has been enqueued -- with torch's current stream (of that thread) already ordered behind the frame -- while later
+        frames still render: the hook for the per-frame all-gather of a ray-sharded job.
         Returns the list of (image, depth) per frame and the per-frame iteration counts."""
         import ctypes
         import time as _t
@@ -710,12 +722,45 @@ class PipelinedDeviceLoop:
             n_ev = DeviceLoop.MAX_TIMED
         import os, time as _t
         _dbg = os.environ.get("SDN_DRIVER_STATS")
+        a_done, worker = None, None
+        if on_done is not None:
+            import threading
+            done = [torch.cuda.Event() for _ in range(n)]
+            for e in done:
+                e.record(cur)                    # materialises the hipEvent_t handles; the driver re-records them
+            a_done = (vp * n)(*[e.cuda_event for e in done])
+            failed = []
+            dev_index = self.streams[0].device_index
+
+            def hand_on():                       # frame f is finished once the driver has published its iteration count
+                torch.cuda.set_device(dev_index)
+                side = self._done_stream = getattr(self, "_done_stream", None) or torch.cuda.Stream()
+                try:
+                    with torch.cuda.stream(side):
+                        for f in range(n):
+                            while iters[f] == 0 and not failed:
+                                _t.sleep(2e-5)
+                            if failed:
+                                return
+                            side.wait_event(done[f])
+                            on_done(f, outputs[f][0], outputs[f][1])
+                except BaseException as exc:     # surfaced by the caller below
+                    failed.append(exc)
+            worker = threading.Thread(target=hand_on, daemon=True)
+            worker.start()
         _t0 = _t.perf_counter()
-        check(lib.sdn_render_frames_pipelined_f16(self._ctxs, self.K, n, a_ro, a_rd, a_img, a_dep, float(bg_color), self.overlap_div, fx["streams"],
-                                                  fx["sides"], fx["ev_main"], fx["ev_copy"], self.host_state.data_ptr(), a_ev, n_ev,
-                                                  (ctypes.c_uint8 * n)(*[1 if e else 0 for e in exclusive]) if exclusive is not None else None,
-                                                  a_ft, iters),
-              "render_frames_pipelined_f16")
+        try:
+            self._drive(lib, n, a_ro, a_rd, a_img, a_dep, bg_color, fx, a_ev, n_ev, exclusive, a_ft, a_done, iters)
+        except BaseException:
+            if worker is not None:
+                failed.append(True)
+                worker.join()
+            raise
+        if worker is not None:
+            worker.join()
+            if failed:
+                raise failed[0]
+            cur.wait_stream(self._done_stream)
         self._ft_refs = ft_refs    # the per-frame constants stay alive until the next stream of frames
         _t1 = _t.perf_counter()
         for s in self.streams:

@@ -45,7 +45,7 @@ PROTOTYPES = {
     "sdn_render_step_f16_ev": [_vp, _u32, _vp, _vp, _vp],
     "sdn_render_finish": [_vp, _f32, _vp, _vp, _vp],
     "sdn_render_frame_f16": [_vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
-    "sdn_render_frames_pipelined_f16": [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp],
+    "sdn_render_frames_pipelined_f16": [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp],
     "sdn_host_mailbox_free": [_vp],
     "sdn_seal_bbox_map": [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sdn_seal_modify_hsv": [_vp, _vp, _u32, _f32, _f32, _f32, _vp],

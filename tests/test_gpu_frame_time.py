@@ -121,3 +121,28 @@ def test_frame_group_equals_frames_rendered_alone(model_bits, H, W, frames):
     assert torch.equal(outs[0][0], out["image"])
     b = grp.render(ro, rd, rev)
     assert torch.equal(outs[1][0], b["image"])
+
+
+def test_on_done_hands_finished_frames_on_in_order(model_bits):
+    """The hook bench.py --gpus N uses to start a frame's all-gather while later frames still render: called once per frame, in
+    frame order, on a helper thread whose current stream is ordered behind that frame's last kernel."""
+    from dnerf_amd.fused import FusedField
+    from dnerf_amd.renderer import PipelinedDeviceLoop
+    model, _ = model_bits
+    H = W = 64
+    cams = [_rays(H, W, 30.0 + 50.0 * f) for f in range(6)]
+    times = [0.0, 0.26, 0.5, 0.26, 0.5, 0.0]
+    pl = PipelinedDeviceLoop(model, FusedField(model, 0.5), H * W, "cuda", contexts=3)
+    outs = [(torch.empty(H * W, 3, device="cuda"), torch.empty(H * W, device="cuda")) for _ in cams]
+    seen, copies = [], []
+
+    def hook(f, img, dep):
+        seen.append(f)
+        copies.append(img.clone())          # on the helper thread's stream, behind frame f
+
+    pl.render_frames([c[0] for c in cams], [c[1] for c in cams], times, outputs=outs, on_done=hook)
+    torch.cuda.synchronize()
+    assert seen == list(range(6))
+    for f in range(6):
+        assert torch.equal(copies[f], outs[f][0])
+    assert not torch.equal(copies[0], copies[2])
