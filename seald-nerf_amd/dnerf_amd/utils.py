@@ -67,17 +67,42 @@ def get_rays(poses, intrinsics, H, W, N=-1, error_map=None, patch_size=1):
     return results
 
 
-def load_reference_checkpoint(model, path, map_location="cpu"):
-    """Loads a checkpoint written by the reference's trainer (nerf/utils.py:1095-1154: a dict whose 'model' entry is the state
-    dict; bare state dicts are accepted too) into a `dnerf_amd.network.NeRFNetwork`.  Parameter and buffer names are the
-    reference's (`encoder.embeddings`, `deform_net.N.weight`, `density_bitfield`, ...), so this is a plain name match; the file is
-    read with `weights_only=True` (nothing in it is executed).  Returns (missing_keys, unexpected_keys) like load_state_dict."""
+def load_reference_checkpoint(model, path, map_location="cpu", optimizer=None, lr_scheduler=None, scaler=None, ema=None, model_only=True):
+    """Loads a checkpoint written by the reference's trainer (`Trainer.save_checkpoint`, nerf/utils.py:1033-1093) into a
+    `dnerf_amd.network.NeRFNetwork`, the way `Trainer.load_checkpoint` (:1095-1154) does:
+
+      {'epoch', 'global_step', 'stats', 'mean_count', 'mean_density', 'model': state_dict,            -- always
+       'optimizer', 'lr_scheduler', 'scaler', 'ema'}                                                    -- `full=True` checkpoints
+      ("best" checkpoints drop `density_grid` from the model entry, :1085-1086); a bare state dict is accepted too (:1107-1110).
+
+    Parameter and buffer names are the reference's (`encoder.embeddings`, `deform_net.N.weight`, `density_bitfield`, ...), so the
+    model entry is a plain name match with strict=False.  With model_only=False the optimizer / lr_scheduler / scaler / ema given
+    are restored from their entries when present (a failure to restore one of them is reported, not raised, as in the reference).
+    The file is read with `weights_only=True` (nothing in it is executed).
+    Returns (missing_keys, unexpected_keys); the trainer bookkeeping is left in `load_reference_checkpoint.last`
+    ({'epoch', 'global_step', 'stats', 'restored': [...], 'failed': [...]})."""
     blob = torch.load(path, map_location=map_location, weights_only=True)
-    state = blob["model"] if isinstance(blob, dict) and "model" in blob else blob
-    result = model.load_state_dict(state, strict=False)
-    if isinstance(blob, dict):
-        if "mean_count" in blob and hasattr(model, "mean_count"):
+    info = {"epoch": None, "global_step": None, "stats": None, "restored": [], "failed": []}
+    load_reference_checkpoint.last = info
+    if not (isinstance(blob, dict) and "model" in blob):
+        result = model.load_state_dict(blob)
+        return result.missing_keys, result.unexpected_keys
+    result = model.load_state_dict(blob["model"], strict=False)
+    if ema is not None and "ema" in blob:
+        ema.load_state_dict(blob["ema"])
+        info["restored"].append("ema")
+    if getattr(model, "cuda_ray", False):
+        if "mean_count" in blob:
             model.mean_count = blob["mean_count"]
-        if "mean_density" in blob and hasattr(model, "mean_density"):
+        if "mean_density" in blob:
             model.mean_density = blob["mean_density"]
+    if not model_only:
+        info.update(epoch=blob.get("epoch"), global_step=blob.get("global_step"), stats=blob.get("stats"))
+        for name, obj in (("optimizer", optimizer), ("lr_scheduler", lr_scheduler), ("scaler", scaler)):
+            if obj is not None and name in blob:
+                try:
+                    obj.load_state_dict(blob[name])
+                    info["restored"].append(name)
+                except Exception as exc:       # the reference logs "[WARN] Failed to load ..." and goes on
+                    info["failed"].append((name, repr(exc)))
     return result.missing_keys, result.unexpected_keys

@@ -499,6 +499,61 @@ def test_load_reference_checkpoint_roundtrip(tmp_path):
         assert ka == kb and torch.equal(va, vb)
 
 
+def test_load_full_reference_layout_checkpoint(tmp_path):
+    """The reference trainer's FULL checkpoint layout (save_checkpoint(full=True), nerf/utils.py:1033-1069): epoch / global_step /
+    stats / mean_count / mean_density / optimizer / lr_scheduler / scaler / ema / model; and the "best" layout, whose model entry has
+    no density_grid (:1085-1086).  Everything is restored by name; the file is read with weights_only=True."""
+    from dnerf_amd import utils
+    from dnerf_amd.bench_scene import build_model
+    a, b = build_model(seed=3).train(), build_model(seed=4).train()
+    a.density_grid.uniform_(0, 1)
+
+    def make(m):
+        opt = torch.optim.Adam(m.get_params(1e-2, 1e-3), betas=(0.9, 0.99), eps=1e-15)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda it: 0.1 ** min(it / 30000, 1))      # main_dnerf.py:134
+        return opt, sched, torch.amp.GradScaler("cuda")
+    opt_a, sched_a, scaler_a = make(a)
+    for _ in range(2):                                   # give the optimizer / scheduler / scaler non-trivial state
+        opt_a.zero_grad(set_to_none=True)
+        loss = sum((p.float() ** 2).mean() for p in a.parameters())
+        scaler_a.scale(loss).backward()
+        scaler_a.step(opt_a); scaler_a.update(); sched_a.step()
+    ema_state = {"decay": 0.95, "num_updates": 2, "shadow_params": [p.detach().clone() for p in a.parameters()], "collected_params": None}
+    state = {"epoch": 5, "global_step": 1234, "stats": {"loss": [0.5, 0.25], "valid_loss": [], "results": [0.1], "checkpoints": [], "best_result": 0.1},
+             "mean_count": 4321, "mean_density": 0.125, "optimizer": opt_a.state_dict(), "lr_scheduler": sched_a.state_dict(),
+             "scaler": scaler_a.state_dict(), "ema": ema_state, "model": a.state_dict()}
+    full = str(tmp_path / "ngp_ep0005.pth")
+    torch.save(state, full)
+    opt_b, sched_b, scaler_b = make(b)
+
+    class Ema:                                           # torch_ema is absent here: the loader only calls load_state_dict on it
+        def load_state_dict(self, sd):
+            self.sd = sd
+    ema_b = Ema()
+    missing, unexpected = utils.load_reference_checkpoint(b, full, map_location="cuda", optimizer=opt_b, lr_scheduler=sched_b, scaler=scaler_b,
+                                                          ema=ema_b, model_only=False)
+    info = utils.load_reference_checkpoint.last
+    assert not missing and not unexpected and b.mean_count == 4321 and b.mean_density == 0.125
+    assert info["epoch"] == 5 and info["global_step"] == 1234 and info["stats"]["best_result"] == 0.1
+    assert sorted(info["restored"]) == ["ema", "lr_scheduler", "optimizer", "scaler"] and not info["failed"]
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    sa, sb = opt_a.state_dict()["state"], opt_b.state_dict()["state"]
+    assert sa.keys() == sb.keys() and all(torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]) for k in sa)
+    assert scaler_b.get_scale() == scaler_a.get_scale() and sched_b.last_epoch == sched_a.last_epoch == 2
+    assert ema_b.sd["num_updates"] == 2
+    # "best" checkpoint: no density_grid in the model entry -> reported missing, everything else loaded
+    best = dict(state, model={k: v for k, v in a.state_dict().items() if k != "density_grid"})
+    for k in ("optimizer", "lr_scheduler", "scaler", "ema"):
+        best.pop(k)
+    path = str(tmp_path / "ngp.pth")
+    torch.save(best, path)
+    c = build_model(seed=5)
+    missing, unexpected = utils.load_reference_checkpoint(c, path, map_location="cuda")
+    assert missing == ["density_grid"] and not unexpected
+    assert torch.equal(c.encoder.embeddings, a.encoder.embeddings) and torch.equal(c.density_bitfield, a.density_bitfield)
+
+
 def test_seal_bbox_kernels_match_the_torch_restatement():
     """csrc/seal.hip against dnerf_amd/seal_mapper's torch restatement of SealNeRF/seal_utils.py (run on the CPU): identical
     masks except within rounding of a face (excluded by an analytic margin), mapped coordinates / directions to 2e-6, colours
