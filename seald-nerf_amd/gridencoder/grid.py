@@ -29,6 +29,9 @@ def _host_offsets(offsets):
     return hit[0], hit[1]
 
 
+_SORT_MIN_BATCH = 65536   # backward: batches at least this large are scattered in cell order (see _grid_encode.backward)
+
+
 class _grid_encode(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
@@ -68,9 +71,26 @@ class _grid_encode(Function):
         """grid.py:68-89: scatter-add into a zeroed table gradient (+ input gradient through dy_dx)."""
         inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
         B, D, C, L, S, H, gridtype, interpolation = ctx.dims
-        grad = grad.view(B, L, C).permute(1, 0, 2).contiguous()
         if grad.dtype != embeddings.dtype:
             grad = grad.to(embeddings.dtype)
+        # Large batches are scattered in CELL ORDER.  The table gradient is an order-free sum (gridencoder.cu:248-340: plain atomic
+        # adds), but the rate of the memory-side atomic units is set by the number of 64-byte segments a wave-instruction touches
+        # (MI355X: 64 lanes in 64 rows ~17x slower than 64 lanes in one 256-B run): with the points sorted by their cell (x fastest, as
+        # the tiled levels linearise rows) neighbouring lanes update the same or neighbouring rows, the kernel's run aggregation merges
+        # the duplicates and what is left coalesces.  One radix sort of B keys + one permuted copy of the operands; ray-ordered
+        # training batches of a few thousand samples are left as they are.
+        perm = None
+        if B >= _SORT_MIN_BATCH and D <= 3:
+            q = (inputs.clamp(0, 1) * 1023.0).to(torch.int32)
+            key = q[:, 0]
+            for d in range(1, D):
+                key = key + (q[:, d] << (10 * d))
+            perm = torch.sort(key).indices
+            inputs = inputs[perm].contiguous()
+            grad = grad.view(B, L * C)[perm]
+            if dy_dx is not None:
+                dy_dx = dy_dx[perm].contiguous()
+        grad = grad.view(B, L, C).permute(1, 0, 2).contiguous()
         grad_embeddings = torch.zeros_like(embeddings)
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
         _, off_ptr = _host_offsets(offsets)
@@ -80,6 +100,8 @@ class _grid_encode(Function):
                                                  _dtype_id(embeddings.dtype), _stream()), "grid_encode_backward")
         if dy_dx is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
+            if perm is not None:
+                grad_inputs = torch.empty_like(grad_inputs).index_copy_(0, perm, grad_inputs)
         return grad_inputs, grad_embeddings, None, None, None, None, None, None, None
 
 
