@@ -401,3 +401,83 @@ def test_device_loop_with_mapper_equals_host_loop_with_mapper(small_scene):
     torch.cuda.synchronize()
     for img, _ in outs:
         assert torch.equal(img, host["image"])
+
+
+def test_pipelined_default_configuration_800x800_equals_device_loop():
+    """The bench default -- PipelinedDeviceLoop, 4 contexts, 800x800, a time per frame -- frame for frame against DeviceLoop.render
+    one at a time: bit-identical images / depths (6 frames: more frames than contexts, so contexts are reused)."""
+    from dnerf_amd.bench_scene import build_scene, camera_path
+    from dnerf_amd import fused
+    from dnerf_amd.renderer import DeviceLoop, PipelinedDeviceLoop
+    sc = build_scene(H=800, W=800, device="cuda", seed=0)
+    ros, rds, times = camera_path(sc, 6)
+    f = fused.FusedField(sc.model, sc.time, fp16=True)
+    N = 800 * 800
+    one = DeviceLoop(sc.model, f, N, "cuda")
+    pl = PipelinedDeviceLoop(sc.model, f, N, "cuda", contexts=4)
+    outs = [(torch.empty(N, 3, device="cuda"), torch.empty(N, device="cuda")) for _ in range(6)]
+    pl.render_frames(ros, rds, times, outputs=outs)
+    torch.cuda.synchronize()
+    total = 0
+    for k in range(6):
+        a = one.render(ros[k], rds[k], times[k])
+        torch.cuda.synchronize()
+        assert torch.equal(a["image"], outs[k][0]), k
+        assert torch.equal(torch.nan_to_num(a["depth"]), torch.nan_to_num(outs[k][1])), k
+        assert a["trace"][0] == (640000, 1, 640128)
+        total += a["n_samples"]
+    assert total > 6 * 500000
+    assert not torch.equal(outs[0][0], outs[3][0])
+
+
+@pytest.fixture(scope="module")
+def lego_scene():
+    from dnerf_amd.bench_scene import build_scene
+    return build_scene(H=64, W=64, device="cuda", seed=0, kind="lego")
+
+
+def test_lego_scene_render_vs_oracle(lego_scene):
+    """BASELINE config 5's geometry (the studded box) at 64x64: the HIP operator loop (fp32) against the CPU oracle's render --
+    indices / counts exact, image 1e-4 -- and the native -O loop within fp16 distance of it."""
+    from dnerf_amd import fused
+    from dnerf_amd.renderer import DeviceLoop, render_frame
+    sc = lego_scene
+    out = render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=False)
+    ref = orender.render_frame_oracle(sc, mode="fp32")
+    assert out["n_samples"] == ref["n_samples"] > 2000
+    assert [tuple(t) for t in out["trace"]] == [tuple(t) for t in ref["trace"]]
+    np.testing.assert_allclose(out["image"].cpu().numpy(), ref["image"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(out["weights_sum"].cpu().numpy(), ref["weights_sum"], rtol=1e-4, atol=1e-4)
+    fast = DeviceLoop(sc.model, fused.FusedField(sc.model, sc.time), sc.rays_o.shape[0], "cuda").render(sc.rays_o, sc.rays_d, sc.time)
+    torch.cuda.synchronize()
+    assert np.abs(fast["image"].cpu().numpy() - ref["image"]).max() < 3e-2
+    assert abs(fast["n_samples"] - ref["n_samples"]) <= 0.01 * ref["n_samples"]
+
+
+def test_lego_scene_800x800_properties():
+    """config 5 at full size on one GPU: deterministic, background exactly the background colour, ray-order independent, and the
+    8-way tile sharding of the frame (what --gpus 8 renders per rank) reassembles to the unsharded frame bit for bit."""
+    from dnerf_amd.bench_scene import build_scene
+    from dnerf_amd import fused
+    from dnerf_amd.dist import shard_rays
+    from dnerf_amd.renderer import DeviceLoop
+    sc = build_scene(H=800, W=800, device="cuda", seed=0, kind="lego")
+    f = fused.FusedField(sc.model, sc.time, fp16=True)
+    N = 800 * 800
+    loop = DeviceLoop(sc.model, f, N, "cuda")
+    a = loop.render(sc.rays_o, sc.rays_d, sc.time)
+    img, ws = a["image"].clone(), a["weights_sum"].clone()
+    b = loop.render(sc.rays_o, sc.rays_d, sc.time)
+    assert torch.equal(img, b["image"]) and a["n_samples"] == b["n_samples"] > 1500000
+    miss = ws == 0
+    assert torch.equal(img[miss], torch.ones_like(img[miss])) and 0.02 < float((~miss).float().mean()) < 0.4
+    assembled = torch.zeros_like(img)
+    shard_loop = None
+    for r in range(8):
+        idx, per = shard_rays(N, 800, r, 8)
+        idx_t = torch.from_numpy(idx).cuda()
+        shard_loop = shard_loop or DeviceLoop(sc.model, f, per, "cuda")
+        o = shard_loop.render(sc.rays_o[idx_t].contiguous(), sc.rays_d[idx_t].contiguous(), sc.time)
+        assembled[idx_t] = o["image"]
+    torch.cuda.synchronize()
+    assert torch.equal(assembled, img)
