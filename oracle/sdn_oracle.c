@@ -522,8 +522,12 @@ void orc_grid_encode_forward(const float *inputs, const void *grid_all, const in
                 }
                 const uint32_t index = get_grid_index(D, C, gridtype, align_corners, 0, hashmap_size, resolution, pgl);
                 for (uint32_t ch = 0; ch < C; ch++) {
-                    /* scalar_t += float*scalar_t : float math, rounded back to scalar_t */
-                    const float v = results[ch] + w * ld(grid_all, goff + index + ch, is_half);
+                    /* results[ch] += w * grid[index + ch]  (gridencoder.cu:187-189) with scalar_t = c10::Half: float * Half is a float
+                     * (Half.h "Arithmetic with floats"), and the only `Half += x` is operator+=(Half&, const Half&) -- the float
+                     * product is converted to Half FIRST, then Half + Half = Half(float(a) + float(b)): two half roundings per corner */
+                    float t = w * ld(grid_all, goff + index + ch, is_half);
+                    if (is_half) t = rh(t);
+                    const float v = results[ch] + t;
                     results[ch] = is_half ? rh(v) : v;
                 }
             }
@@ -548,7 +552,9 @@ void orc_grid_encode_forward(const float *inputs, const void *grid_all, const in
                         for (uint32_t ch = 0; ch < C; ch++) {
                             float diff = ld(grid_all, goff + ir + ch, is_half) - ld(grid_all, goff + il + ch, is_half);
                             if (is_half) diff = rh(diff); /* Half - Half -> Half */
-                            const float v = rg[ch] + w * diff * pos_deriv[gd];
+                            float t = w * diff * pos_deriv[gd];   /* float * Half * float -> float; Half += float rounds it to Half first */
+                            if (is_half) t = rh(t);
+                            const float v = rg[ch] + t;
                             rg[ch] = is_half ? rh(v) : v;
                         }
                     }

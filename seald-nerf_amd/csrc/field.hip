@@ -367,8 +367,10 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     for (int l = 0; l < 6; l++) {
 #endif
         const unsigned char *cur = s_w[(l + 1) & 1];
+#if SDN_ABL != 6
         #pragma unroll
         for (int t = 0; t < 4; t++) acc_to_frags<true>(acc[t], bf[2 * t], bf[2 * t + 1]);
+#endif
         stage_wait_and_sync();  // stage l+1 landed for everyone; everyone is done reading the other buffer (layer l)
         // refill the other buffer with stage l+2 (D(l+2) for l < 5, the tail stage for l == 5); it lands under this layer's MFMAs
         stage_load(P.weights + (size_t)(l < 5 ? kBlkD1 + (l + 1) * 32 : kBlkD7) * 1024, s_w[l & 1], kStageBytes, wave, lane);
@@ -382,7 +384,9 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
         for (int i = 0; i < 32; i++) {
             const int ks = i >> 2, mt = i & 3;
             const half8 a = ring[i % LA];
+#if SDN_ABL != 5
             if (i + LA < 32) ring[i % LA] = lds_frag(cur, ((i + LA) & 3) * 8 + ((i + LA) >> 2), lane);
+#endif
             if (ks == 0) {
                 f32x16 z;
                 #pragma unroll
@@ -510,21 +514,25 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
 #endif
             #pragma unroll
             for (int lq = 0; lq < kGridBatch; lq++) {
-                // kernel_grid: half += float * half, rounded to half after every corner.  The running pair (r0, r1) stays packed in fp16;
-                // v_fma_mix_f32 reads fp16 halves as fp32 operands, so  t = w * val  is fma(w, val, -0)  and  r + t  is fma(1, r, t):
-                // the same two individually rounded fp32 operations as before without the three conversions around them
-                // (5 instead of 9 VALU instructions per corner; the whole phase is VALU-issue bound).
-                uint32_t acc2 = 0u;
+                // kernel_grid (gridencoder.cu:187-189), scalar_t = at::Half:  results[ch] += w * grid[index + ch]  is
+                //   t = Half(w * float(val));  results = Half(float(results) + float(t))
+                // -- the float product is converted to Half first (the only `Half += x` takes a Half).  The products come from
+                // v_fma_mix_f32 reading the fp16 halves of the gathered pair in place (w * val as fma(w, val, -0): the individually
+                // rounded fp32 product), one v_cvt_pk_f16_f32 rounds both channels, and the Half + Half sum is ONE v_pk_add_f16:
+                // for two fp16 operands the fp16-rounded exact sum equals Half(fp32 sum) (24 >= 2 * 11 + 2 bits: no double-rounding
+                // case exists).  4 VALU instructions per corner for both channels.
+                typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+                half2v accv = {(_Float16)0.0f, (_Float16)0.0f};
                 #pragma unroll
                 for (uint32_t idx = 0; idx < 8; idx++) {
                     float w = 1;
                     #pragma unroll
                     for (uint32_t d = 0; d < 3; d++) w *= (idx & (1u << d)) ? pos[lq][d] : 1 - pos[lq][d];
                     const uint32_t bits = (idx & 1u) ? pairs[lq][idx >> 1].y : pairs[lq][idx >> 1].x;
-                    const float s0 = mix_add_lo(mix_mul_lo(w, bits), acc2), s1 = mix_add_hi(mix_mul_hi(w, bits), acc2);
-                    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-                    acc2 = __builtin_bit_cast(uint32_t, (half2v){(_Float16)s0, (_Float16)s1});
+                    const half2v t = {(_Float16)mix_mul_lo(w, bits), (_Float16)mix_mul_hi(w, bits)};
+                    accv = accv + t;
                 }
+                uint32_t acc2 = __builtin_bit_cast(uint32_t, accv);
                 if (oob) acc2 = 0u;
                 const int li = lb * kGridBatch + lq;
                 gfw[li >> 2][li & 3] = acc2;

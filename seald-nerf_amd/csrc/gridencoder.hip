@@ -156,7 +156,9 @@ __global__ void __launch_bounds__(256) k_grid_fwd(const float *__restrict__ inpu
     #pragma unroll
     for (uint32_t idx = 0; idx < (1u << D); idx++) {
         #pragma unroll
-        for (uint32_t ch = 0; ch < C; ch++) results[ch] = Num<T>::rnd(results[ch] + ws[idx] * vals[idx][ch]);
+        // results[ch] += w * grid[...] with at::Half results: the float product is converted to Half first (the only `Half += x` takes a
+        // Half), then Half + Half rounds once more -- two half roundings per corner (gridencoder.cu:187-189, c10 Half.h)
+        for (uint32_t ch = 0; ch < C; ch++) results[ch] = Num<T>::rnd(results[ch] + Num<T>::rnd(ws[idx] * vals[idx][ch]));
     }
     #pragma unroll
     for (uint32_t ch = 0; ch < C; ch++) Num<T>::st(out + ch, results[ch]);
@@ -182,7 +184,7 @@ __global__ void __launch_bounds__(256) k_grid_fwd(const float *__restrict__ inpu
                 #pragma unroll
                 for (uint32_t ch = 0; ch < C; ch++) {
                     const float diff = Num<T>::rnd(vals[corner | (1u << gd)][ch] - vals[corner][ch]);
-                    rg[ch] = Num<T>::rnd(rg[ch] + w * diff * pos_deriv[gd]);
+                    rg[ch] = Num<T>::rnd(rg[ch] + Num<T>::rnd(w * diff * pos_deriv[gd]));
                 }
             }
             #pragma unroll

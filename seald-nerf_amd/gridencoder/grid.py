@@ -29,7 +29,7 @@ def _host_offsets(offsets):
     return hit[0], hit[1]
 
 
-_SORT_MIN_BATCH = 65536   # backward: batches at least this large are scattered in cell order (see _grid_encode.backward)
+_SORT_MIN_BATCH = 1 << 20   # backward: batches at least this large are scattered in Morton order (see _grid_encode.backward)
 
 
 class _grid_encode(Function):
@@ -73,18 +73,24 @@ class _grid_encode(Function):
         B, D, C, L, S, H, gridtype, interpolation = ctx.dims
         if grad.dtype != embeddings.dtype:
             grad = grad.to(embeddings.dtype)
-        # Large batches are scattered in CELL ORDER.  The table gradient is an order-free sum (gridencoder.cu:248-340: plain atomic
-        # adds), but the rate of the memory-side atomic units is set by the number of 64-byte segments a wave-instruction touches
-        # (MI355X: 64 lanes in 64 rows ~17x slower than 64 lanes in one 256-B run): with the points sorted by their cell (x fastest, as
-        # the tiled levels linearise rows) neighbouring lanes update the same or neighbouring rows, the kernel's run aggregation merges
-        # the duplicates and what is left coalesces.  One radix sort of B keys + one permuted copy of the operands; ray-ordered
-        # training batches of a few thousand samples are left as they are.
+        # Very large batches are scattered in MORTON ORDER of their cells.  The table gradient is an order-free sum (gridencoder.cu:
+        # 248-340: plain atomic adds), but the memory-side atomic units of the MI355X work at a rate set by the number of 64-byte
+        # segments a wave-instruction touches (64 lanes in 64 rows ~17x slower than 64 lanes in one 256-B run).  With the points in
+        # Z-order the 64 lanes of a wave sit in a small cube: on the levels whose cells are at least as large as that cube the kernel's
+        # run aggregation merges the lanes that share a row and the rest coalesces; on the finer levels every lane still owns its row
+        # (the nature of a hash grid: no ordering of the POINTS changes that).  One radix sort of B 30-bit keys + one permuted copy of
+        # the operands.  Ray-ordered training batches (neighbouring samples of a ray share their coarse cells already; measured 2x
+        # slower when re-sorted) and anything below _SORT_MIN_BATCH are left as they are.
         perm = None
-        if B >= _SORT_MIN_BATCH and D <= 3:
+        if B >= _SORT_MIN_BATCH and D == 3:
             q = (inputs.clamp(0, 1) * 1023.0).to(torch.int32)
-            key = q[:, 0]
-            for d in range(1, D):
-                key = key + (q[:, d] << (10 * d))
+
+            def spread(v):   # 10 bits -> every third bit
+                v = (v | (v << 16)) & 0x030000FF
+                v = (v | (v << 8)) & 0x0300F00F
+                v = (v | (v << 4)) & 0x030C30C3
+                return (v | (v << 2)) & 0x09249249
+            key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
             perm = torch.sort(key).indices
             inputs = inputs[perm].contiguous()
             grad = grad.view(B, L * C)[perm]
