@@ -37,7 +37,9 @@ template <> struct Num<float> {
 };
 template <> struct Num<__half> {
     static __device__ __forceinline__ float ld(const __half *p) { return __half2float(*p); }
-    static __device__ __forceinline__ float rnd(float v) { return __half2float(__float2half_rn(v)); }
+    // (the empty asm pins v as an fp32 VALUE: without it the compiler folds `half(a * b)` / `half(a + b)` into v_fma_mixlo_f16, which
+    // rounds the exact result ONCE to fp16 -- the reference rounds the float operation to fp32 first and converts that)
+    static __device__ __forceinline__ float rnd(float v) { asm volatile("" : "+v"(v)); return __half2float(__float2half_rn(v)); }
     static __device__ __forceinline__ void st(__half *p, float v) { *p = __float2half_rn(v); }
 };
 
