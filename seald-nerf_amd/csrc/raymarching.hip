@@ -454,6 +454,175 @@ __global__ void __launch_bounds__(256) k_march_train_count(const float *__restri
     num_steps_out[n] = num_steps;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Wave-per-ray form of the counting pass (FAST configuration with a constant step, i.e. dt_gamma == 0: what dnerf runs).
+//
+// With a constant step every parameter the marcher ever visits is a point of ONE lattice  L_0 = t_start, L_{k+1} = fl(L_k + dt):
+// a sample advances by dt, and an empty voxel is left by `do t += dt while (t < tt)` -- the same additions.  Which lattice points
+// are VISITED is a chain: next(k) = k + 1 if L_k lies in an occupied voxel, else the first m > k with L_m >= tt_k (tt_k: the voxel's
+// exit parameter, from L_k alone).  So 64 lanes take 64 consecutive lattice points, evaluate occupancy / exit parameter in
+// parallel with the sequential marcher's own expressions, and the wave walks the chain over ballots (scalar work, one readlane
+// per empty voxel).  Visited set, samples, counts and the recorded parameters are the sequential kernel's bit for bit: nothing
+// is approximated, the dependent chain of ~1000 cycles per voxel probe just becomes one probe round per 64 lattice points.
+// One ray per wave instead of one per lane: 4096 rays fill the chip (4 waves per SIMD) where the lane-per-ray kernel kept 64
+// waves busy for as long as its longest ray.  Occupancy bits and cull marks are read from global memory (L2-resident, 256 KiB +
+// 4 KiB): a probe round is one parallel load, an LDS image per 4-ray workgroup would cost more than it saves.
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lane_lattice(float base, float dt, uint32_t lane, float &next_base) {
+    // L_{lane} of the lattice starting at base, by `lane` successive additions (float addition is not associative: the values
+    // must come from the recurrence); also returns L_64
+    float v = base, mine = base;
+    #pragma unroll 8
+    for (uint32_t i = 0; i < 64; i++) {
+        if (i == lane) mine = v;
+        v += dt;
+    }
+    next_base = v;
+    return mine;
+}
+
+__global__ void __launch_bounds__(256) k_march_train_count_wave(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                                const uint8_t *__restrict__ grid, float bound, uint32_t max_steps, uint32_t N,
+                                                                uint32_t H, const float *__restrict__ nears, const float *__restrict__ fars,
+                                                                const float *__restrict__ noises, uint32_t *__restrict__ num_steps_out,
+                                                                const uint32_t *__restrict__ cull, float *__restrict__ sample_t) {
+    const uint32_t n = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (n >= N) return;   // wave-uniform
+    MarcherT<true> m;
+    m.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, 0.0f, max_steps, 1u, H, grid);
+    const float far = fars[n], dt = m.dt_const;
+    float t0 = nears[n];
+    t0 += m.step_size(t0) * noises[n];
+    bool go = t0 < far;
+    float t_end = far;
+    if (cull && go) {
+        // ray_may_hit with the scan positions spread over the lanes (same positions: s_i by i successive additions of ds)
+        const int *meta = reinterpret_cast<const int *>(cull + kCullWords);
+        const int bx0 = meta[0], by0 = meta[1], bz0 = meta[2];
+        const int bnx = meta[3] - bx0 + 1, bny = meta[4] - by0 + 1, bnz = meta[5] - bz0 + 1;
+        const float len = sqrtf(m.dx * m.dx + m.dy * m.dy + m.dz * m.dz);
+        const float ds = (2.0f / kCullRes) / fmaxf(len, 1e-12f);
+        const float cw = 2.0f / kCullRes;
+        float s0 = t0, s1 = far;
+        bool may = !(bnx <= 0 || bny <= 0 || bnz <= 0);
+        if (may) {
+            const float lo[3] = {(float)bx0 * cw - 1.0f, (float)by0 * cw - 1.0f, (float)bz0 * cw - 1.0f};
+            const float hi[3] = {(float)(bx0 + bnx) * cw - 1.0f, (float)(by0 + bny) * cw - 1.0f, (float)(bz0 + bnz) * cw - 1.0f};
+            const float o[3] = {m.ox, m.oy, m.oz}, d[3] = {m.dx, m.dy, m.dz};
+            #pragma unroll
+            for (int a = 0; a < 3; a++) {
+                if (d[a] != 0.0f) {
+                    const float r = 1.0f / d[a];
+                    const float ta = (lo[a] - o[a]) * r, tb = (hi[a] - o[a]) * r;
+                    s0 = fmaxf(s0, fminf(ta, tb) - ds);
+                    s1 = fminf(s1, fmaxf(ta, tb) + ds);
+                } else if (o[a] < lo[a] - cw || o[a] > hi[a] + cw) {
+                    may = false;
+                }
+            }
+            if (!(s0 <= s1)) may = false;
+        }
+        if (!may) {
+            go = false;
+        } else {
+            bool hit = false, ended = false;
+            float base = s0;
+            for (int round = 0; round < 2 && !ended; round++) {   // 96 scan positions: lanes 0..63, then 0..31
+                float nb;
+                const float s = lane_lattice(base, ds, lane, nb);
+                base = nb;
+                const bool in_range = round == 0 || lane < 32u;
+                const float ss = fminf(s, s1);
+                const float x = clampf_(m.ox + ss * m.dx, -1.0f, 1.0f), y = clampf_(m.oy + ss * m.dy, -1.0f, 1.0f), z = clampf_(m.oz + ss * m.dz, -1.0f, 1.0f);
+                const int cx = (int)fminf((x + 1) * (0.5f * kCullRes), (float)(kCullRes - 1));
+                const int cy = (int)fminf((y + 1) * (0.5f * kCullRes), (float)(kCullRes - 1));
+                const int cz = (int)fminf((z + 1) * (0.5f * kCullRes), (float)(kCullRes - 1));
+                const bool marked = in_range && cull_marked(cull, cx, cy, cz);
+                // the sequential scan stops after the first position with s >= s1 (that position is still tested)
+                const unsigned long long stop = __ballot(in_range && s >= s1);
+                const uint32_t last = stop ? (uint32_t)__builtin_ctzll(stop) : (round == 0 ? 63u : 31u);
+                const unsigned long long mk = __ballot(marked && lane <= last);
+                if (mk) {
+                    hit = true;
+                    const uint32_t top = 63u - (uint32_t)__builtin_clzll(mk);
+                    t_end = __shfl(ss + ds, (int)top, 64);
+                }
+                if (stop) ended = true;
+            }
+            if (!ended) { t_end = far; hit = true; }   // longer than 96 cells: "may hit, no early end"
+            go = hit;
+        }
+    }
+    uint32_t num_steps = 0;
+    float *ts = sample_t + (size_t)n * max_steps;
+    float base = t0;
+    float carry_tt = -__FLT_MAX__;      // exit parameter of an empty voxel whose successor lies beyond the previous window
+    while (go && num_steps < max_steps) {
+        float nb;
+        const float t = lane_lattice(base, dt, lane, nb);
+        const bool act = t < far && t < t_end;      // the loop condition of the sequential marcher at this lattice point
+        // occupancy and (for an empty voxel) the exit parameter, with MarcherT<true>::probe's expressions
+        const float x = clampf_(m.ox + t * m.dx, -bound, bound), y = clampf_(m.oy + t * m.dy, -bound, bound), z = clampf_(m.oz + t * m.dz, -bound, bound);
+        const int nx = (int)clampf_((x + 1) * m.halfH, 0.0f, m.Hm1), ny = (int)clampf_((y + 1) * m.halfH, 0.0f, m.Hm1),
+                  nz = (int)clampf_((z + 1) * m.halfH, 0.0f, m.Hm1);
+        bool occ = false;
+        if (act && (!cull || cull_marked(cull, nx >> 2, ny >> 2, nz >> 2))) {
+            const uint32_t index = morton3D_8bit((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+            occ = grid[index >> 3] & (1u << (index & 7u));
+        }
+        const float tx = ((((float)nx + m.ex) * m.twoRH - 1) - x) * m.rdx;
+        const float ty = ((((float)ny + m.ey) * m.twoRH - 1) - y) * m.rdy;
+        const float tz = ((((float)nz + m.ez) * m.twoRH - 1) - z) * m.rdz;
+        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        const unsigned long long occ_m = __ballot(act && occ), act_m = __ballot(act);
+        // successor of an empty lane inside this window: the first later lattice point >= tt (at least one step), else 64
+        // (a 128^3 voxel is crossed in at most 8 steps of dt_min; longer crossings walk on)
+        uint32_t nxt = lane + 1u;
+        const bool empty = act && !occ;
+        for (int k = 0; k < 64; k++) {
+            const float lv = __shfl(t, (int)(nxt & 63u), 64);
+            const bool more = empty && nxt < 64u && lv < tt;
+            if (!__any(more)) break;
+            if (more) nxt++;
+        }
+        // entry point of the chain into this window
+        uint32_t cur = 0;
+        float new_carry = -__FLT_MAX__;
+        if (carry_tt != -__FLT_MAX__) {
+            const unsigned long long ge = __ballot(t >= carry_tt);
+            cur = ge ? (uint32_t)__builtin_ctzll(ge) : 64u;
+            if (!ge) new_carry = carry_tt;      // the voxel's exit lies beyond this window too: keep walking
+        }
+        unsigned long long emit = 0ull;
+        uint32_t budget = max_steps - num_steps;
+        bool done = false;
+        while (cur < 64u) {
+            if (!((act_m >> cur) & 1ull)) { done = true; break; }          // t >= far or t >= t_end: the ray is finished
+            if ((occ_m >> cur) & 1ull) {
+                // a run of occupied lattice points: every one is visited and sampled
+                const unsigned long long rest = ~(occ_m >> cur);
+                uint32_t run = rest ? (uint32_t)__builtin_ctzll(rest) : 64u - cur;
+                if (run > 64u - cur) run = 64u - cur;
+                if (run >= budget) { run = budget; done = true; }
+                emit |= ((run >= 64u) ? ~0ull : ((1ull << run) - 1ull)) << cur;
+                budget -= run;
+                cur += run;
+                if (done) break;
+            } else {
+                const uint32_t to = (uint32_t)__shfl((int)nxt, (int)cur, 64);
+                if (to >= 64u) new_carry = __shfl(tt, (int)cur, 64);
+                cur = to;
+            }
+        }
+        if ((emit >> lane) & 1ull) ts[num_steps + (uint32_t)__popcll(emit & ((1ull << lane) - 1ull))] = t;
+        num_steps += (uint32_t)__popcll(emit);
+        if (done) break;
+        carry_tt = new_carry;
+        base = nb;
+    }
+    if (lane == 0) num_steps_out[n] = num_steps;
+}
+
 // Block-level inclusive scan of one uint32 per thread (1024 threads = 16 waves): DPP-free,
 // __shfl_up based wave scan + LDS carry.
 __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t *lds /*[16]*/, uint32_t &block_total) {
@@ -1388,7 +1557,10 @@ int sdn_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
         int rc = sdn_int::build_cull(grid, cull, st);
         if (rc) return rc;
     }
-    if (fast) hipLaunchKernelGGL(k_march_train_count<true>, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
+    if (fast && dt_gamma == 0.0f && H <= 256u)   // constant step: one WAVE per ray (k_march_train_count_wave), same samples bit for bit
+        hipLaunchKernelGGL(k_march_train_count_wave, dim3(sdn_div_up(N, 4u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, max_steps, N, H, nears,
+                           fars, noises, num_steps, use_cull ? (const uint32_t *)cull : nullptr, sample_t);
+    else if (fast) hipLaunchKernelGGL(k_march_train_count<true>, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
                                  max_steps, N, C, H, nears, fars, noises, num_steps, use_cull ? (const uint32_t *)cull : nullptr, sample_t);
     else hipLaunchKernelGGL(k_march_train_count<false>, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
                             max_steps, N, C, H, nears, fars, noises, num_steps, (const uint32_t *)nullptr, sample_t);
