@@ -31,7 +31,6 @@
 //   * optional live-sample index list: only slots that hold a sample are evaluated (the reference evaluates
 //     the network on every padded slot).
 #include <math.h>
-#include <stdlib.h>
 
 #include "sdn_common.h"
 #include "grid_common.h"
@@ -59,7 +58,6 @@ constexpr int kBlkTotal = kBlkC2 + 4;     // 240
 static_assert(kBlkTotal - kBlkD7 == 32, "the tail stage must be exactly one 32 KiB buffer");
 
 constexpr int kStageBytes = 32768;
-constexpr int kLatencyRounds = 1;   // see field_forward_f16
 constexpr int kWaves = 8;                 // waves per workgroup, 32 points each; two workgroups per CU = 4 waves per SIMD
 constexpr int kPointsPerWG = 32 * kWaves;
 
@@ -706,15 +704,10 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
     }
     // expect_points (0 = unknown): the caller's estimate of the live points when M is only a loose bound of them
     const uint32_t busy = expect_points ? sdn_div_up(expect_points < M ? expect_points : M, (uint32_t)kPointsPerWG) : wgs;
-    // latency variant (one workgroup per CU at a time, deep LDS read-ahead) up to kLatencyRounds rounds of workgroups: a lone
-    // workgroup finishes in ~20 us where two co-resident ones take ~42-50 us between them (they move through the kernel's phases
-    // in lock-step and compete for the same unit at every moment), so two ROUNDS of lone workgroups beat one round of pairs
-    static int lat_rounds = -1;
-    if (lat_rounds < 0) {
-        const char *e = getenv("SDN_FIELD_LATENCY_ROUNDS");   // tuning override (measurement only)
-        lat_rounds = e ? atoi(e) : kLatencyRounds;
-    }
-    const bool small = busy <= (uint32_t)cus * (uint32_t)lat_rounds;
+    // latency variant (one workgroup per CU, deep LDS read-ahead) while the launch is at most one workgroup per CU.  (Measured,
+    // profiles/r02_field_latency_rounds.txt: running 2+ ROUNDS of lone workgroups instead of one round of co-resident pairs is
+    // slower -- 57.6 vs 51.9 us at 126 976 points.)
+    const bool small = busy <= (uint32_t)cus;
     if (table_is_padded(offsets_host)) {
         if (small) hipLaunchKernelGGL((k_field_f16<2, 8, false, true>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
         else hipLaunchKernelGGL((k_field_f16<4, 2, false, true>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);

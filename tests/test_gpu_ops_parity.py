@@ -600,19 +600,23 @@ def test_seal_bbox_kernels_match_the_torch_restatement():
         assert np.allclose(got.cpu().numpy(), want.numpy(), atol=2e-6)
 
 
-@pytest.mark.parametrize("max_steps,H", [(1024, 128), (24, 128), (1024, 64), (64, 32)])
-def test_march_rays_train_wave_per_ray_kernel_exact(cam, max_steps, H):
+@pytest.mark.parametrize("max_steps,H,full", [(1024, 128, False), (1024, 128, True), (256, 128, False), (1024, 64, False), (512, 32, True)])
+def test_march_rays_train_wave_per_ray_kernel_exact(cam, max_steps, H, full):
     """The constant-step (dt_gamma == 0) training march runs one WAVE per ray over 64-point windows of the step lattice
-    (k_march_train_count_wave): counts, per-ray offsets and every sample bit-identical to the oracle's sequential march -- also with
-    a sample budget small enough to cut rays short (max_steps 24 / 64: the cap can fall anywhere inside a window), with perturbed
-    starts, and on coarser grids (no cull grid below 128^3)."""
+    (k_march_train_count_wave): counts, per-ray offsets and every sample bit-identical to the oracle's sequential march -- with
+    perturbed starts, on coarser grids (no cull grid below 128^3), with a coarser step (max_steps 256), and on a fully occupied
+    grid, where whole windows are sampled and rays collect hundreds of samples (the step is the cube diagonal / max_steps, so the
+    max_steps cap itself is only ever reached through rounding)."""
     import raymarching
     from dnerf_amd import scene
     N = 1500
     rng = np.random.default_rng(21)
     sel = rng.integers(0, cam["N"], N)
     ro, rd = cam["ro"][sel], cam["rd"][sel]
-    bf = cam["bf"] if H == 128 else scene.jumpingjacks_occupancy(0.5, H)
+    if full:
+        bf = np.full(H ** 3 // 8, 255, np.uint8)
+    else:
+        bf = cam["bf"] if H == 128 else scene.jumpingjacks_occupancy(0.5, H)
     nears, fars = cam["nears"][sel], cam["fars"][sel]
     noises = rng.random(N, dtype=np.float32)
     real_rand = torch.rand
@@ -626,9 +630,7 @@ def test_march_rays_train_wave_per_ray_kernel_exact(cam, max_steps, H):
         rm_mod.torch.rand = real_rand
     counter_r = np.zeros(2, np.int32)
     ref = O.march_rays_train(ro, rd, 1.0, bf, 1, H, nears, fars, counter_r, -1, True, 128, False, 0, max_steps, noises=noises)
-    assert np.array_equal(counter.cpu().numpy(), counter_r) and counter_r[0] > 500
+    assert np.array_equal(counter.cpu().numpy(), counter_r) and counter_r[0] > (50000 if full else 300)
     for o, r, name in zip(out, ref, ("xyzs", "dirs", "deltas", "rays")):
         assert o.shape == r.shape, name
         assert np.array_equal(o.cpu().numpy().view(np.uint32), r.view(np.uint32)), name
-    if max_steps < 100:
-        assert int(ref[3][:, 2].max()) == max_steps          # some rays do hit the cap
