@@ -334,10 +334,6 @@ typedef struct SdnRenderCtx {
     uint32_t n_group_frames, rays_per_frame;
     const uint8_t *frame_bitfield[SDN_MAX_GROUP_FRAMES];
     uint8_t *slot_frame;
-    /* optional [N + 4] uint32 scratch (with rays_tend; bound 1, cascade 1, H 128, dt_gamma 0): the loop then marches in "wave mode" --
-     * a select pass (cull test per alive ray, compact list of the rays that can still produce a sample) and one WAVE per listed
-     * ray, which finds the ray's next samples over 64-point windows of its step lattice.  Same samples bit for bit. */
-    uint32_t *march_cand;
 } SdnRenderCtx;
 
 /* Resets per-ray state (alive = 0..N-1, rays_t = nears, accumulators = 0), the loop record and the counters, and builds

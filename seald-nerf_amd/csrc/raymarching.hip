@@ -195,16 +195,6 @@ using Marcher = MarcherT<false>;
 static inline bool fast_config(float bound, uint32_t C, uint32_t H) {
     return C == 1 && bound == 1.0f && H >= 2 && H <= 256 && (H & (H - 1)) == 0;
 }
-// "wave mode" of the device loop (select pass + one wave per marching ray): the dnerf configuration -- FAST, constant step, the
-// 128^3 grid with its cull grid
-static inline bool wave_mode(float bound, float dt_gamma, uint32_t C, uint32_t H, const void *cull) {
-    return fast_config(bound, C, H) && dt_gamma == 0.0f && H == 128 && cull != nullptr;
-}
-// persistent waves of k_march_wave: 4 per workgroup, at most 16 per CU-slot of 256 CUs; never more than the rays that may march
-static inline uint32_t wave_grid(uint32_t bound_rays) {
-    const uint32_t want = (bound_rays + 3u) / 4u;
-    return want < 4096u ? (want ? want : 1u) : 4096u;
-}
 
 // ---------------------------------------------------------------------------
 // Exact early-out for rays that cannot produce a sample ("cull grid").
@@ -822,7 +812,6 @@ __global__ void __launch_bounds__(256) k_composite_train_bwd(const float *__rest
 // marked cell -- is a property of the ray, not of where the scan started, so the device loop computes it on a ray's first
 // march and later iterations only compare (kTendUnset: not computed yet; kTendDead: the ray cannot produce a sample).
 constexpr float kTendUnset = -2.0f, kTendDead = -1.0f;
-constexpr uint32_t kCandHead = 4;   // wave mode: the candidate list's entries start after its counters
 // device loop: the cache's base pointer travels in the loop record (state[13], state[14]; 0 = no cache)
 __device__ __forceinline__ float *state_tend(const int32_t *__restrict__ state) {
     return reinterpret_cast<float *>(((unsigned long long)(uint32_t)state[14] << 32) | (uint32_t)state[13]);
@@ -1129,9 +1118,8 @@ __global__ void __launch_bounds__(256) k_loop_init(uint32_t N, uint32_t max_step
                                                    float *__restrict__ rays_t, float *__restrict__ weights_sum, float *__restrict__ depth,
                                                    float *__restrict__ image, int32_t *__restrict__ state, int32_t *__restrict__ live_counts,
                                                    uint32_t n_counters, unsigned long long mailbox, uint32_t frame_tag,
-                                                   float *__restrict__ rays_tend, uint32_t *__restrict__ cand) {
+                                                   float *__restrict__ rays_tend) {
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
-    if (cand && n < kCandHead) cand[n] = 0;
     if (n < N) {
         if (rays_tend) rays_tend[n] = kTendUnset;
         alive_a[n] = (int32_t)n;
@@ -1360,282 +1348,6 @@ __global__ void __launch_bounds__(256) k_composite_march(float T_thresh, int32_t
     publish_snapshot(state, snap, call);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// "Wave mode" of the device loop (FAST configuration, constant step, cull grid + per-ray t_end cache): marching is split into
-//   * a SELECT pass, one lane per alive ray: the ray's cull test (cached after its first march), the zero fill of the slots of
-//     rays that cannot produce a sample, and a compact list of the rays that can ("candidates");
-//   * k_march_wave, one WAVE per candidate: the next n_step samples of the ray found over 64-point windows of its step lattice
-//     (see k_march_train_count_wave: same construction, same exactness argument -- every visited parameter is a lattice point).
-// A lane-per-ray marcher is a chain of ~1000 dependent cycles per voxel probe with at most a few hundred waves in flight; a wave
-// per ray turns 64 probes into one parallel round and spreads a few ten thousand rays over the whole chip.
-// cand: [0], [1] = candidate counts of even / odd iterations, entries from cand[4] on.
-// ---------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void cull_cache_load(const uint32_t *__restrict__ cull, uint4 *s_cull4, OccCache &oc) {
-    if (cull) {  // kernel-uniform; contains a barrier: every thread of the 256-thread workgroup calls it
-        s_cull4[threadIdx.x] = reinterpret_cast<const uint4 *>(cull)[threadIdx.x];
-        const int *meta = reinterpret_cast<const int *>(cull + kCullWords);
-        oc.fx0 = meta[0]; oc.fy0 = meta[1]; oc.fz0 = meta[2];
-        oc.fnx = meta[3] - oc.fx0 + 1; oc.fny = meta[4] - oc.fy0 + 1; oc.fnz = meta[5] - oc.fz0 + 1;
-        __syncthreads();
-        oc.s_cull = reinterpret_cast<const uint32_t *>(s_cull4);
-    }
-}
-
-// may this ray still produce a sample from parameter t on?  (the head of march_ray: cull test, cached per ray)
-__device__ __forceinline__ bool select_ray(const OccCache &oc, const float *o, const float *d, float t, float far, float *tend) {
-    bool go = t < far;
-    float t_end = far;
-    if (oc.s_cull && go) {
-        const float cached = tend ? *tend : kTendUnset;
-        if (cached != kTendUnset) {
-            t_end = cached;
-            go = t < t_end;
-        } else {
-            go = ray_may_hit(oc.s_cull, o[0], o[1], o[2], d[0], d[1], d[2], t, far, t_end, oc.fx0, oc.fy0, oc.fz0, oc.fnx, oc.fny, oc.fnz);
-            if (tend) *tend = go ? t_end : kTendDead;
-        }
-    }
-    return go && t < far && t < t_end;
-}
-
-// zero steps mark the slots of a ray that emits nothing: the compositor stops at the first slot with deltas[0] == 0
-__device__ __forceinline__ void zero_deltas(float *pl, uint32_t n_step) {
-    for (uint32_t k = 0; k < n_step; k++) { pl[2 * k] = 0; pl[2 * k + 1] = 0; }
-}
-
-// wave-aggregated append of the lanes with `take` to the candidate list of iteration slot
-__device__ __forceinline__ void cand_append(bool take, uint32_t n, uint32_t *__restrict__ cand, uint32_t slot) {
-    const unsigned long long m = __ballot(take);
-    if (!m) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(cand + slot, (uint32_t)__popcll(m));
-    base = __shfl(base, 0, 64);
-    if (take) cand[kCandHead + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = n;
-}
-
-// SELECT pass of a normal-mode iteration (one lane per alive ray of the compacted list)
-__global__ void __launch_bounds__(256) k_march_select(const int32_t *__restrict__ alive_a, const int32_t *__restrict__ alive_b,
-                                                      const float *__restrict__ rays_t, const float *__restrict__ rays_o,
-                                                      const float *__restrict__ rays_d, const float *__restrict__ fars,
-                                                      float *__restrict__ deltas, const uint32_t *__restrict__ cull,
-                                                      const int32_t *__restrict__ state, uint32_t *__restrict__ cand, FrameSel fs) {
-    const uint32_t n_alive = (uint32_t)state[0], n_step = (uint32_t)state[1];
-    if (n_alive == 0) return;
-    const int32_t *__restrict__ alive = state[4] ? alive_b : alive_a;
-    const uint32_t slot = (uint32_t)state[3] & 1u;
-    __shared__ uint4 s_cull4[256];
-    __shared__ uint32_t s_min4[4];
-    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
-    const int index = n < n_alive ? alive[n] : -1;
-    const bool grouped = fs.n_frames > 1;  // kernel-uniform
-    const uint32_t frame = (grouped && index >= 0) ? (uint32_t)index / fs.rays_per_frame : (grouped ? kNoFrame : 0u);
-    bool marches = false;
-    uint32_t fcur = grouped ? block_min_256(frame, s_min4) : 0u;
-    while (fcur != kNoFrame) {
-        OccCache oc;
-        cull_cache_load((grouped && cull) ? cull + (size_t)fcur * fs.cull_stride : cull, s_cull4, oc);
-        if (index >= 0 && frame == fcur) {
-            float *tend = state_tend(state);
-            if (tend) tend += index;
-            marches = select_ray(oc, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, rays_t[index], fars[index], tend);
-        }
-        if (!grouped) break;
-        fcur = block_min_256((frame != kNoFrame && frame > fcur) ? frame : kNoFrame, s_min4);
-    }
-    if (index >= 0 && !marches) zero_deltas(deltas + (size_t)n * n_step * 2, n_step);
-    cand_append(marches, n, cand, slot);
-}
-
-// Steady-mode iteration: compositing of iteration `it` and the SELECT pass of iteration it + 1 (k_composite_march without the march)
-__global__ void __launch_bounds__(256) k_composite_select(float T_thresh, int32_t *__restrict__ alive_a, int32_t *__restrict__ alive_b,
-                                                          float *__restrict__ rays_t, const float *__restrict__ rays_o,
-                                                          const float *__restrict__ rays_d, const float *__restrict__ fars,
-                                                          const float *__restrict__ sigmas, const float *__restrict__ rgbs,
-                                                          float *__restrict__ deltas, float *__restrict__ weights_sum,
-                                                          float *__restrict__ depth, float *__restrict__ image, const uint32_t *__restrict__ cull,
-                                                          int32_t *__restrict__ state, int32_t *__restrict__ ticket, int32_t *__restrict__ trace,
-                                                          int32_t *__restrict__ snap, uint32_t *__restrict__ cand, FrameSel fs) {
-    __shared__ uint4 s_cull4[256];
-    __shared__ uint32_t s_cnt[4], s_min4[4];
-    __shared__ int s_last;
-    const uint32_t n_alive = (uint32_t)state[0], n_step = (uint32_t)state[1], list_len = (uint32_t)state[8];
-    const int32_t it = state[3];
-    int32_t *__restrict__ alive = state[4] ? alive_b : alive_a;
-    const bool march_next = (uint32_t)state[2] + n_step < (uint32_t)state[6];  // `while step < max_steps` admits another iteration
-    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
-    bool survives = false;
-    if (n_alive > 0 && blockIdx.x * 256u < list_len) {  // workgroup-uniform
-        const int index = n < list_len ? alive[n] : -1;
-        float *pl = deltas + (size_t)n * n_step * 2;
-        if (index >= 0) {
-            survives = composite_ray(index, n_step, T_thresh, sigmas + (size_t)n * n_step, rgbs + (size_t)n * n_step * 3, pl, rays_t,
-                                     weights_sum, depth, image);
-            if (!survives) alive[n] = -1;
-        }
-        const bool wants = survives && march_next;
-        const bool grouped = fs.n_frames > 1;  // kernel-uniform
-        const uint32_t frame = (grouped && wants) ? (uint32_t)index / fs.rays_per_frame : (grouped ? kNoFrame : 0u);
-        bool marches = false;
-        uint32_t fcur = grouped ? block_min_256(frame, s_min4) : 0u;
-        while (fcur != kNoFrame) {
-            OccCache oc;
-            cull_cache_load((grouped && cull) ? cull + (size_t)fcur * fs.cull_stride : cull, s_cull4, oc);
-            if (wants && frame == fcur) {
-                float *tend = state_tend(state);
-                if (tend) tend += index;
-                marches = select_ray(oc, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, rays_t[index], fars[index], tend);
-            }
-            if (!grouped) break;
-            fcur = block_min_256((frame != kNoFrame && frame > fcur) ? frame : kNoFrame, s_min4);
-        }
-        if (wants && !marches) zero_deltas(pl, n_step);
-        cand_append(marches, n, cand, (uint32_t)(it + 1) & 1u);
-    }
-    // survivors of this workgroup -> global accumulator; the last workgroup of the launch advances the loop record
-    const unsigned long long mask = __ballot(survives);
-    if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(mask);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t c = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        if (c) atomicAdd(state + 9, (int32_t)c);
-        __threadfence();
-        s_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
-    }
-    __syncthreads();
-    if (!s_last || threadIdx.x != 0) return;
-    __threadfence();
-    *ticket = 0;
-    const int32_t call = state[7];
-    state[7] = call + 1;
-    if (state[0] > 0) {
-        trace[2 * it] = state[0];
-        trace[2 * it + 1] = state[1];
-        state[2] += state[1];
-        state[3] = it + 1;
-        int32_t n_new = atomicAdd(state + 9, 0);
-        state[9] = 0;
-        if (state[2] >= state[6]) n_new = 0;
-        state[0] = n_new;  // n_step stays 8: N / n_new >= 8 holds from here on
-    }
-    publish_snapshot(state, snap, call);
-}
-
-// One WAVE per candidate ray: its next n_step samples.  Persistent waves stride over the candidate list of the current iteration.
-__global__ void __launch_bounds__(256) k_march_wave(const int32_t *__restrict__ alive_a, const int32_t *__restrict__ alive_b,
-                                                    const float *__restrict__ rays_t, const float *__restrict__ rays_o,
-                                                    const float *__restrict__ rays_d, float bound, uint32_t max_steps, uint32_t H,
-                                                    const uint8_t *__restrict__ grid, const float *__restrict__ fars, float *__restrict__ xyzs,
-                                                    float *__restrict__ dirs, float *__restrict__ deltas, uint32_t *__restrict__ live_idx,
-                                                    uint32_t *__restrict__ live_counts, const int32_t *__restrict__ state,
-                                                    uint32_t *__restrict__ cand, FrameSel fs) {
-    const uint32_t it = (uint32_t)state[3], n_step = (uint32_t)state[1];
-    const uint32_t count = cand[it & 1u];
-    if (blockIdx.x == 0 && threadIdx.x == 0) cand[(it + 1u) & 1u] = 0;     // the next iteration's SELECT pass starts from an empty list
-    const int32_t *__restrict__ alive = state[4] ? alive_b : alive_a;
-    const float *__restrict__ tend_all = state_tend(state);
-    uint32_t *__restrict__ live_count = live_counts + it;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
-    for (uint32_t c = wave; c < count; c += n_waves) {   // wave-uniform
-        const uint32_t n = cand[kCandHead + c];
-        const int index = alive[n];
-        const uint32_t frame = fs.n_frames > 1 ? (uint32_t)index / fs.rays_per_frame : 0u;
-        const uint8_t *__restrict__ grid_f = fs.n_frames > 1 ? frame_grid_uniform(fs, frame) : grid;
-        MarcherT<true> m;
-        m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, 0.0f, max_steps, 1u, H, grid_f);
-        const float far = fars[index], dt = m.dt_const;
-        const float t_end = tend_all ? fminf(tend_all[index] < 0.0f ? far : tend_all[index], far) : far;   // (SELECT stored a bound >= 0)
-        const float t_init = rays_t[index];
-        float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3, *pl = deltas + (size_t)n * n_step * 2;
-        uint32_t step = 0;
-        float base = t_init, last_t = t_init, carry_tt = -__FLT_MAX__;
-        while (step < n_step) {
-            float nb;
-            const float t = lane_lattice(base, dt, lane, nb);
-            const bool act = t < far && t < t_end;
-            const float x = clampf_(m.ox + t * m.dx, -bound, bound), y = clampf_(m.oy + t * m.dy, -bound, bound), z = clampf_(m.oz + t * m.dz, -bound, bound);
-            const int nx = (int)clampf_((x + 1) * m.halfH, 0.0f, m.Hm1), ny = (int)clampf_((y + 1) * m.halfH, 0.0f, m.Hm1),
-                      nz = (int)clampf_((z + 1) * m.halfH, 0.0f, m.Hm1);
-            bool occ = false;
-            if (act) {
-                const uint32_t idx = morton3D_8bit((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
-                occ = grid_f[idx >> 3] & (1u << (idx & 7u));
-            }
-            const float tx = ((((float)nx + m.ex) * m.twoRH - 1) - x) * m.rdx;
-            const float ty = ((((float)ny + m.ey) * m.twoRH - 1) - y) * m.rdy;
-            const float tz = ((((float)nz + m.ez) * m.twoRH - 1) - z) * m.rdz;
-            const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
-            const unsigned long long occ_m = __ballot(act && occ), act_m = __ballot(act);
-            uint32_t nxt = lane + 1u;
-            const bool empty = act && !occ;
-            for (int k = 0; k < 64; k++) {
-                const float lv = __shfl(t, (int)(nxt & 63u), 64);
-                const bool more = empty && nxt < 64u && lv < tt;
-                if (!__any(more)) break;
-                if (more) nxt++;
-            }
-            uint32_t cur = 0;
-            float new_carry = -__FLT_MAX__;
-            if (carry_tt != -__FLT_MAX__) {
-                const unsigned long long ge = __ballot(t >= carry_tt);
-                cur = ge ? (uint32_t)__builtin_ctzll(ge) : 64u;
-                if (!ge) new_carry = carry_tt;
-            }
-            unsigned long long emit = 0ull;
-            uint32_t budget = n_step - step;
-            bool done = false;
-            while (cur < 64u) {
-                if (!((act_m >> cur) & 1ull)) { done = true; break; }
-                if ((occ_m >> cur) & 1ull) {
-                    const unsigned long long rest = ~(occ_m >> cur);
-                    uint32_t run = rest ? (uint32_t)__builtin_ctzll(rest) : 64u - cur;
-                    if (run > 64u - cur) run = 64u - cur;
-                    if (run >= budget) { run = budget; done = true; }
-                    emit |= ((run >= 64u) ? ~0ull : ((1ull << run) - 1ull)) << cur;
-                    budget -= run;
-                    cur += run;
-                    if (done) break;
-                } else {
-                    const uint32_t to = (uint32_t)__shfl((int)nxt, (int)cur, 64);
-                    if (to >= 64u) new_carry = __shfl(tt, (int)cur, 64);
-                    cur = to;
-                }
-            }
-            // the parameter after a sample is the NEXT lattice point; deltas[1] is measured from the parameter after the previous
-            // sample (from the ray's t for its first sample of this call): raymarching.cu:783-790
-            const float t_up = __shfl_down(t, 1, 64);
-            const float after = lane == 63u ? nb : t_up;
-            if (emit) {
-                const bool mine = (emit >> lane) & 1ull;
-                const unsigned long long below = emit & ((1ull << lane) - 1ull);
-                const uint32_t rank = (uint32_t)__popcll(below);
-                const uint32_t prev_lane = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
-                const float prev_after = __shfl(after, (int)prev_lane, 64);
-                if (mine) {
-                    const uint32_t j = step + rank;
-                    px[3 * j] = x; px[3 * j + 1] = y; px[3 * j + 2] = z;
-                    pd[3 * j] = m.dx; pd[3 * j + 1] = m.dy; pd[3 * j + 2] = m.dz;
-                    pl[2 * j] = dt;
-                    pl[2 * j + 1] = after - (below ? prev_after : last_t);
-                    if (fs.n_frames > 1) fs.slot_frame[(size_t)n * n_step + j] = (uint8_t)frame;
-                }
-                const uint32_t top = 63u - (uint32_t)__builtin_clzll(emit);
-                last_t = __shfl(after, (int)top, 64);
-                step += (uint32_t)__popcll(emit);
-            }
-            if (done) break;
-            carry_tt = new_carry;
-            base = nb;
-        }
-        if (lane >= step && lane < n_step) { pl[2 * lane] = 0; pl[2 * lane + 1] = 0; }    // unused slots end the ray's list
-        uint32_t lbase = 0;
-        if (lane == 0 && step) lbase = atomicAdd(live_count, step);
-        lbase = __shfl(lbase, 0, 64);
-        if (lane < step) live_idx[lbase + lane] = n * n_step + lane;
-    }
-}
-
 // image = image + (1 - weights_sum) * bg ; depth = clamp(depth - nears, 0) / (fars - nears)   (dnerf/renderer.py:378-379)
 __global__ void __launch_bounds__(256) k_loop_finish(uint32_t N, const float *__restrict__ nears, const float *__restrict__ fars,
                                                      const float *__restrict__ weights_sum, const float *__restrict__ depth,
@@ -1656,26 +1368,18 @@ namespace sdn_int {
 
 int loop_begin(uint32_t N, uint32_t max_steps, const float *nears, int32_t *alive_a, float *rays_t, float *weights_sum, float *depth,
                float *image, int32_t *state, int32_t *live_counts, uint32_t n_counters, void *mailbox, uint32_t frame_tag, float *rays_tend,
-               uint32_t *cand, hipStream_t st) {
+               hipStream_t st) {
     const uint32_t threads = N > n_counters ? N : n_counters;
     hipLaunchKernelGGL(k_loop_init, dim3(sdn_div_up(threads, 256u)), dim3(256), 0, st, N, max_steps, nears, alive_a, rays_t, weights_sum, depth,
-                       image, state, live_counts, n_counters, (unsigned long long)(uintptr_t)mailbox, frame_tag, rays_tend, cand);
+                       image, state, live_counts, n_counters, (unsigned long long)(uintptr_t)mailbox, frame_tag, rays_tend);
     return sdn_launch_status();
 }
 
 int loop_march(uint32_t bound_alive, const int32_t *alive_a, const int32_t *alive_b, const float *rays_t, const float *rays_o,
                const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
                const float *fars, float *xyzs, float *dirs, float *deltas, const uint32_t *cull, uint32_t *live_idx,
-               uint32_t *live_counts, const int32_t *state, const FrameSel &fs, uint32_t *cand, hipStream_t st) {
+               uint32_t *live_counts, const int32_t *state, const FrameSel &fs, hipStream_t st) {
     const dim3 g(sdn_div_up(bound_alive + 128u, 256u)), b(256);
-    if (cand && wave_mode(bound, dt_gamma, C, H, cull)) {
-        // SELECT (lane per alive ray) + one wave per candidate ray
-        hipLaunchKernelGGL(k_march_select, dim3(sdn_div_up(bound_alive, 256u)), b, 0, st, alive_a, alive_b, rays_t, rays_o, rays_d, fars, deltas, cull,
-                           state, cand, fs);
-        hipLaunchKernelGGL(k_march_wave, dim3(wave_grid(bound_alive)), b, 0, st, alive_a, alive_b, rays_t, rays_o, rays_d, bound, max_steps, H, grid, fars,
-                           xyzs, dirs, deltas, live_idx, live_counts, state, cand, fs);
-        return sdn_launch_status();
-    }
     if (fast_config(bound, C, H)) {
         if (cull && H != 128) cull = nullptr;
         hipLaunchKernelGGL(k_march_rays<true>, g, b, 0, st, 0u, 0u, alive_a, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars,
@@ -1715,25 +1419,18 @@ int loop_composite_compact(uint32_t bound_alive, float T_thresh, int32_t *alive_
 int loop_steady_begin(uint32_t bound_alive, const int32_t *alive_a, const int32_t *alive_b, const float *rays_t, const float *rays_o,
                       const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
                       const float *fars, float *xyzs, float *dirs, float *deltas, const uint32_t *cull, uint32_t *live_idx,
-                      uint32_t *live_counts, int32_t *state, const FrameSel &fs, uint32_t *cand, hipStream_t st) {
+                      uint32_t *live_counts, int32_t *state, const FrameSel &fs, hipStream_t st) {
     hipLaunchKernelGGL(k_steady_begin, dim3(1), dim3(64), 0, st, state);
     return loop_march(bound_alive, alive_a, alive_b, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas,
-                      cull, live_idx, live_counts, state, fs, cand, st);
+                      cull, live_idx, live_counts, state, fs, st);
 }
 
 int loop_composite_march(uint32_t bound_list, float T_thresh, int32_t *alive_a, int32_t *alive_b, float *rays_t, const float *rays_o,
                          const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
                          const float *fars, const float *sigmas, const float *rgbs, float *xyzs, float *dirs, float *deltas,
                          float *weights_sum, float *depth, float *image, const uint32_t *cull, uint32_t *live_idx, uint32_t *live_counts,
-                         int32_t *state, int32_t *ticket, int32_t *trace, int32_t *snap, const FrameSel &fs, uint32_t *cand, hipStream_t st) {
+                         int32_t *state, int32_t *ticket, int32_t *trace, int32_t *snap, const FrameSel &fs, hipStream_t st) {
     const dim3 g(sdn_div_up(bound_list, 256u)), b(256);
-    if (cand && wave_mode(bound, dt_gamma, C, H, cull)) {
-        hipLaunchKernelGGL(k_composite_select, g, b, 0, st, T_thresh, alive_a, alive_b, rays_t, rays_o, rays_d, fars, sigmas, rgbs, deltas, weights_sum,
-                           depth, image, cull, state, ticket, trace, snap, cand, fs);
-        hipLaunchKernelGGL(k_march_wave, dim3(wave_grid(bound_list)), b, 0, st, (const int32_t *)alive_a, (const int32_t *)alive_b, (const float *)rays_t,
-                           rays_o, rays_d, bound, max_steps, H, grid, fars, xyzs, dirs, deltas, live_idx, live_counts, (const int32_t *)state, cand, fs);
-        return sdn_launch_status();
-    }
     if (fast_config(bound, C, H)) {
         if (cull && H != 128) cull = nullptr;
         hipLaunchKernelGGL(k_composite_march<true>, g, b, 0, st, T_thresh, alive_a, alive_b, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,

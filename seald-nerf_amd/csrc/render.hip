@@ -17,16 +17,13 @@
 #include "sdn_internal.h"
 
 namespace sdn_int {
-// candidate list of the loop's "wave mode" (select pass + one wave per marching ray): needs the per-ray cull cache as well
-static inline uint32_t *wave_cand(const SdnRenderCtx *c) { return (c->march_cand && c->rays_tend) ? c->march_cand : nullptr; }
-
 int render_begin(const SdnRenderCtx *c, void *mailbox, uint32_t frame_tag, hipStream_t st) {
     if (c->aabb) {  // nears / fars of this frame's rays, on the frame's stream (one Python round trip less per frame)
         int rc0 = sdn_near_far_from_aabb(c->rays_o, c->rays_d, c->aabb, c->N, c->min_near, (float *)c->nears, (float *)c->fars, st);
         if (rc0) return rc0;
     }
     int rc = loop_begin(c->N, c->max_steps, c->nears, c->alive_a, c->rays_t, c->weights_sum, c->depth, c->image, c->state, c->live_counts,
-                        c->n_counters, mailbox, frame_tag, c->rays_tend, wave_cand(c), st);
+                        c->n_counters, mailbox, frame_tag, c->rays_tend, st);
     if (rc) return rc;
     if (c->H == 128 && c->C == 1)
         rc = c->n_group_frames > 1 ? build_cull_group(frame_sel(c), (uint32_t *)c->cull_bits, st) : build_cull(c->bitfield, (uint32_t *)c->cull_bits, st);
@@ -85,7 +82,7 @@ int sdn_render_step_f16_ev(const SdnRenderCtx *c, uint32_t bound_alive, void *ev
     const uint32_t *cull = (c->H == 128 && c->C == 1) ? (const uint32_t *)c->cull_bits : nullptr;
     int rc = sdn_int::loop_march(bound_alive, c->alive_a, c->alive_b, c->rays_t, c->rays_o, c->rays_d, c->bound, c->dt_gamma, c->max_steps,
                                  c->C, c->H, c->bitfield, c->fars, c->xyzs, c->dirs, c->deltas, cull, c->live_idx,
-                                 (uint32_t *)c->live_counts, c->state, sdn_int::frame_sel(c), sdn_int::wave_cand(c), st);
+                                 (uint32_t *)c->live_counts, c->state, sdn_int::frame_sel(c), st);
     if (rc) return rc;
     // n_alive * n_step <= N always (n_step <= N / n_alive), and <= 8 * bound_alive
     uint64_t m_bound = (uint64_t)bound_alive * 8u;
@@ -177,8 +174,7 @@ struct FrameRun {
                 rc = sdn_int::loop_composite_march(bound, c->T_thresh, c->alive_a, c->alive_b, c->rays_t, c->rays_o, c->rays_d, c->bound,
                                                    c->dt_gamma, c->max_steps, c->C, c->H, c->bitfield, c->fars, c->sigmas, c->rgbs, c->xyzs,
                                                    c->dirs, c->deltas, c->weights_sum, c->depth, c->image, cull(), c->live_idx,
-                                                   (uint32_t *)c->live_counts, c->state, c->n_out, c->trace, snap_dev, sdn_int::frame_sel(c),
-                                                   sdn_int::wave_cand(c), st);
+                                                   (uint32_t *)c->live_counts, c->state, c->n_out, c->trace, snap_dev, sdn_int::frame_sel(c), st);
         }
         if (rc) return rc;
         if (mail_dev) return 0;
@@ -234,8 +230,7 @@ struct FrameRun {
                     // iteration `it` (enqueued, normal mode) ends with a compacted list; freeze it and march iteration it+1
                     int rc = sdn_int::loop_steady_begin(bound, c->alive_a, c->alive_b, c->rays_t, c->rays_o, c->rays_d, c->bound, c->dt_gamma,
                                                         c->max_steps, c->C, c->H, c->bitfield, c->fars, c->xyzs, c->dirs, c->deltas, cull(),
-                                                        c->live_idx, (uint32_t *)c->live_counts, c->state, sdn_int::frame_sel(c),
-                                                        sdn_int::wave_cand(c), st);
+                                                        c->live_idx, (uint32_t *)c->live_counts, c->state, sdn_int::frame_sel(c), st);
                     if (rc) return rc;
                     steady = true;
                 }

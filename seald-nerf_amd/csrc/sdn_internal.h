@@ -18,23 +18,23 @@ FrameSel frame_sel(const SdnRenderCtx *c);
 
 int loop_begin(uint32_t N, uint32_t max_steps, const float *nears, int32_t *alive_a, float *rays_t, float *weights_sum, float *depth,
                float *image, int32_t *state, int32_t *live_counts, uint32_t n_counters, void *mailbox, uint32_t frame_tag, float *rays_tend,
-               uint32_t *cand, hipStream_t st);
+               hipStream_t st);
 int loop_march(uint32_t bound_alive, const int32_t *alive_a, const int32_t *alive_b, const float *rays_t, const float *rays_o,
                const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
                const float *fars, float *xyzs, float *dirs, float *deltas, const uint32_t *cull, uint32_t *live_idx,
-               uint32_t *live_counts, const int32_t *state, const FrameSel &fs, uint32_t *cand, hipStream_t st);
+               uint32_t *live_counts, const int32_t *state, const FrameSel &fs, hipStream_t st);
 int loop_composite_compact(uint32_t bound_alive, float T_thresh, int32_t *alive_a, int32_t *alive_b, float *rays_t, const float *sigmas,
                            const float *rgbs, const float *deltas, float *weights_sum, float *depth, float *image, int32_t *state,
                            uint32_t *block_totals, int32_t *n_out, int32_t *trace, int32_t *snap, hipStream_t st);
 int loop_steady_begin(uint32_t bound_alive, const int32_t *alive_a, const int32_t *alive_b, const float *rays_t, const float *rays_o,
                       const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
                       const float *fars, float *xyzs, float *dirs, float *deltas, const uint32_t *cull, uint32_t *live_idx,
-                      uint32_t *live_counts, int32_t *state, const FrameSel &fs, uint32_t *cand, hipStream_t st);
+                      uint32_t *live_counts, int32_t *state, const FrameSel &fs, hipStream_t st);
 int loop_composite_march(uint32_t bound_list, float T_thresh, int32_t *alive_a, int32_t *alive_b, float *rays_t, const float *rays_o,
                          const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
                          const float *fars, const float *sigmas, const float *rgbs, float *xyzs, float *dirs, float *deltas,
                          float *weights_sum, float *depth, float *image, const uint32_t *cull, uint32_t *live_idx, uint32_t *live_counts,
-                         int32_t *state, int32_t *ticket, int32_t *trace, int32_t *snap, const FrameSel &fs, uint32_t *cand, hipStream_t st);
+                         int32_t *state, int32_t *ticket, int32_t *trace, int32_t *snap, const FrameSel &fs, hipStream_t st);
 int loop_finish(uint32_t N, const float *nears, const float *fars, const float *weights_sum, const float *depth, const float *image, float bg,
                 float *image_out, float *depth_out, hipStream_t st);
 int render_begin(const SdnRenderCtx *c, void *mailbox, uint32_t frame_tag, hipStream_t st);

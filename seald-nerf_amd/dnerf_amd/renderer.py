@@ -465,8 +465,7 @@ class DeviceLoop:
     RING = 4
     MAX_TIMED = 24  # iterations whose fused-field launch can be timed in place (the headline frame has 11 + 1)
 
-    def __init__(self, model, field, N, device, max_steps=1024, T_thresh=1e-2, dt_gamma=0.0, mailbox=True, mapper=None, frames=1,
-                 wave_march=True):
+    def __init__(self, model, field, N, device, max_steps=1024, T_thresh=1e-2, dt_gamma=0.0, mailbox=True, mapper=None, frames=1):
         """frames > 1: a FRAME GROUP -- the N rays are `frames` equal, frame-major blocks (the shards of consecutive frames of a camera
         path / of successive time steps) rendered together by one loop, each at its own time (`bind(..., time=[t_0, ..., t_F-1])`):
         the chain of ~30 dependent launches of a loop is paid once per group instead of once per frame.  Per-ray results do not
@@ -489,8 +488,6 @@ class DeviceLoop:
                         cull_bits=torch.empty(self.frames * int(lib.sdn_cull_grid_bytes()), dtype=torch.uint8, device=device))
         if self.frames > 1:
             self.buf["slot_frame"] = torch.zeros(M, dtype=torch.uint8, device=device)
-        if wave_march:   # "wave mode" marching (select pass + one wave per marching ray); the driver falls back where it does not apply
-            self.buf["march_cand"] = torch.zeros(N + 4, dtype=i32, device=device)
         self.image_out, self.depth_out = z(N, 3), z(N)
         self.snap = self.buf["trace"][2 * n_counters: 2 * n_counters + 8].view(4, 2)  # device ring written by the advance
         from sdn_backend import HostMailbox

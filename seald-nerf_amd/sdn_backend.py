@@ -75,7 +75,7 @@ class SdnRenderCtx(ctypes.Structure):
                 + [(n, _u32) for n in ("N", "M_cap", "n_counters", "max_steps", "C", "H")]
                 + [(n, _f32) for n in ("bound", "dt_gamma", "T_thresh", "density_scale")]
                 + [("zero_deform", ctypes.c_int32), ("aabb", _vp), ("min_near", _f32), ("reserved_", ctypes.c_int32), ("rays_tend", _vp), ("seal", _vp), ("seal_mask", _vp),
-                   ("n_group_frames", _u32), ("rays_per_frame", _u32), ("frame_bitfield", _vp * MAX_GROUP_FRAMES), ("slot_frame", _vp), ("march_cand", _vp)])
+                   ("n_group_frames", _u32), ("rays_per_frame", _u32), ("frame_bitfield", _vp * MAX_GROUP_FRAMES), ("slot_frame", _vp)])
 
 
 class SdnSealBox(ctypes.Structure):

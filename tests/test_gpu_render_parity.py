@@ -481,27 +481,3 @@ def test_lego_scene_800x800_properties():
         assembled[idx_t] = o["image"]
     torch.cuda.synchronize()
     assert torch.equal(assembled, img)
-
-
-@pytest.mark.parametrize("side", [64, 800])
-def test_wave_mode_marching_equals_lane_per_ray_marching(side):
-    """The device loop's "wave mode" (select pass + one wave per marching ray over 64-point windows of the step lattice) against the
-    lane-per-ray marchers it replaces: identical image, depth, per-iteration trace and sample count -- the samples are the same
-    samples."""
-    from dnerf_amd.bench_scene import build_scene, camera_path
-    from dnerf_amd import fused
-    from dnerf_amd.renderer import DeviceLoop
-    sc = build_scene(H=side, W=side, device="cuda", seed=0)
-    ros, rds, times = camera_path(sc, 4)
-    f = fused.FusedField(sc.model, sc.time, fp16=True)
-    N = side * side
-    wave = DeviceLoop(sc.model, f, N, "cuda", wave_march=True)
-    lane = DeviceLoop(sc.model, f, N, "cuda", wave_march=False)
-    for k in range(4):
-        a = wave.render(ros[k], rds[k], times[k])
-        img, dep, tr, ns = a["image"].clone(), a["depth"].clone(), a["trace"], a["n_samples"]
-        b = lane.render(ros[k], rds[k], times[k])
-        torch.cuda.synchronize()
-        assert tr == b["trace"] and ns == b["n_samples"] > 0, k
-        assert torch.equal(img, b["image"]), k
-        assert torch.equal(torch.nan_to_num(dep), torch.nan_to_num(b["depth"])), k
