@@ -36,9 +36,6 @@
 #include "grid_common.h"
 #include "sh_eval.h"
 
-#ifndef SDN_ABL
-#define SDN_ABL 0   // timing-experiment switches (tools/field_microbench.py); 0 in every shipped build
-#endif
 
 namespace {
 
@@ -126,18 +123,7 @@ __device__ __forceinline__ void acc_to_frags(const f32x16 &acc, half8 &f0, half8
         f0[j] = (_Float16)acc[j];
         f1[j] = (_Float16)acc[8 + j];
     }
-#ifdef SDN_RELU_F32
     if (RELU) {
-        #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            f0[j] = (_Float16)fmaxf(acc[j], 0.0f);
-            f1[j] = (_Float16)fmaxf(acc[8 + j], 0.0f);
-        }
-    }
-    if (false) {
-#else
-    if (RELU) {
-#endif
         const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
         f0 = __builtin_elementwise_max(f0, zero);
         f1 = __builtin_elementwise_max(f1, zero);
@@ -146,9 +132,8 @@ __device__ __forceinline__ void acc_to_frags(const f32x16 &acc, half8 &f0, half8
 
 __device__ __forceinline__ float round_h(float v) { return (float)(_Float16)v; }
 
-// fp32 multiply / add with one operand taken straight from the low / high half of a packed fp16 pair (v_fma_mix_f32):
+// fp32 multiply with one operand taken straight from the low / high half of a packed fp16 pair (v_fma_mix_f32):
 //   mix_mul_*(w, h2) = w * float(h2.half)        as fma(w, half, -0)  -- identical to the rounded product for every input
-//   mix_add_*(t, h2) = float(h2.half) + t        as fma(1, half, t)
 __device__ __forceinline__ float mix_mul_lo(float w, uint32_t h2) {
     float r;
     asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(h2), "s"(-0.0f));
@@ -159,36 +144,10 @@ __device__ __forceinline__ float mix_mul_hi(float w, uint32_t h2) {
     asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(h2), "s"(-0.0f));
     return r;
 }
-__device__ __forceinline__ float mix_add_lo(float t, uint32_t h2) {
-    float r;
-    asm("v_fma_mix_f32 %0, 1.0, %1, %2 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(h2), "v"(t));
-    return r;
-}
-__device__ __forceinline__ float mix_add_hi(float t, uint32_t h2) {
-    float r;
-    asm("v_fma_mix_f32 %0, 1.0, %1, %2 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(h2), "v"(t));
-    return r;
-}
-
-// sin(a) for |a| < ~1e4 to ~1e-7 absolute: 3-term Cody-Waite reduction by pi (explicit FMAs: this file is built with
-// -ffp-contract=off) + odd degree-9 minimax polynomial on [-pi/2, pi/2].  The standalone freq_encode kernel uses OCML
-// sinf (<= 1 ulp); the two agree to ~1e-7, far below the fp16 rounding the features get as MFMA operands.
-__device__ __forceinline__ float fast_sin(float a) {
-    const float k = rintf(a * 0.31830988618379067f);
-    float r = __builtin_fmaf(-k, 3.140625f, a);                  // pi_hi  (8 significant bits: k * pi_hi exact)
-    r = __builtin_fmaf(-k, 9.67502593994140625e-4f, r);        // pi_mid
-    r = __builtin_fmaf(-k, 1.509957990978376e-7f, r);          // pi_lo
-    const float r2 = r * r;
-    float p = __builtin_fmaf(r2, 2.6083159809786593e-6f, -1.9810690719168633e-4f);
-    p = __builtin_fmaf(p, r2, 8.3330785855650902e-3f);
-    p = __builtin_fmaf(p, r2, -1.6666659712791443e-1f);
-    const float s = __builtin_fmaf(r * r2, p, r);
-    const int ki = (int)k;
-    return __int_as_float(__float_as_int(s) ^ ((ki & 1) << 31));
-}
-
-// sin(a) and cos(a) with one shared Cody-Waite reduction by pi: r = a - k pi in [-pi/2, pi/2], sin(a) = (-1)^k sin(r),
-// cos(a) = (-1)^k cos(r); odd degree-9 / even degree-10 minimax polynomials (~1e-7 absolute for |a| < ~1e4).
+// sin(a) and cos(a) with one shared 3-term Cody-Waite reduction by pi (explicit FMAs: this file is built with -ffp-contract=off):
+// r = a - k pi in [-pi/2, pi/2], sin(a) = (-1)^k sin(r), cos(a) = (-1)^k cos(r); odd degree-9 / even degree-10 polynomials,
+// ~1.3e-7 absolute for |a| < ~1e4.  The standalone freq_encode kernel uses OCML sinf (<= 1 ulp); the two agree to ~1e-7, far below
+// the fp16 rounding the features get as MFMA operands.
 __device__ __forceinline__ void fast_sincos(float a, float &sn, float &cs) {
     const float k = rintf(a * 0.31830988618379067f);
     float r = __builtin_fmaf(-k, 3.140625f, a);
@@ -253,15 +212,6 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     }
     const uint32_t count = P.state ? P.live_count[P.state[3]] : (P.live_idx ? *P.live_count : P.M);
     if (blockIdx.x * (uint32_t)kPointsPerWG >= count) return;  // workgroup-uniform: nothing to do, no barrier touched
-#if SDN_ABL == 9
-    unsigned long long ts[12];
-    int nts = 0;
-    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
-    #define SDN_TS() ts[nts++] = __builtin_readcyclecounter()
-#else
-    #define SDN_TS()
-#endif
-    SDN_TS();
     const uint32_t n = lane & 31u, h = lane >> 5;
     const uint32_t i = blockIdx.x * (uint32_t)kPointsPerWG + wave * 32u + n;
     const bool valid = i < count;
@@ -303,11 +253,7 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
         float sv[5][3], cv[5][3];
         #pragma unroll
         for (int dd = 0; dd < 3; dd++) {
-#if SDN_ABL == 1
-            sv[0][dd] = xs[dd] * fscale; cv[0][dd] = xs[dd];
-#else
             fast_sincos(xs[dd] * fscale, sv[0][dd], cv[0][dd]);
-#endif
             #pragma unroll
             for (int f = 1; f < 5; f++) {
                 const float sp = sv[f - 1][dd], cp = cv[f - 1][dd];
@@ -344,7 +290,6 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
             for (int r = 0; r < 16; r++) acc[mt][r] = b0[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h];
         }
     }
-    SDN_TS();   // 1: features done
     // Wave priority follows the phase.  All vector instructions of a SIMD share one issue port and the arbiter prefers the oldest
     // wave, so a co-resident workgroup that is in its VALU-only grid phase starves a younger one's MFMAs completely (measured:
     // the second workgroup of a CU made no progress until the first had retired -- two tiles took 28 + 23 us, not ~35).  An MFMA
@@ -352,25 +297,16 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     // fills the remaining 24 and the two phases overlap.
     __builtin_amdgcn_s_setprio(2);
     stage_wait_and_sync();  // D0 and D1 are resident
-    SDN_TS();   // 2: first stages landed
     #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
         #pragma unroll
         for (int mt = 0; mt < 4; mt++) acc[mt] = mfma(lds_frag(s_w[0], mt * 4 + ks, lane), bf[ks], acc[mt]);
     }
-
-    SDN_TS();   // 3: layer 0 issued
     // ---------------- deform layers 1..6 (128 -> 128, ReLU): stage l+1 uses buffer (l+1)&1 ----------------
-#if SDN_ABL == 4
-    for (int l = 5; l < 6; l++) {
-#else
     for (int l = 0; l < 6; l++) {
-#endif
         const unsigned char *cur = s_w[(l + 1) & 1];
-#if SDN_ABL != 6
         #pragma unroll
         for (int t = 0; t < 4; t++) acc_to_frags<true>(acc[t], bf[2 * t], bf[2 * t + 1]);
-#endif
         stage_wait_and_sync();  // stage l+1 landed for everyone; everyone is done reading the other buffer (layer l)
         // refill the other buffer with stage l+2 (D(l+2) for l < 5, the tail stage for l == 5); it lands under this layer's MFMAs
         stage_load(P.weights + (size_t)(l < 5 ? kBlkD1 + (l + 1) * 32 : kBlkD7) * 1024, s_w[l & 1], kStageBytes, wave, lane);
@@ -384,9 +320,7 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
         for (int i = 0; i < 32; i++) {
             const int ks = i >> 2, mt = i & 3;
             const half8 a = ring[i % LA];
-#if SDN_ABL != 5
             if (i + LA < 32) ring[i % LA] = lds_frag(cur, ((i + LA) & 3) * 8 + ((i + LA) >> 2), lane);
-#endif
             if (ks == 0) {
                 f32x16 z;
                 #pragma unroll
@@ -408,7 +342,6 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     }
     #pragma unroll
     for (int t = 0; t < 4; t++) acc_to_frags<true>(acc[t], bf[2 * t], bf[2 * t + 1]);
-    SDN_TS();   // 4: hidden layers issued
     stage_wait_and_sync();  // tail stage (D7 | S0 | S1 | C0 | C1 | C2) resident in buffer 1
     const unsigned char *tail = s_w[1];
     constexpr int tD7 = 0, tS0 = kBlkS0 - kBlkD7, tS1 = kBlkS1 - kBlkD7, tC0 = kBlkC0 - kBlkD7, tC1 = kBlkC1 - kBlkD7, tC2 = kBlkC2 - kBlkD7;
@@ -432,17 +365,10 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
             u[c] = (xd + P.bound) / (2 * P.bound);  // GridEncoder.forward (grid.py:149)
         }
     }
-
-    SDN_TS();   // 5: deform output
     __builtin_amdgcn_s_setprio(0);
     // ---------------- grid encode: lane-half h evaluates levels 8h .. 8h+7 ----------------
     half8 gf[2];
     uint32_t gfw[2][4];   // the same 2 x 8 halfs as packed pairs
-#if SDN_ABL == 3
-    #pragma unroll
-    for (int j = 0; j < 8; j++) { gf[0][j] = (_Float16)u[j % 3]; gf[1][j] = (_Float16)u[(j + 1) % 3]; }
-    if (false)
-#endif
     {
         const bool oob = (u[0] < 0) | (u[0] > 1) | (u[1] < 0) | (u[1] > 1) | (u[2] < 0) | (u[2] > 1);
         // The x and x+1 corners of a (y, z) corner pair are neighbouring table rows, so one 8-byte gather fetches both:
@@ -485,15 +411,10 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
                     corner(lq, c, tab, row0, mask, hsize, pos[lq]);
                     // the pair (rl, rl + 1) is always inside the level (PAD: row hsize exists and repeats row 0)
                     const uint32_t rl = PAD ? row0 : min(row0, hsize - 2u);
-#if SDN_ABL == 2
-                    pairs[lq][c] = make_uint2(rl, rl + 1u);
-#else
                     __builtin_memcpy(&pairs[lq][c], table_bytes + ((tab + rl) << 2), 8);   // 4-byte aligned 8-byte gather
-#endif
                     if (!PAD && row0 > rl) wrapbits |= 1u << (4 * lq + (int)c);
                 }
             }
-#if SDN_ABL != 2
             // On a capped level the x corner may be the LAST row: it is then the second row of the pair that was fetched and the
             // x+1 corner is row 0.  Patched after every gather of the batch has been issued (a branch per gather would make each
             // wait for its own data); practically never taken (1 row in 2^19).
@@ -511,7 +432,6 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
                     }
                 }
             }
-#endif
             #pragma unroll
             for (int lq = 0; lq < kGridBatch; lq++) {
                 // kernel_grid (gridencoder.cu:187-189), scalar_t = at::Half:  results[ch] += w * grid[index + ch]  is
@@ -543,14 +463,11 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
         }
     }
 
-#if SDN_ABL != 3
     #pragma unroll
     for (int q = 0; q < 2; q++) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         gf[q] = __builtin_bit_cast(half8, (u32x4){gfw[q][0], gfw[q][1], gfw[q][2], gfw[q][3]});
     }
-#endif
-    SDN_TS();   // 6: grid features
     // ---------------- sigma net: 32 -> 64 (ReLU) -> 16 ----------------
     f32x16 s0[2];
     #pragma unroll
@@ -570,8 +487,6 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     for (int ks = 0; ks < 4; ks++) hv = mfma(lds_frag(tail, tS1 + ks, lane), sf[ks], hv);
     // h[0] (lane-half 0, register 0) is the density logit; trunc_exp = exp in fp32 of the fp16 value
     const float sigma = P.density_scale * expf(round_h(hv[0]));
-
-    SDN_TS();   // 7: sigma
     if constexpr (CELLS) {
         if (h == 0 && valid) P.sigmas[p] = sigma;   // duplicates in the list: any one of them wins, as with tmp_grid[indices] = sigmas
         return;
@@ -619,19 +534,6 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     for (int r = 0; r < 16; r++) co[r] = 0.0f;
     #pragma unroll
     for (int ks = 0; ks < 4; ks++) co = mfma(lds_frag(tail, tC2 + ks, lane), c2f[ks], co);
-
-    SDN_TS();   // 8: colour net issued
-#if SDN_ABL == 9
-    if (co[0] == 12345.678f) ts[0] = 0;   // keep the accumulator (and with it the MFMAs before the last stamp) alive
-    if (threadIdx.x == 0) {   // per workgroup: {start, end} in 10 ns ticks relative to a common origin, shader cycles; block 0 also its phase stamps
-        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
-        float *o = P.rgbs + 64 + 4 * (size_t)blockIdx.x;
-        o[0] = (float)(long long)(rt0 & 0xFFFFFFull); o[1] = (float)(long long)(rt1 & 0xFFFFFFull); o[2] = (float)(long long)(ts[nts - 1] - ts[0]);
-        if (blockIdx.x == 0) for (int k = 0; k < nts; k++) P.rgbs[k] = (float)(long long)(ts[k] - ts[0]);
-        if (blockIdx.x == 300) for (int k = 0; k < nts; k++) P.rgbs[16 + k] = (float)(long long)(ts[k] - ts[0]);
-    }
-    return;
-#endif
     if (h == 0 && valid) {
         P.sigmas[p] = sigma;
         #pragma unroll

@@ -53,21 +53,6 @@ def main():
     torch.cuda.synchronize()
     us = s.elapsed_time(e) * 1000 / args.iters
     sig, rgb = f(xyz, dirs)
-    if os.environ.get("SDN_DUMP_TS"):   # diagnostic build (-DSDN_ABL=9): phase time stamps of workgroup 0 in shader-clock cycles
-        flat = rgb.reshape(-1).cpu().numpy()
-        print("timestamps", [int(v) for v in flat[:12].tolist()], flush=True)
-        print("timestamps block 300", [int(v) for v in flat[16:28].tolist()], flush=True)
-        nb = (args.points + 255) // 256
-        per = flat[64:64 + 4 * nb].reshape(nb, 4)
-        t0, t1, cyc = per[:, 0], per[:, 1], per[:, 2]
-        dur = (t1 - t0) * 0.01
-        print("blocks", nb, "span_us", round(float((t1.max() - t0.min()) * 0.01), 2), "start_spread_us", round(float((t0.max() - t0.min()) * 0.01), 2),
-              "block_us min/med/max", [round(float(v), 2) for v in (dur.min(), np.median(dur), dur.max())],
-              "clock_GHz med", round(float(np.median(cyc / np.maximum(dur, 1e-3)) / 1e3), 3), flush=True)
-        print("deciles_us", [round(float(v), 1) for v in np.percentile(dur, [0, 10, 20, 30, 40, 50, 60, 70, 80, 90, 100])], flush=True)
-        slow = np.nonzero(dur > 1.4 * np.median(dur))[0]
-        print("slow blocks", len(slow), "idx", slow[:24].tolist(), "xcd", (slow % 8)[:24].tolist(), "cycles", [int(v) for v in cyc[slow][:8]],
-              "start_us", [round(float(v), 2) for v in ((t0[slow] - t0.min()) * 0.01)[:8]], flush=True)
     print(json.dumps({"points": args.points, "us_per_launch": round(us, 2), "tflops": round(235520 * args.points / us / 1e6, 1),
                       "checksum": [float(sig.double().sum()), float(rgb.double().sum())]}), flush=True)
 
