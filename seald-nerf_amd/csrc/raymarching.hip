@@ -609,8 +609,10 @@ __global__ void __launch_bounds__(256) k_march_train_count_wave(const float *__r
                 cur += run;
                 if (done) break;
             } else {
-                const uint32_t to = (uint32_t)__shfl((int)nxt, (int)cur, 64);
-                if (to >= 64u) new_carry = __shfl(tt, (int)cur, 64);
+                // (cur is wave-uniform: v_readlane with a scalar lane index, not an LDS-latency ds_bpermute)
+                const uint32_t cur_s = __builtin_amdgcn_readfirstlane(cur);
+                const uint32_t to = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)cur_s);
+                if (to >= 64u) new_carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tt), (int)cur_s));
                 cur = to;
             }
         }
