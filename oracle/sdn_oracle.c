@@ -18,9 +18,16 @@
  *     point where the reference's at::Half operators round.
  *
  * Parity pin: the reference ships no golden vectors for these kernels
- * (testing/test_raymarching.py is empty); see tests/golden/README.md for what
- * is pinned (freq via encoding.FreqEncoder, SH via the reference's closed
- * forms, grid via float64 gradcheck) and what is "parity unpinned".
+ * (testing/test_raymarching.py is empty) and its .cu files cannot be built
+ * here (CUDA toolkit, CUTLASS).  What pins this restatement (tests/golden/README.md):
+ *   - per operator: freq via the reference's encoding.FreqEncoder, SH via its closed
+ *     forms, trunc_exp / colour conversions via its pure-torch code, grid via the
+ *     float64 gradcheck its test prescribes;
+ *   - above the operator boundary: the reference's own dnerf/renderer.py,
+ *     dnerf/network.py, SealDNeRF/renderer.py, seal_utils.py and nerf/utils.get_rays
+ *     EXECUTED over these operators (tests/golden/gen_caller_fixtures.py ->
+ *     caller_*.npz): loop traces, images, network outputs, training gradients;
+ *   - only ffmlp stays "parity unpinned" (oracle/ffmlp.py).
  *
  * Each function cites the reference file:line it follows
  * (paths relative to /root/reference).
