@@ -699,7 +699,13 @@ def cpu_baseline(sc, side):
     orender.render_run_cpu(state, ro, rd, 0.5, threads=cores)
     dt = time.perf_counter() - t0
     n = ro.shape[0]
-    return {"value": n * 128 / dt, "unit": "sampled-points/s", "rays_per_s": n / dt, "cores": cores, "kind": "port",
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
+    except OSError:
+        pass
+    return {"value": n * 128 / dt, "unit": "sampled-points/s", "rays_per_s": n / dt, "cores": cores, "cpu_model": model, "kind": "port",
             "sample": f"{side}x{side} rays of the same camera and weights, 128 uniform samples/ray (the reference's non-cuda_ray "
                       f"sampler, upsample_steps=0, max_ray_batch=4096), fp32, {dt:.1f} s; it samples empty space too, so rays/s is the "
                       f"like-for-like figure"}
