@@ -178,6 +178,13 @@ __device__ __forceinline__ void stage_load(const unsigned char *__restrict__ g, 
     }
 }
 
+// One 1-KiB piece of a stage: piece k of this wave (pieces are dealt to the waves round-robin, as stage_load does).
+__device__ __forceinline__ void stage_piece(const unsigned char *__restrict__ g, unsigned char *lds, int k, uint32_t wave, uint32_t lane) {
+    const uint32_t off = __builtin_amdgcn_readfirstlane((wave + (uint32_t)k * kWaves) * 1024u);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off + lane * 16),
+                                     (__attribute__((address_space(3))) void *)(lds + off), 16, 0, 0);
+}
+
 // A staged buffer may be read once (a) every wave's own direct-to-LDS loads have landed -- they are pending LDS writes on the
 // VM counter, and hipcc does NOT reliably emit the vmcnt wait in front of __syncthreads() for them (checked in the ISA:
 // only lgkmcnt was waited) -- and (b) the workgroup has met at the barrier.
@@ -309,7 +316,10 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
         for (int t = 0; t < 4; t++) acc_to_frags<true>(acc[t], bf[2 * t], bf[2 * t + 1]);
         stage_wait_and_sync();  // stage l+1 landed for everyone; everyone is done reading the other buffer (layer l)
         // refill the other buffer with stage l+2 (D(l+2) for l < 5, the tail stage for l == 5); it lands under this layer's MFMAs
-        stage_load(P.weights + (size_t)(l < 5 ? kBlkD1 + (l + 1) * 32 : kBlkD7) * 1024, s_w[l & 1], kStageBytes, wave, lane);
+        // (its four 1-KiB pieces per wave are issued between this layer's MFMAs, not in front of them: a direct-to-LDS load costs
+        // 60-180 cycles of issue, and eight waves issuing four each at the layer boundary kept the matrix pipe idle for that long)
+        const unsigned char *__restrict__ refill_src = P.weights + (size_t)(l < 5 ? kBlkD1 + (l + 1) * 32 : kBlkD7) * 1024;
+        unsigned char *refill_dst = s_w[l & 1];
         // (a software-pipelined variant -- fragments of k-step ks+1 read while the MFMAs of ks run -- needs 32 more VGPRs,
         // i.e. 3 waves per SIMD instead of 4, and measured 20 % slower: latency is hidden by occupancy here)
         // look-ahead: the LDS reads of fragments i+1 .. i+LA are in flight while MFMA i issues
@@ -321,6 +331,7 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
             const int ks = i >> 2, mt = i & 3;
             const half8 a = ring[i % LA];
             if (i + LA < 32) ring[i % LA] = lds_frag(cur, ((i + LA) & 3) * 8 + ((i + LA) >> 2), lane);
+            if ((i & 7) == 1 && (i >> 3) < kStageBytes / 1024 / kWaves) stage_piece(refill_src, refill_dst, i >> 3, wave, lane);
             if (ks == 0) {
                 f32x16 z;
                 #pragma unroll
