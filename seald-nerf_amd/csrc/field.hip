@@ -181,7 +181,9 @@ __device__ __forceinline__ void stage_load(const unsigned char *__restrict__ g, 
 // One 1-KiB piece of a stage: piece k of this wave (pieces are dealt to the waves round-robin, as stage_load does).
 __device__ __forceinline__ void stage_piece(const unsigned char *__restrict__ g, unsigned char *lds, int k, uint32_t wave, uint32_t lane) {
     const uint32_t off = __builtin_amdgcn_readfirstlane((wave + (uint32_t)k * kWaves) * 1024u);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off + lane * 16),
+    // (uniform 64-bit base in SGPRs + one 32-bit lane offset: the saddr form of the load, no 64-bit VGPR address per piece)
+    const __attribute__((address_space(1))) unsigned char *base = (const __attribute__((address_space(1))) unsigned char *)(g + off);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (lane << 4)),
                                      (__attribute__((address_space(3))) void *)(lds + off), 16, 0, 0);
 }
 
@@ -209,7 +211,12 @@ __device__ __forceinline__ half8 lds_frag(const unsigned char *buf, int blk, uin
 template <int OCC, int LA, bool CELLS, bool PAD>
 __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, TiledLevels lv) {
     constexpr int kGridBatch = OCC >= 4 ? 4 : 8;   // grid levels (per lane-half) whose gathers are in flight together (register budget)
-    __shared__ __attribute__((aligned(16))) unsigned char s_w[2][kStageBytes];
+    // Two SEPARATE LDS arrays, and a hidden-layer loop unrolled so that every access names its array at compile time: the compiler
+    // treats a direct-to-LDS load as a store to LDS and puts `s_waitcnt vmcnt(0)` in front of every later LDS read it cannot prove
+    // disjoint -- with one array indexed by `l & 1` that was every layer's first fragment read, i.e. each layer waited for the
+    // NEXT layer's 32 KiB to land before it issued its first MFMA (found in the ISA; ~600 cycles per layer).
+    __shared__ __attribute__((aligned(16))) unsigned char s_w0[kStageBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char s_w1[kStageBytes];
     __shared__ uint4 s_lv[16][2];   // per grid level: {offset, s1, s2, hsize}, {mask, scale, -, -}
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (threadIdx.x < 16) {         // visible to everyone after the first stage barrier below
@@ -226,8 +233,8 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     const uint32_t p = P.live_idx ? P.live_idx[ii] : ii;
 
     // stage 0 (D0, 16 KiB) -> buf 0 and stage 1 (D1) -> buf 1 start now and land under the feature computation
-    stage_load(P.weights + (size_t)kBlkD0 * 1024, s_w[0], 16 * 1024, wave, lane);
-    stage_load(P.weights + (size_t)kBlkD1 * 1024, s_w[1], kStageBytes, wave, lane);
+    stage_load(P.weights + (size_t)kBlkD0 * 1024, s_w0, 16 * 1024, wave, lane);
+    stage_load(P.weights + (size_t)kBlkD1 * 1024, s_w1, kStageBytes, wave, lane);
 
     float x0, x1, x2, d0 = 0, d1 = 0, d2 = 0;
     if constexpr (CELLS) {
@@ -307,19 +314,18 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
         #pragma unroll
-        for (int mt = 0; mt < 4; mt++) acc[mt] = mfma(lds_frag(s_w[0], mt * 4 + ks, lane), bf[ks], acc[mt]);
+        for (int mt = 0; mt < 4; mt++) acc[mt] = mfma(lds_frag(s_w0, mt * 4 + ks, lane), bf[ks], acc[mt]);
     }
     // ---------------- deform layers 1..6 (128 -> 128, ReLU): stage l+1 uses buffer (l+1)&1 ----------------
-    for (int l = 0; l < 6; l++) {
-        const unsigned char *cur = s_w[(l + 1) & 1];
+    // One hidden layer: fragments from `cur`, refill of `other` (static arrays: see the comment at their declaration).
+    auto hidden_layer = [&](int l, const unsigned char *cur, unsigned char *other) __attribute__((always_inline)) {
         #pragma unroll
         for (int t = 0; t < 4; t++) acc_to_frags<true>(acc[t], bf[2 * t], bf[2 * t + 1]);
         stage_wait_and_sync();  // stage l+1 landed for everyone; everyone is done reading the other buffer (layer l)
         // refill the other buffer with stage l+2 (D(l+2) for l < 5, the tail stage for l == 5); it lands under this layer's MFMAs
         // (its four 1-KiB pieces per wave are issued between this layer's MFMAs, not in front of them: a direct-to-LDS load costs
-        // 60-180 cycles of issue, and eight waves issuing four each at the layer boundary kept the matrix pipe idle for that long)
+        // 60-180 cycles of issue)
         const unsigned char *__restrict__ refill_src = P.weights + (size_t)(l < 5 ? kBlkD1 + (l + 1) * 32 : kBlkD7) * 1024;
-        unsigned char *refill_dst = s_w[l & 1];
         // (a software-pipelined variant -- fragments of k-step ks+1 read while the MFMAs of ks run -- needs 32 more VGPRs,
         // i.e. 3 waves per SIMD instead of 4, and measured 20 % slower: latency is hidden by occupancy here)
         // look-ahead: the LDS reads of fragments i+1 .. i+LA are in flight while MFMA i issues
@@ -331,7 +337,7 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
             const int ks = i >> 2, mt = i & 3;
             const half8 a = ring[i % LA];
             if (i + LA < 32) ring[i % LA] = lds_frag(cur, ((i + LA) & 3) * 8 + ((i + LA) >> 2), lane);
-            if ((i & 7) == 1 && (i >> 3) < kStageBytes / 1024 / kWaves) stage_piece(refill_src, refill_dst, i >> 3, wave, lane);
+            if ((i & 7) == 1 && (i >> 3) < kStageBytes / 1024 / kWaves) stage_piece(refill_src, other, i >> 3, wave, lane);
             if (ks == 0) {
                 f32x16 z;
                 #pragma unroll
@@ -350,11 +356,16 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, LA, 0);
+    };
+    #pragma unroll 1
+    for (int lp = 0; lp < 3; lp++) {      // layers 2 lp (reads s_w1, refills s_w0) and 2 lp + 1 (the other way round)
+        hidden_layer(2 * lp, s_w1, s_w0);
+        hidden_layer(2 * lp + 1, s_w0, s_w1);
     }
     #pragma unroll
     for (int t = 0; t < 4; t++) acc_to_frags<true>(acc[t], bf[2 * t], bf[2 * t + 1]);
     stage_wait_and_sync();  // tail stage (D7 | S0 | S1 | C0 | C1 | C2) resident in buffer 1
-    const unsigned char *tail = s_w[1];
+    const unsigned char *tail = s_w1;
     constexpr int tD7 = 0, tS0 = kBlkS0 - kBlkD7, tS1 = kBlkS1 - kBlkD7, tC0 = kBlkC0 - kBlkD7, tC1 = kBlkC1 - kBlkD7, tC2 = kBlkC2 - kBlkD7;
 
     // ---------------- deform layer 7 (128 -> 3) ----------------
@@ -625,8 +636,9 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
         if (small) hipLaunchKernelGGL((k_field_f16<2, 8, false, true>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
         else hipLaunchKernelGGL((k_field_f16<4, 2, false, true>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
     } else {
-        if (small) hipLaunchKernelGGL((k_field_f16<2, 8, false, false>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
-        else hipLaunchKernelGGL((k_field_f16<4, 2, false, false>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+        // reference-layout table (the public entry point with a caller's own table): one variant only -- with the wrap bookkeeping
+        // the throughput variant does not fit 128 VGPRs without spilling; the padded layout is the product path
+        hipLaunchKernelGGL((k_field_f16<2, 8, false, false>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
     }
     return sdn_launch_status();
 }
