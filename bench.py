@@ -64,6 +64,8 @@ def parse():
                          "reference's nn.Linear stack under autocast")
     ap.add_argument("--train-graph", type=int, default=1, help="--mode train with --train-mlp ffmlp: replay the step as one captured HIP "
                                                                 "graph (dnerf_amd/train_graph.py); 0 = launch it from Python")
+    ap.add_argument("--train-native", type=int, default=1, help="--mode train: the step as ONE native call (sdn_train_step_f16, "
+                                                                 "dnerf_amd/train_native.py); 0 = the autograd step (graphed or eager)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-side", type=int, default=96, help="side of the CPU-baseline sample image")
     return ap.parse_args()
@@ -89,7 +91,8 @@ def train_mode(args):
     idx = torch.randint(0, sc.rays_o.shape[0], (n_rays,), generator=g).to(dev)
     rays_o, rays_d = sc.rays_o[idx][None].contiguous(), sc.rays_d[idx][None].contiguous()
     target = torch.rand(1, n_rays, 3, generator=torch.Generator(device="cpu").manual_seed(2)).to(dev)
-    graphed = bool(args.train_graph) and type(model).__name__ == "NeRFNetworkFF"
+    native = bool(args.train_native) and not args.fp32
+    graphed = bool(args.train_graph) and type(model).__name__ == "NeRFNetworkFF" and not native
     # the graph needs the optimizer that takes GradScaler's found_inf on the device (fused + capturable Adam)
     groups = model.get_params(1e-2, 1e-3)
     if graphed:
@@ -112,6 +115,11 @@ def train_mode(args):
     for _ in range(2):  # first steps: unknown point budget (M = N * max_steps buffers, host read-back), as in the reference
         step()
     model.mean_count = int(model.step_counter[:2, 0].sum().item() / 2)  # what update_extra_state does (dnerf/renderer.py:550-552)
+    if native:
+        from dnerf_amd.train_native import NativeTrainStep
+        nstep = NativeTrainStep(model, opt, scaler, n_rays, dev, perturb=True, bg_color=1)
+        nstep.load(rays_o, rays_d, target, sc.time)
+        step = nstep  # noqa: F811  (inputs stay in the step's buffers, as with the graph)
     if graphed:
         from dnerf_amd.train_graph import GraphedTrainStep
         gstep = GraphedTrainStep(model, opt, scaler, n_rays, dev)
@@ -140,8 +148,10 @@ def train_mode(args):
                       "ms_per_step": dt / args.steps * 1e3, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "dtype": "f32" if args.fp32 else "f16",
                       "data": "synthetic", "config": {"workload": "BASELINE config 3", "rays": n_rays, "sampled_points_per_step": n_points,
                                                       "mean_count": model.mean_count,
-                                                      "mlps": "deform + colour MLPs on the fused-MLP operator (ffmlp), density MLP hipBLASLt" if type(model).__name__ == "NeRFNetworkFF" else "nn.Linear stack (hipBLASLt GEMMs)",
-                                                      "launch": "one captured HIP graph per step (fused capturable Adam)" if graphed else "eager (Python launches)"},
+                                                      "mlps": ("deform + colour MLPs on the fused-MLP kernels, density MLP in a per-sample dot2 kernel" if native else
+                                                               "deform + colour MLPs on the fused-MLP operator (ffmlp), density MLP hipBLASLt" if type(model).__name__ == "NeRFNetworkFF" else "nn.Linear stack (hipBLASLt GEMMs)"),
+                                                      "launch": ("one native call per step (sdn_train_step_f16: ~35 launches, Adam + fp16 copies + gradient clear in one pass)" if native
+                                                                 else "one captured HIP graph per step (fused capturable Adam)" if graphed else "eager (Python launches)")},
                       "kernel_times": summ}))
 
 

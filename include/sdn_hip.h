@@ -399,6 +399,88 @@ int sdn_host_mailbox_free(void *mailbox);
 /* image_out [N,3] = image + (1 - weights_sum) * bg; depth_out [N] = clamp(depth - nears, 0) / (fars - nears). */
 int sdn_render_finish(const SdnRenderCtx *ctx, float bg_color, float *image_out, float *depth_out, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * native training step of the dynamic field  ("next" row of the hot path: the caller that trains what the render path evaluates)
+ * reference: dnerf/utils.py:38-125 `train_step` (MSE criterion, main_dnerf.py:103) -> dnerf/renderer.py:260-331 `run_cuda`,
+ * training branch (near_far_from_aabb, march_rays_train, network forward, composite_rays_train, background mix) ->
+ * dnerf/network.py:123-169 under `-O` (fp16 autocast; nerf/utils.py:880-893 GradScaler) -> torch.optim.Adam(betas (0.9, 0.99),
+ * eps 1e-15) as main_dnerf.py:118 builds it -> optionally torch_ema's shadow update (nerf/utils.py:906).
+ * ONE call = one optimizer step in ~35 launches: nothing goes back to the host, no autograd graph, no per-step allocation.
+ * The arithmetic is the reference's op sequence with its dtypes (fp16 operands / fp32 accumulation in the MLPs, one fp16
+ * rounding per layer; fp16 table and table gradient; fp32 encoders, compositing, loss and Adam); results agree with the
+ * op-by-op path within fp16 accumulation-order tolerance (tests/test_gpu_train_native.py), not bit for bit.
+ * ------------------------------------------------------------------------- */
+#define SDN_TRAIN_N_PARAMS 14   /* encoder.embeddings, deform_net.0..7, sigma_net.0..1, color_net.0..2 (dnerf/network.py:260-275) */
+
+typedef struct SdnTrainParam {
+    float *param;                 /* fp32 master, the parameter's own storage, [n] */
+    float *exp_avg, *exp_avg_sq;  /* Adam moments, [n] */
+    float *ema;                   /* torch_ema shadow [n], or NULL */
+    uint64_t n;
+} SdnTrainParam;
+
+typedef struct SdnTrainStep {
+    /* batch (device memory) */
+    const float *rays_o, *rays_d;   /* [N,3] */
+    const float *target;            /* [N,3] ground-truth colours, already mixed with the background (utils.py:76-79) */
+    const float *bg_color;          /* [N,3] per-ray background (utils.py:74), or NULL: bg_value on every channel */
+    float bg_value;
+    uint32_t N, M;                  /* rays; sample budget = mean_count rounded as raymarching.py:200-203 */
+    /* scene */
+    const uint8_t *bitfield;        /* occupancy slice of `time` (dnerf/renderer.py:285) */
+    const float *aabb;              /* device, [6] (aabb_train) */
+    float bound, min_near, dt_gamma, density_scale, T_thresh;
+    float time;                     /* frame time by value; time == 0 is the canonical frame: no deformation, and the
+                                     * deformation MLP is left out of the optimizer step (its gradient is None in the reference,
+                                     * dnerf/network.py:140) */
+    uint32_t cascade, grid_size, max_steps;
+    int32_t perturb;                /* 1: per-ray start offsets from a counter-based generator (the reference draws torch.rand) */
+    uint64_t noise_seed;
+    const float *noises;            /* optional [N]: per-ray offsets in [0,1) to use instead of the generator (replays a torch.rand draw) */
+    int32_t *counter;               /* [2] (samples, rays) of this step: the step-counter slot of dnerf/renderer.py:296-298 */
+    /* grid encoder geometry (gridencoder/grid.py:96-141) */
+    int32_t grid_offsets[17];
+    float grid_S;
+    uint32_t grid_H;
+    /* parameters, in the order of SDN_TRAIN_N_PARAMS */
+    SdnTrainParam params[SDN_TRAIN_N_PARAMS];
+    /* optimizer */
+    double lr_table, lr_net;        /* network.py:260-275: encoder tables at lr, MLPs at lr_net (doubles: torch derives the step
+                                     * size and 1 - beta on the host in double precision) */
+    double beta1, beta2, eps;
+    float *adam_steps;              /* device [2]: optimizer steps taken by {everything but the deformation MLP, the deformation MLP} */
+    float *loss_scale;              /* device [1]: GradScaler's scale */
+    int32_t *growth_tracker;        /* device [1] */
+    float growth_factor, backoff_factor;
+    uint32_t growth_interval;
+    float ema_decay;                /* this step's effective decay (min(decay, (1 + n) / (10 + n))), for parameters with `ema` */
+    /* results */
+    float *loss_out;                /* device [1]: the unscaled loss of this step */
+    float *image_out;               /* optional [N,3]: predicted colours */
+    void *workspace;                /* sdn_train_layout().total_bytes, 256-byte aligned; persistent (holds the fp16 copies of the
+                                     * parameters that the kernels read): call sdn_train_refresh once before the first step and
+                                     * after every outside change of the parameters */
+    int32_t mode;                   /* 0: full step; 1: forward + backward only (gradients stay in the workspace) */
+    int32_t reserved_;
+} SdnTrainStep;
+
+/* Byte offsets into the workspace of what a caller or a test may want to look at.  fp16 "flat" networks are laid out as the fused
+ * MLP operator wants them (ffmlp.cu:631): [hidden, in16] ++ (L-1) x [hidden, hidden] ++ [16, hidden], zero padding included. */
+typedef struct SdnTrainLayout {
+    uint64_t total_bytes;
+    uint64_t w_table, w_deform, w_sigma0, w_sigma1, w_color;   /* fp16 copies of the parameters */
+    uint64_t g_table, g_deform, g_sigma0, g_sigma1, g_color;   /* fp16 gradients (scaled by the loss scale), same layouts */
+    uint64_t xyzs, dirs, deltas, rays;                         /* march_rays_train outputs: [M,3] [M,3] [M,2] f32, [N,3] i32 */
+    uint64_t sigmas, rgbs;                                     /* [M] f32 (density_scale applied), [M,3] f32 */
+    uint64_t weights_sum, depth, image;                        /* [N] [N] [N,3] f32, before the background mix */
+    uint64_t found_inf;                                        /* f32 [1] */
+} SdnTrainLayout;
+
+int sdn_train_layout(uint32_t N, uint32_t M, uint32_t max_steps, const int32_t *grid_offsets, SdnTrainLayout *out);
+/* fp16 copies of all parameters from the fp32 masters; clears the gradient accumulator of the table. */
+int sdn_train_refresh(const SdnTrainStep *s, void *stream);
+int sdn_train_step_f16(const SdnTrainStep *s, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,7 @@
 //   * weight gradients: split-K MFMA kernel, batch rows staged row-major in LDS and read column-wise with the gfx950
 //     transposing LDS read (ds_read_b64_tr_b16), fp32 partials per split + a deterministic reduction (no atomics).
 #include "ffmlp_kernels.h"
+#include "sdn_internal.h"
 
 namespace sdn_ff {
 // instantiated in ffmlp_act.hip: every activation other than ReLU (run-time dispatch inside the kernels)
@@ -62,11 +63,7 @@ __device__ __forceinline__ LayerDesc layer_desc(const PackArgs &P, uint32_t i) {
     return d;
 }
 
-__global__ void k_ffmlp_pack(PackArgs P, uint32_t total_frags) {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t frag = gid >> 6;
-    const uint32_t lane = gid & 63u;
-    if (frag >= total_frags) return;
+__device__ __forceinline__ void pack_frag(const PackArgs &P, uint32_t frag, uint32_t lane) {
     const uint32_t dst = frag;
     const uint32_t nlayers = P.L + ((P.backward && !P.with_last) ? 0u : 1u);
     LayerDesc d{};
@@ -85,6 +82,23 @@ __global__ void k_ffmlp_pack(PackArgs P, uint32_t total_frags) {
         v[j] = m < d.M ? P.w[d.off + (size_t)m * d.sm + (size_t)kk * d.sk] : (_Float16)0;
     }
     *reinterpret_cast<half8 *>(P.packed + (size_t)dst * 1024 + lane * 16) = v;
+}
+
+__global__ void k_ffmlp_pack(PackArgs P, uint32_t total_frags) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((gid >> 6) >= total_frags) return;
+    pack_frag(P, gid >> 6, gid & 63u);
+}
+
+// several networks / directions in one launch (blockIdx.y = job): the training step re-packs both directions of its MLPs once per step
+constexpr int kMaxPackJobs = 8;
+struct PackMany { PackArgs a[kMaxPackJobs]; uint32_t nf[kMaxPackJobs]; };
+
+__global__ void k_ffmlp_pack_many(PackMany Q) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t job = blockIdx.y;
+    if ((gid >> 6) >= Q.nf[job]) return;
+    pack_frag(Q.a[job], gid >> 6, gid & 63u);
 }
 
 uint32_t total_frags_host(uint32_t in_dim, uint32_t W, uint32_t L, int backward, int with_last) {
@@ -296,6 +310,79 @@ int forward_common(const void *inputs, const void *weights, uint32_t B, uint32_t
 
 }  // namespace
 
+namespace sdn_ffh {
+
+uint32_t total_frags(uint32_t in_dim, uint32_t W, uint32_t L, int backward, int with_last) { return total_frags_host(in_dim, W, L, backward, with_last); }
+
+int pack_many(const PackJob *jobs, uint32_t n, hipStream_t st) {
+    if (n == 0) return 0;
+    if (n > (uint32_t)kMaxPackJobs) return SDN_E_UNSUPPORTED;
+    PackMany q;
+    uint32_t max_nf = 1;
+    for (uint32_t i = 0; i < (uint32_t)kMaxPackJobs; i++) {
+        const PackJob &j = jobs[i < n ? i : 0];
+        q.a[i] = PackArgs{(const _Float16 *)j.weights, (unsigned char *)j.packed, j.in_dim, j.W, j.L, j.backward, j.with_last};
+        q.nf[i] = i < n ? total_frags_host(j.in_dim, j.W, j.L, j.backward, j.with_last) : 0;
+        if (q.nf[i] > max_nf) max_nf = q.nf[i];
+    }
+    hipLaunchKernelGGL(k_ffmlp_pack_many, dim3(sdn_div_up(max_nf * 64u, 256u), n), dim3(256), 0, st, q);
+    return sdn_launch_status();
+}
+
+int forward_packed(const void *inputs, const void *packed, uint32_t B, uint32_t in_dim, uint32_t W, uint32_t L, uint32_t act,
+                   void *forward_buffer, void *outputs, hipStream_t st) {
+    if (B == 0) return 0;
+    if (!dims_ok(in_dim, 16, W, L) || act > ACT_NONE) return SDN_E_UNSUPPORTED;
+    FfArgs a{(const _Float16 *)inputs, (const unsigned char *)packed, (_Float16 *)forward_buffer, nullptr, (_Float16 *)outputs, B, in_dim, 16, L, act,
+             total_frags_host(in_dim, W, L, 0, 1)};
+    return forward_buffer ? launch_fused<1>(W, a, st) : launch_fused<0>(W, a, st);
+}
+
+int backward_packed(const void *grad, const void *packed, const void *forward_buffer, uint32_t B, uint32_t in_dim, uint32_t W, uint32_t L,
+                    uint32_t act, int want_dx, void *backward_buffer, void *grad_inputs, hipStream_t st) {
+    if (B == 0) return 0;
+    if (!dims_ok(in_dim, 16, W, L) || act > ACT_NONE || act == ACT_SINE) return SDN_E_UNSUPPORTED;
+    FfArgs a{(const _Float16 *)grad, (const unsigned char *)packed, (_Float16 *)backward_buffer, (const _Float16 *)forward_buffer,
+             want_dx ? (_Float16 *)grad_inputs : nullptr, B, 16, in_dim, L, act, total_frags_host(in_dim, W, L, 1, want_dx ? 1 : 0)};
+    return launch_fused<2>(W, a, st);
+}
+
+uint64_t dw_jobs_bytes(const DwJob *jobs, uint32_t n, uint32_t B) {
+    uint64_t t = 0;
+    for (uint32_t i = 0; i < n; i++) t += dw_partial_bytes(B, jobs[i].M, jobs[i].N);
+    return t;
+}
+
+// every job's split-K partial sums in ONE launch (blockIdx.z = job) + one deterministic reduction launch
+int dw_jobs(const DwJob *jobs, uint32_t n, uint32_t B, void *partial, hipStream_t st) {
+    if (n == 0 || B == 0) return 0;
+    if (n > (uint32_t)kMaxDw) return SDN_E_UNSUPPORTED;
+    DwBatch bt;
+    uint32_t max_ns = 1, max_blocks = 1, max_red = 1;
+    float *next = (float *)partial;
+    for (uint32_t i = 0; i < n; i++) {
+        const DwJob &j = jobs[i];
+        DwArgs d;
+        d.G = (const _Float16 *)j.G; d.X = (const _Float16 *)j.X; d.partial = next; d.B = B; d.ldg = j.ldg; d.ldx = j.ldx; d.M = j.M; d.N = j.N;
+        d.Mpad = (j.M + 31) / 32 * 32; d.Npad = (j.N + 31) / 32 * 32;
+        const uint32_t blocks = dw_blocks(j.M, j.N);
+        const uint32_t ns = dw_splits(B, blocks);
+        d.rows_per_split = sdn_div_up(sdn_div_up(B, ns), (uint32_t)kDwRows) * kDwRows;
+        const uint32_t ns_used = sdn_div_up(B, d.rows_per_split);
+        bt.a[i] = d; bt.out[i] = (_Float16 *)j.out; bt.nsplit[i] = ns_used; bt.blocks[i] = blocks;
+        next += dw_partial_bytes(B, j.M, j.N) / sizeof(float);
+        if (ns_used > max_ns) max_ns = ns_used;
+        if (blocks > max_blocks) max_blocks = blocks;
+        if (sdn_div_up(j.M * j.N, 64u) > max_red) max_red = sdn_div_up(j.M * j.N, 64u);
+    }
+    for (uint32_t k = n; k < (uint32_t)kMaxDw; k++) { bt.a[k] = bt.a[0]; bt.out[k] = nullptr; bt.nsplit[k] = 0; bt.blocks[k] = 0; }
+    hipLaunchKernelGGL(k_ffmlp_dw_batched, dim3(max_ns, max_blocks, n), dim3(256), 0, st, bt);
+    hipLaunchKernelGGL(k_ffmlp_dw_reduce_batched, dim3(max_red, n), dim3(256), 0, st, bt);
+    return sdn_launch_status();
+}
+
+}  // namespace sdn_ffh
+
 extern "C" {
 
 uint64_t sdn_ffmlp_scratch_bytes(uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers) {
@@ -343,52 +430,29 @@ int sdn_ffmlp_backward(const void *grad, const void *inputs, const void *weights
     rc = launch_fused<2>(W, a, st);
     if (rc) return rc;
 
-    // 2. weight gradients, layer by layer (split-K over the batch, deterministic two-pass reduction)
+    // 2. weight gradients (split-K over the batch, deterministic two-pass reduction): every layer in one launch when the partial
+    //    sums fit, else layer by layer through one region
     const uint64_t fw = total_frags_host(in, W, L, 0, 1), bw = total_frags_host(in, W, L, 1, 1);
     float *partial = (float *)((unsigned char *)scratch + (fw > bw ? fw : bw) * 1024);
     const _Float16 *fwd = (const _Float16 *)forward_buffer, *bwd = (const _Float16 *)backward_buffer;
     _Float16 *gw = (_Float16 *)grad_weights;
-    const bool batched = dw_batched(B, in, W, L);
-    DwBatch bt;
-    uint32_t n_bt = 0, max_ns = 1, max_blocks = 1, max_red = 1;
-    float *next_partial = partial;
-    auto dw = [&](const _Float16 *G, uint32_t ldg, uint32_t M, const _Float16 *X, uint32_t ldx, uint32_t N, _Float16 *out) -> int {
-        DwArgs d;
-        d.G = G; d.X = X; d.partial = next_partial; d.B = B; d.ldg = ldg; d.ldx = ldx; d.M = M; d.N = N;
-        d.Mpad = (M + 31) / 32 * 32; d.Npad = (N + 31) / 32 * 32;
-        const uint32_t blocks = dw_blocks(M, N);
-        const uint32_t ns = dw_splits(B, blocks);
-        d.rows_per_split = sdn_div_up(sdn_div_up(B, ns), (uint32_t)kDwRows) * kDwRows;
-        const uint32_t ns_used = sdn_div_up(B, d.rows_per_split);
-        if (batched) {                        // collected; launched together below
-            bt.a[n_bt] = d; bt.out[n_bt] = out; bt.nsplit[n_bt] = ns_used; bt.blocks[n_bt] = blocks;
-            n_bt++;
-            next_partial += dw_partial_bytes(B, M, N) / sizeof(float);
-            if (ns_used > max_ns) max_ns = ns_used;
-            if (blocks > max_blocks) max_blocks = blocks;
-            if (sdn_div_up(M * N, 64u) > max_red) max_red = sdn_div_up(M * N, 64u);
-            return 0;
-        }
-        hipLaunchKernelGGL(k_ffmlp_dw, dim3(ns_used, blocks), dim3(256), 0, st, d);
-        hipLaunchKernelGGL(k_ffmlp_dw_reduce, dim3(sdn_div_up(M * N, 64u)), dim3(256), 0, st, d.partial, ns_used, M, N, d.Mpad, d.Npad, out);
-        return sdn_launch_status();
-    };
     const size_t BW = (size_t)B * W;
+    sdn_ffh::DwJob jobs[kMaxDw];
+    uint32_t n = 0;
+    if (L + 1 > (uint32_t)kMaxDw) return SDN_E_UNSUPPORTED;
     // output layer: dW_out [16, W] = grad^T X_L                                   (ffmlp.cu:800-811)
-    rc = dw((const _Float16 *)grad, 16, 16, fwd + (L - 1) * BW, W, W, gw + (size_t)W * in + (size_t)(L - 1) * W * W);
-    if (rc) return rc;
+    jobs[n++] = {grad, 16, 16, fwd + (L - 1) * BW, W, W, gw + (size_t)W * in + (size_t)(L - 1) * W * W};
     // hidden layers: dW_j [W, W] = G_j^T X_j, G_j = backward_buffer[L - 1 - j]   (ffmlp.cu:845-863)
-    for (uint32_t j = L - 1; j >= 1; j--) {
-        rc = dw(bwd + (size_t)(L - 1 - j) * BW, W, W, fwd + (size_t)(j - 1) * BW, W, W, gw + (size_t)W * in + (size_t)(j - 1) * W * W);
+    for (uint32_t j = L - 1; j >= 1; j--)
+        jobs[n++] = {bwd + (size_t)(L - 1 - j) * BW, W, W, fwd + (size_t)(j - 1) * BW, W, W, gw + (size_t)W * in + (size_t)(j - 1) * W * W};
+    // input layer: dW_0 [W, in] = G_0^T inputs                                    (ffmlp.cu:866-876)
+    jobs[n++] = {bwd + (size_t)(L - 1) * BW, W, W, inputs, in, in, gw};
+    if (dw_batched(B, in, W, L)) return sdn_ffh::dw_jobs(jobs, n, B, partial, st);
+    for (uint32_t k = 0; k < n; k++) {
+        rc = sdn_ffh::dw_jobs(jobs + k, 1, B, partial, st);
         if (rc) return rc;
     }
-    // input layer: dW_0 [W, in] = G_0^T inputs                                    (ffmlp.cu:866-876)
-    rc = dw(bwd + (size_t)(L - 1) * BW, W, W, (const _Float16 *)inputs, in, in, gw);
-    if (rc || !batched) return rc;
-    for (uint32_t k = n_bt; k < (uint32_t)kMaxDw; k++) { bt.a[k] = bt.a[0]; bt.out[k] = nullptr; bt.nsplit[k] = 0; bt.blocks[k] = 0; }
-    hipLaunchKernelGGL(k_ffmlp_dw_batched, dim3(max_ns, max_blocks, n_bt), dim3(256), 0, st, bt);
-    hipLaunchKernelGGL(k_ffmlp_dw_reduce_batched, dim3(max_red, n_bt), dim3(256), 0, st, bt);
-    return sdn_launch_status();
+    return 0;
 }
 
 }  // extern "C"

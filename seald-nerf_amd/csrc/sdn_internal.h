@@ -50,3 +50,19 @@ int field_cells_f16(const int32_t *cells, const uint32_t *cell_count, uint32_t n
                     uint32_t H, float bound, float density_scale, int zero_deform, float *tmp_slice, hipStream_t st);
 
 }  // namespace sdn_int
+
+// Host-side pieces of the fused-MLP operator (ffmlp.hip) that the native training step (train.hip) composes itself: packing of
+// several networks in one launch, the fused forward / backward chains on already packed fragments, and any set of weight-gradient
+// products  out[M,N] = G[B,ldg]^T X[B,ldx]  (fp16 operands, fp32 split-K partial sums) in one launch + one reduction.
+namespace sdn_ffh {
+struct PackJob { const void *weights; void *packed; uint32_t in_dim, W, L; int backward, with_last; };
+struct DwJob { const void *G; uint32_t ldg, M; const void *X; uint32_t ldx, N; void *out; };
+uint32_t total_frags(uint32_t in_dim, uint32_t W, uint32_t L, int backward, int with_last);
+int pack_many(const PackJob *jobs, uint32_t n, hipStream_t st);
+int forward_packed(const void *inputs, const void *packed, uint32_t B, uint32_t in_dim, uint32_t W, uint32_t L, uint32_t act,
+                   void *forward_buffer, void *outputs, hipStream_t st);
+int backward_packed(const void *grad, const void *packed, const void *forward_buffer, uint32_t B, uint32_t in_dim, uint32_t W, uint32_t L,
+                    uint32_t act, int want_dx, void *backward_buffer, void *grad_inputs, hipStream_t st);
+uint64_t dw_jobs_bytes(const DwJob *jobs, uint32_t n, uint32_t B);
+int dw_jobs(const DwJob *jobs, uint32_t n, uint32_t B, void *partial, hipStream_t st);
+}  // namespace sdn_ffh

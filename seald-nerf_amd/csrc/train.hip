@@ -1,0 +1,679 @@
+// Native training step of the dynamic field for gfx950 (MI355X): one C call = one optimizer step.
+//
+// Behavioural contract (what the step computes, in the reference's own order and dtypes):
+//   dnerf/utils.py:38-125       train_step: render the ray batch, MSE against the ground truth (main_dnerf.py:103), mean
+//   dnerf/renderer.py:260-331   run_cuda, training branch: near_far_from_aabb -> march_rays_train(perturb, mean_count budget) ->
+//                               network -> density_scale -> composite_rays_train -> image + (1 - weights_sum) * bg
+//   dnerf/network.py:123-169    freq(x,10) ++ freq(t,6) -> deformation MLP (8 x 128) -> x + deform (0 at t == 0) -> tiled grid ->
+//                               sigma MLP (64) -> trunc_exp | SH(d,4) ++ geo -> colour MLP (64,64) -> sigmoid, all bias-free
+//                               Linear layers under fp16 autocast (fp16 operands, fp32 accumulation, fp16 result per layer)
+//   nerf/utils.py:880-906       GradScaler.scale(loss).backward(); scaler.step(optimizer); scaler.update(); ema.update()
+//   main_dnerf.py:118           Adam(betas (0.9, 0.99), eps 1e-15) over network.py:260-275's groups (tables at lr, MLPs at lr_net)
+//
+// Why a native step: at 4096 rays / ~9000 samples the op-by-op step is ~160 launches of a few microseconds each (autograd glue:
+// casts, fills, cats, the per-call weight packing, a 48 -> 24 MB table cast per step, three optimizer passes) -- launch-bound even
+// when replayed as one HIP graph.  Here the step is ~35 launches: the existing operators' kernels (marching, fused MLP chains,
+// grid encoder, compositing) composed directly, the glue between them fused into a handful of small kernels, every layer's
+// weight gradient in one split-K launch, and ONE optimizer pass that also rewrites the fp16 copies the next step reads and clears
+// the table's gradient accumulator.  Nothing is read back to the host.
+//
+// Everything below the MLP chains is per-sample streaming work (a few hundred bytes per sample): those kernels are launch- and
+// latency-bound at this batch size, not bandwidth-bound; the optimizer pass over the 12 M-entry table is the one HBM-bound piece
+// (30 B per entry: p, m, v read + written fp32, fp16 gradient read + cleared, fp16 copy written).
+#include <math.h>
+#include <stddef.h>
+
+#include "sdn_common.h"
+#include "sdn_internal.h"
+#include "sh_eval.h"
+
+namespace {
+
+using namespace sdn_sh;
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// ---- the network's fixed geometry (dnerf/network.py:10-96 defaults; the mirror is dnerf_amd/network.py) ------------------------------
+constexpr uint32_t kDefIn = 80, kDefCols = 76, kDefW = 128, kDefL = 7;   // 63 + 13 frequency features (padded to 80) -> 7 hidden layers -> 3
+constexpr uint32_t kSigIn = 32, kSigW = 64, kSigOut = 16;               // 16 levels x 2 -> 64 -> 1 + 15
+constexpr uint32_t kColIn = 32, kColCols = 31, kColW = 64, kColL = 2;    // SH 16 ++ geo 15 (padded to 32) -> 64 -> 64 -> 3
+constexpr uint32_t kDefFlat = kDefW * kDefIn + (kDefL - 1) * kDefW * kDefW + 16 * kDefW;
+constexpr uint32_t kColFlat = kColW * kColIn + (kColL - 1) * kColW * kColW + 16 * kColW;
+constexpr uint32_t kLevels = 16;
+constexpr uint32_t ACT_RELU = 0;
+
+struct Hyper {          // written by the optimizer prologue, read by the update kernel
+    float inv_scale;
+    float step_size[2][2];   // [table | net][everything else | deformation MLP]
+    float bc2_sqrt[2];
+    float found_inf;
+    int32_t skip;
+    int32_t pad_[7];
+};
+
+struct Layout {
+    uint64_t total;
+    uint64_t w_table, w_deform, w_sigma0, w_sigma1, w_color, g_table, hyper;                 // persistent
+    uint64_t pk_def_f, pk_def_b, pk_col_f, pk_col_b;
+    uint64_t nears, fars, noises, rays, pts, gflat, march;
+    uint64_t enc_in, def_hidden, def_out, xdef, grid_out, dy_dx, enc_rm, h1, hout, sigmas, col_in, col_hidden, col_out, rgbs;
+    uint64_t weights_sum, depth, image, grad_image, grad_ws;
+    uint64_t dcol_out, dh0, col_bwd, dcol_in, dh, dh1, denc, dx16, ddef, def_bwd;
+    uint64_t g_deform, g_sigma0, g_sigma1, g_color, dw_partial;
+};
+
+void dw_job_list(const Layout &L, unsigned char *ws, uint32_t M, sdn_ffh::DwJob *jobs, uint32_t &n);
+
+Layout make_layout(uint32_t N, uint32_t M, uint32_t max_steps, uint64_t table_entries) {
+    Layout L{};
+    uint64_t at = 0;
+    auto take = [&](uint64_t bytes) { const uint64_t o = at; at = (at + bytes + 255u) & ~(uint64_t)255u; return o; };
+    const uint64_t m = M, n = N;
+    L.w_table = take(table_entries * 2);  L.w_deform = take(kDefFlat * 2);  L.w_sigma0 = take(kSigW * kSigIn * 2);
+    L.w_sigma1 = take(kSigOut * kSigW * 2);  L.w_color = take(kColFlat * 2);  L.g_table = take(table_entries * 2);
+    L.hyper = take(sizeof(Hyper));
+    L.pk_def_f = take((uint64_t)sdn_ffh::total_frags(kDefIn, kDefW, kDefL, 0, 1) * 1024);
+    L.pk_def_b = take((uint64_t)sdn_ffh::total_frags(kDefIn, kDefW, kDefL, 1, 0) * 1024);
+    L.pk_col_f = take((uint64_t)sdn_ffh::total_frags(kColIn, kColW, kColL, 0, 1) * 1024);
+    L.pk_col_b = take((uint64_t)sdn_ffh::total_frags(kColIn, kColW, kColL, 1, 1) * 1024);
+    L.nears = take(n * 4);  L.fars = take(n * 4);  L.noises = take(n * 4);  L.rays = take(n * 12);
+    L.pts = take(m * 32);                       // xyzs [M,3] | dirs [M,3] | deltas [M,2], zero-filled every step ...
+    L.gflat = take(m * 16);                     // ... together with grad_sigmas [M] | grad_rgbs [M,3] (must follow `pts`)
+    L.march = take(sdn_march_rays_train_scratch_bytes(N, max_steps));
+    L.enc_in = take(m * kDefIn * 2);  L.def_hidden = take(m * kDefL * kDefW * 2);  L.def_out = take(m * 32);
+    L.xdef = take(m * 12);  L.grid_out = take(m * kLevels * 4);  L.dy_dx = take(m * kLevels * 12);
+    L.enc_rm = take(m * kSigIn * 2);  L.h1 = take(m * kSigW * 2);  L.hout = take(m * kSigOut * 2);  L.sigmas = take(m * 4);
+    L.col_in = take(m * kColIn * 2);  L.col_hidden = take(m * kColL * kColW * 2);  L.col_out = take(m * 32);  L.rgbs = take(m * 12);
+    L.weights_sum = take(n * 4);  L.depth = take(n * 4);  L.image = take(n * 12);  L.grad_image = take(n * 12);  L.grad_ws = take(n * 4);
+    L.dcol_out = take(m * 32);  L.dh0 = take(m * 2);  L.col_bwd = take(m * kColL * kColW * 2);  L.dcol_in = take(m * kColIn * 2);
+    L.dh = take(m * kSigOut * 2);  L.dh1 = take(m * kSigW * 2);  L.denc = take(m * kLevels * 4);  L.dx16 = take(m * 6);
+    L.ddef = take(m * 32);  L.def_bwd = take(m * kDefL * kDefW * 2);
+    L.g_deform = take(kDefFlat * 2);  L.g_sigma0 = take(kSigW * kSigIn * 2);  L.g_sigma1 = take(kSigOut * kSigW * 2);  L.g_color = take(kColFlat * 2);
+    sdn_ffh::DwJob jobs[16];
+    uint32_t nj = 0;
+    dw_job_list(L, nullptr, M, jobs, nj);
+    L.dw_partial = take(sdn_ffh::dw_jobs_bytes(jobs, nj, M));
+    L.total = at;
+    return L;
+}
+
+// all 13 weight-gradient products of the step: deformation MLP (8), colour MLP (3), sigma MLP (2)
+void dw_job_list(const Layout &L, unsigned char *ws, uint32_t M, sdn_ffh::DwJob *jobs, uint32_t &n) {
+    auto H = [&](uint64_t off) { return (const _Float16 *)(ws + off); };
+    auto G = [&](uint64_t off) { return (_Float16 *)(ws + off); };
+    n = 0;
+    const size_t mw = (size_t)M * kDefW, mc = (size_t)M * kColW;
+    // deformation MLP (layout of the flat gradient: [128, 80] ++ 6 x [128, 128] ++ [16, 128]; ffmlp.cu:800-876 for the pairing)
+    jobs[n++] = {H(L.ddef), 16, 16, H(L.def_hidden) + (kDefL - 1) * mw, kDefW, kDefW, G(L.g_deform) + kDefW * kDefIn + (kDefL - 1) * kDefW * kDefW};
+    for (uint32_t j = kDefL - 1; j >= 1; j--)
+        jobs[n++] = {H(L.def_bwd) + (kDefL - 1 - j) * mw, kDefW, kDefW, H(L.def_hidden) + (j - 1) * mw, kDefW, kDefW,
+                     G(L.g_deform) + kDefW * kDefIn + (j - 1) * kDefW * kDefW};
+    jobs[n++] = {H(L.def_bwd) + (kDefL - 1) * mw, kDefW, kDefW, H(L.enc_in), kDefIn, kDefIn, G(L.g_deform)};
+    // colour MLP ([64, 32] ++ [64, 64] ++ [16, 64])
+    jobs[n++] = {H(L.dcol_out), 16, 16, H(L.col_hidden) + (kColL - 1) * mc, kColW, kColW, G(L.g_color) + kColW * kColIn + (kColL - 1) * kColW * kColW};
+    for (uint32_t j = kColL - 1; j >= 1; j--)
+        jobs[n++] = {H(L.col_bwd) + (kColL - 1 - j) * mc, kColW, kColW, H(L.col_hidden) + (j - 1) * mc, kColW, kColW,
+                     G(L.g_color) + kColW * kColIn + (j - 1) * kColW * kColW};
+    jobs[n++] = {H(L.col_bwd) + (kColL - 1) * mc, kColW, kColW, H(L.col_in), kColIn, kColIn, G(L.g_color)};
+    // sigma MLP: dW2 [16, 64] = dh^T h1, dW1 [64, 32] = dh1^T enc
+    jobs[n++] = {H(L.dh), kSigOut, kSigOut, H(L.h1), kSigW, kSigW, G(L.g_sigma1)};
+    jobs[n++] = {H(L.dh1), kSigW, kSigW, H(L.enc_rm), kSigIn, kSigIn, G(L.g_sigma0)};
+}
+
+// ---- small kernels --------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float u01(uint64_t seed, uint32_t i) {   // splitmix64 -> 24 random bits -> [0, 1), like torch.rand's float grid
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1u);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__global__ void __launch_bounds__(256) k_train_rays(float *__restrict__ noises, const float *__restrict__ given, uint32_t N, uint64_t seed, int perturb,
+                                                    int32_t *counter, Hyper *hyper) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { counter[0] = 0; counter[1] = 0; hyper->found_inf = 0.0f; }    // renderer.py:296-298 counter.zero_()
+    if (i < N) noises[i] = perturb ? (given ? given[i] : u01(seed, i)) : 0.0f;
+}
+
+// freq(x, 10) ++ freq(t, 6) as the fp16 input rows of the deformation MLP (freqencoder.cu:30-58's formula; the autocast cast of
+// F.linear's input).  One thread per (sample, 16th of a row).
+__global__ void __launch_bounds__(256) k_train_encode(const float *__restrict__ xyzs, uint32_t M, float time, _Float16 *__restrict__ enc) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = t >> 4, j = t & 15u;
+    if (b >= M) return;
+    _Float16 *row = enc + (size_t)b * kDefIn;
+    const float half_pi = 3.141592653589793f / 2;
+    if (j < 10) {
+        #pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const float a = scalbnf(xyzs[(size_t)b * 3 + d], (int)j);
+            row[3 + 6 * j + d] = (_Float16)sinf(a + 0.0f);
+            row[6 + 6 * j + d] = (_Float16)sinf(a + half_pi);
+        }
+    } else if (j == 10) {
+        #pragma unroll
+        for (int d = 0; d < 3; d++) row[d] = (_Float16)xyzs[(size_t)b * 3 + d];
+    } else if (j == 11) {
+        row[63] = (_Float16)time;
+        #pragma unroll
+        for (int f = 0; f < 6; f++) {
+            const float a = scalbnf(time, f);
+            row[64 + 2 * f] = (_Float16)sinf(a + 0.0f);
+            row[65 + 2 * f] = (_Float16)sinf(a + half_pi);
+        }
+    } else if (j == 12) {
+        row[76] = 0; row[77] = 0; row[78] = 0; row[79] = 0;
+    }
+}
+
+// x + deform (network.py:140-145, deform = 0 on the canonical frame), normalised as GridEncoder.forward does (grid.py:146)
+__global__ void __launch_bounds__(256) k_train_xdef(const float *__restrict__ xyzs, const _Float16 *__restrict__ def_out, uint32_t M, int zero_deform,
+                                                    float bound, float *__restrict__ xdef) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * 3) return;
+    const uint32_t b = t / 3, d = t - b * 3;
+    const float v = xyzs[t] + (zero_deform ? 0.0f : (float)def_out[(size_t)b * 16 + d]);
+    xdef[t] = (v + bound) / (2 * bound);
+}
+
+__device__ __forceinline__ float dot2(h2 a, h2 b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
+
+// sigma MLP forward (32 -> 64 -> 16, ReLU), trunc_exp (activation.py:5-17) x density_scale, SH(d, 4), and the colour MLP's input
+// row [SH | geo | 0].  One lane per sample: the two weight matrices (6 KiB) sit in LDS and every lane reads the same address
+// (broadcast); fp16 products accumulate in fp32 (v_dot2_f32_f16) and round to fp16 once per layer, as the GEMMs of the Linear
+// layers do.  3 072 MACs per sample -- not worth a matrix-core kernel at 9 000 samples.
+struct SigmaFwd {
+    const _Float16 *grid_out;   // [16][M][2]
+    const _Float16 *w1, *w2;    // [64,32], [16,64]
+    const float *dirs;          // [M,3]
+    _Float16 *enc_rm, *h1, *hout, *col_in;
+    float *sigmas;
+    uint32_t M;
+    float density_scale;
+};
+
+__global__ void __launch_bounds__(64) k_train_sigma_fwd(SigmaFwd P) {
+    __shared__ h2 s_w1[kSigW][kSigIn / 2];
+    __shared__ h2 s_w2[kSigOut][kSigW / 2];
+    for (uint32_t i = threadIdx.x; i < kSigW * kSigIn / 2; i += 64) (&s_w1[0][0])[i] = reinterpret_cast<const h2 *>(P.w1)[i];
+    for (uint32_t i = threadIdx.x; i < kSigOut * kSigW / 2; i += 64) (&s_w2[0][0])[i] = reinterpret_cast<const h2 *>(P.w2)[i];
+    __syncthreads();
+    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= P.M) return;
+    h2 x[kSigIn / 2];
+    #pragma unroll
+    for (uint32_t l = 0; l < kLevels; l++) x[l] = reinterpret_cast<const h2 *>(P.grid_out)[(size_t)l * P.M + b];
+    h8 *erow = reinterpret_cast<h8 *>(P.enc_rm + (size_t)b * kSigIn);
+    #pragma unroll
+    for (int q = 0; q < 4; q++) erow[q] = h8{x[4 * q][0], x[4 * q][1], x[4 * q + 1][0], x[4 * q + 1][1], x[4 * q + 2][0], x[4 * q + 2][1], x[4 * q + 3][0], x[4 * q + 3][1]};
+    h2 hid[kSigW / 2];
+    #pragma unroll
+    for (uint32_t j = 0; j < kSigW; j++) {
+        float acc = 0.0f;
+        #pragma unroll
+        for (uint32_t k = 0; k < kSigIn / 2; k++) acc = dot2(s_w1[j][k], x[k], acc);
+        _Float16 v = (_Float16)acc;
+        v = v > (_Float16)0 ? v : (_Float16)0;
+        hid[j >> 1][j & 1] = v;
+    }
+    h8 *hrow = reinterpret_cast<h8 *>(P.h1 + (size_t)b * kSigW);
+    #pragma unroll
+    for (int q = 0; q < 8; q++) hrow[q] = h8{hid[4 * q][0], hid[4 * q][1], hid[4 * q + 1][0], hid[4 * q + 1][1], hid[4 * q + 2][0], hid[4 * q + 2][1], hid[4 * q + 3][0], hid[4 * q + 3][1]};
+    _Float16 o[kSigOut];
+    #pragma unroll
+    for (uint32_t r = 0; r < kSigOut; r++) {
+        float acc = 0.0f;
+        #pragma unroll
+        for (uint32_t k = 0; k < kSigW / 2; k++) acc = dot2(s_w2[r][k], hid[k], acc);
+        o[r] = (_Float16)acc;
+    }
+    h8 *orow = reinterpret_cast<h8 *>(P.hout + (size_t)b * kSigOut);
+    orow[0] = h8{o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]};
+    orow[1] = h8{o[8], o[9], o[10], o[11], o[12], o[13], o[14], o[15]};
+    P.sigmas[b] = P.density_scale * expf((float)o[0]);
+    float sh[16], u0[1], u1[1], u2[1];
+    sh_eval<4, false>(P.dirs[(size_t)b * 3], P.dirs[(size_t)b * 3 + 1], P.dirs[(size_t)b * 3 + 2], sh, u0, u1, u2);
+    h8 *crow = reinterpret_cast<h8 *>(P.col_in + (size_t)b * kColIn);
+    crow[0] = h8{(_Float16)sh[0], (_Float16)sh[1], (_Float16)sh[2], (_Float16)sh[3], (_Float16)sh[4], (_Float16)sh[5], (_Float16)sh[6], (_Float16)sh[7]};
+    crow[1] = h8{(_Float16)sh[8], (_Float16)sh[9], (_Float16)sh[10], (_Float16)sh[11], (_Float16)sh[12], (_Float16)sh[13], (_Float16)sh[14], (_Float16)sh[15]};
+    crow[2] = h8{o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8]};
+    crow[3] = h8{o[9], o[10], o[11], o[12], o[13], o[14], o[15], (_Float16)0};
+}
+
+__device__ __forceinline__ _Float16 sigmoid16(_Float16 c) { return (_Float16)(1.0f / (1.0f + expf(-(float)c))); }
+
+// rgb = sigmoid(colour MLP output) in fp16 (network.py:166), widened for composite_rays_train (cast_inputs float32)
+__global__ void __launch_bounds__(256) k_train_rgb(const _Float16 *__restrict__ col_out, uint32_t M, float *__restrict__ rgbs) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * 3) return;
+    const uint32_t b = t / 3, c = t - b * 3;
+    rgbs[t] = (float)sigmoid16(col_out[(size_t)b * 16 + c]);
+}
+
+// pred = image + (1 - weights_sum) * bg (renderer.py:318); loss = mean over rays of the mean over channels of (pred - gt)^2
+// (utils.py:85, :125); gradients of scale * loss with respect to image and weights_sum.  ONE workgroup: the loss is a
+// deterministic tree sum, 4096 rays are 4 per thread.
+__global__ void __launch_bounds__(1024) k_train_loss(const float *__restrict__ image, const float *__restrict__ ws, const float *__restrict__ bg,
+                                                     float bg_value, const float *__restrict__ gt, uint32_t N, const float *__restrict__ loss_scale,
+                                                     float *__restrict__ loss_out, float *__restrict__ grad_image, float *__restrict__ grad_ws,
+                                                     float *__restrict__ image_out) {
+    __shared__ float s_part[16];
+    const float c = (*loss_scale / (float)N) / 3.0f;
+    float acc = 0.0f;
+    for (uint32_t r = threadIdx.x; r < N; r += 1024) {
+        const float one_minus = 1.0f - ws[r];
+        float sq = 0.0f, gws = 0.0f;
+        #pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const float b = bg ? bg[(size_t)r * 3 + ch] : bg_value;
+            const float pred = image[(size_t)r * 3 + ch] + one_minus * b;
+            const float d = pred - gt[(size_t)r * 3 + ch];
+            const float g = (d * 2.0f) * c;
+            grad_image[(size_t)r * 3 + ch] = g;
+            gws -= g * b;
+            sq += d * d;
+            if (image_out) image_out[(size_t)r * 3 + ch] = pred;
+        }
+        grad_ws[r] = gws;
+        acc += sq / 3.0f;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63u) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int w = 0; w < 16; w++) t += s_part[w];
+        *loss_out = t / (float)N;
+    }
+}
+
+// backward of: composite's float32 cast (-> fp16), sigmoid (fp16, torch's a * (1 - y) * y in float), density_scale, trunc_exp
+// (g * exp(clamp(x, -15, 15)), then the cast back to fp16 of its float32 input)
+__global__ void __launch_bounds__(256) k_train_colour_grad(const float *__restrict__ gflat, const _Float16 *__restrict__ col_out,
+                                                           const _Float16 *__restrict__ hout, uint32_t M, float density_scale,
+                                                           _Float16 *__restrict__ dcol_out, _Float16 *__restrict__ dh0) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= M) return;
+    const float *g_sigma = gflat, *g_rgb = gflat + M;
+    _Float16 d[3];
+    #pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const _Float16 g16 = (_Float16)g_rgb[(size_t)b * 3 + c];
+        const float y = (float)sigmoid16(col_out[(size_t)b * 16 + c]);
+        d[c] = (_Float16)(((float)g16 * (1.0f - y)) * y);
+    }
+    h8 *row = reinterpret_cast<h8 *>(dcol_out + (size_t)b * 16);
+    row[0] = h8{d[0], d[1], d[2], 0, 0, 0, 0, 0};
+    row[1] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+    const float x = fminf(fmaxf((float)hout[(size_t)b * kSigOut], -15.0f), 15.0f);
+    dh0[b] = (_Float16)((g_sigma[b] * density_scale) * expf(x));
+}
+
+// sigma MLP backward: dh = [trunc_exp gradient | colour MLP's gradient of geo], dh1 = (dh W2) * relu', denc = dh1 W1 in the grid
+// encoder's [level][sample][2] layout; dh and dh1 also row-major for the weight-gradient products.
+struct SigmaBwd {
+    const _Float16 *dh0, *dcol_in, *h1, *w1, *w2;
+    _Float16 *dh, *dh1, *denc;
+    uint32_t M;
+};
+
+__global__ void __launch_bounds__(64) k_train_sigma_bwd(SigmaBwd P) {
+    __shared__ h2 s_w2t[kSigW][kSigOut / 2];     // [j][o/2] = (W2[o][j], W2[o+1][j])
+    __shared__ h2 s_w1t[kSigIn][kSigW / 2];      // [k][j/2] = (W1[j][k], W1[j+1][k])
+    for (uint32_t i = threadIdx.x; i < kSigW * kSigOut / 2; i += 64) {
+        const uint32_t j = i / (kSigOut / 2), o = 2 * (i % (kSigOut / 2));
+        s_w2t[j][o >> 1] = h2{P.w2[o * kSigW + j], P.w2[(o + 1) * kSigW + j]};
+    }
+    for (uint32_t i = threadIdx.x; i < kSigIn * kSigW / 2; i += 64) {
+        const uint32_t k = i / (kSigW / 2), j = 2 * (i % (kSigW / 2));
+        s_w1t[k][j >> 1] = h2{P.w1[j * kSigIn + k], P.w1[(j + 1) * kSigIn + k]};
+    }
+    __syncthreads();
+    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= P.M) return;
+    const h8 *ci = reinterpret_cast<const h8 *>(P.dcol_in + (size_t)b * kColIn);
+    const h8 g0 = ci[2], g1 = ci[3];             // columns 16..31 of the colour MLP's input gradient: geo 0..14, pad
+    const _Float16 d0 = P.dh0[b];
+    const h8 da = h8{d0, g0[0], g0[1], g0[2], g0[3], g0[4], g0[5], g0[6]}, db = h8{g0[7], g1[0], g1[1], g1[2], g1[3], g1[4], g1[5], g1[6]};
+    h8 *dhrow = reinterpret_cast<h8 *>(P.dh + (size_t)b * kSigOut);
+    dhrow[0] = da; dhrow[1] = db;
+    const h2 dh[8] = {h2{da[0], da[1]}, h2{da[2], da[3]}, h2{da[4], da[5]}, h2{da[6], da[7]}, h2{db[0], db[1]}, h2{db[2], db[3]}, h2{db[4], db[5]}, h2{db[6], db[7]}};
+    const h8 *hrow = reinterpret_cast<const h8 *>(P.h1 + (size_t)b * kSigW);
+    h2 d1[kSigW / 2];
+    #pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const h8 hv = hrow[q];
+        #pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t j = 8 * q + e;
+            float acc = 0.0f;
+            #pragma unroll
+            for (uint32_t o = 0; o < kSigOut / 2; o++) acc = dot2(s_w2t[j][o], dh[o], acc);
+            d1[j >> 1][j & 1] = hv[e] > (_Float16)0 ? (_Float16)acc : (_Float16)0;
+        }
+    }
+    h8 *d1row = reinterpret_cast<h8 *>(P.dh1 + (size_t)b * kSigW);
+    #pragma unroll
+    for (int q = 0; q < 8; q++) d1row[q] = h8{d1[4 * q][0], d1[4 * q][1], d1[4 * q + 1][0], d1[4 * q + 1][1], d1[4 * q + 2][0], d1[4 * q + 2][1], d1[4 * q + 3][0], d1[4 * q + 3][1]};
+    #pragma unroll
+    for (uint32_t l = 0; l < kLevels; l++) {
+        float a0 = 0.0f, a1 = 0.0f;
+        #pragma unroll
+        for (uint32_t j = 0; j < kSigW / 2; j++) { a0 = dot2(s_w1t[2 * l][j], d1[j], a0); a1 = dot2(s_w1t[2 * l + 1][j], d1[j], a1); }
+        reinterpret_cast<h2 *>(P.denc)[(size_t)l * P.M + b] = h2{(_Float16)a0, (_Float16)a1};
+    }
+}
+
+// gradient of the deformation MLP's output: grid input gradient (fp16 -> float), / (2 bound) of the normalisation, the fp16 cast of
+// `deform.to(x.dtype)`; zero columns 3..15 of the operator's 16-wide output
+__global__ void __launch_bounds__(256) k_train_deform_grad(const _Float16 *__restrict__ dx16, uint32_t M, float bound, _Float16 *__restrict__ ddef) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= M) return;
+    _Float16 d[3];
+    #pragma unroll
+    for (int c = 0; c < 3; c++) d[c] = (_Float16)((float)dx16[(size_t)b * 3 + c] / (2 * bound));
+    h8 *row = reinterpret_cast<h8 *>(ddef + (size_t)b * 16);
+    row[0] = h8{d[0], d[1], d[2], 0, 0, 0, 0, 0};
+    row[1] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+}
+
+// ---- optimizer ------------------------------------------------------------------------------------------------------------------
+struct CheckArgs { const _Float16 *g[5]; uint32_t n8[5]; uint32_t count; Hyper *hyper; };
+
+// GradScaler's non-finite check over every gradient of the step (amp's _amp_foreach_non_finite_check_and_unscale_)
+__global__ void __launch_bounds__(256) k_train_check(CheckArgs A) {
+    bool bad = false;
+    for (uint32_t s = 0; s < A.count; s++) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(A.g[s]);
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < A.n8[s]; i += gridDim.x * blockDim.x) {
+            const uint4 v = p[i];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            #pragma unroll
+            for (int k = 0; k < 4; k++) bad |= ((w[k] & 0x7C00u) == 0x7C00u) | ((w[k] & 0x7C000000u) == 0x7C000000u);
+        }
+    }
+    if (bad) A.hyper->found_inf = 1.0f;
+}
+
+struct Prologue {
+    Hyper *hyper;
+    float *steps, *scale;
+    int32_t *tracker;
+    double beta1, beta2, lr_table, lr_net;
+    float growth, backoff;
+    uint32_t interval;
+    int deform_active;
+};
+
+// One thread: the skip decision, bias corrections in double as torch's Adam computes them on the host (adam.py _single_tensor_adam:
+// 1 - beta ** step, lr / bias_correction1, bias_correction2 ** 0.5), and amp_update_scale (AmpKernels.cu) for the NEXT step.
+__global__ void k_train_prologue(Prologue P) {
+    Hyper *h = P.hyper;
+    const bool found = h->found_inf != 0.0f;
+    const float scale = *P.scale;
+    h->skip = found ? 1 : 0;
+    h->inv_scale = (float)(1.0 / (double)scale);
+    if (!found) {
+        P.steps[0] += 1.0f;
+        if (P.deform_active) P.steps[1] += 1.0f;
+    }
+    for (int g = 0; g < 2; g++) {
+        const double st = (double)P.steps[g] > 0 ? (double)P.steps[g] : 1.0;
+        const double bc1 = 1.0 - pow(P.beta1, st), bc2 = 1.0 - pow(P.beta2, st);
+        h->step_size[0][g] = (float)(P.lr_table / bc1);
+        h->step_size[1][g] = (float)(P.lr_net / bc1);
+        h->bc2_sqrt[g] = (float)sqrt(bc2);
+    }
+    if (found) {
+        *P.scale = scale * P.backoff;
+        *P.tracker = 0;
+    } else {
+        const int32_t ok = *P.tracker + 1;
+        if (ok == (int32_t)P.interval) {
+            const float grown = scale * P.growth;
+            if (isfinite(grown)) *P.scale = grown;
+            *P.tracker = 0;
+        } else {
+            *P.tracker = ok;
+        }
+    }
+}
+
+struct AdamSeg {
+    float *p, *m, *v, *ema;
+    _Float16 *g;        // fp16 gradient, element (r, c) at r * ld + c
+    _Float16 *w16;      // fp16 copy, same layout
+    uint32_t n, cols, ld;
+    uint32_t lr_idx, group, zero_grad, frozen, blk_begin;
+};
+struct AdamArgs {
+    AdamSeg seg[SDN_TRAIN_N_PARAMS];
+    uint32_t nseg;
+    const Hyper *hyper;
+    float one_minus_b1, b2, one_minus_b2, eps, ema_keep;   // ema_keep = 1 - decay
+};
+
+// torch.optim.Adam, single-tensor form (adam.py:_single_tensor_adam; amsgrad / weight_decay / maximize off), on gradients unscaled
+// the way GradScaler.unscale_ does (float(grad) * inv_scale):   m.lerp_(g, 1 - b1);  v.mul_(b2).addcmul_(g, g, 1 - b2);
+// denom = sqrt(v) / bias_correction2_sqrt + eps;  p.addcdiv_(m, denom, -step_size).   The same pass writes the fp16 copy the next
+// step's kernels read (the autocast casts of the reference), clears the table's gradient accumulator, and applies torch_ema's
+// shadow -= (1 - decay) * (shadow - p).  A step with a non-finite gradient changes nothing but the accumulator and the shadows.
+__global__ void __launch_bounds__(256) k_train_adam(AdamArgs A) {
+    uint32_t s = 0;
+    for (uint32_t k = 1; k < A.nseg; k++) s = blockIdx.x >= A.seg[k].blk_begin ? k : s;
+    const AdamSeg &S = A.seg[s];
+    const Hyper &H = *A.hyper;
+    const bool update = !H.skip && !S.frozen;
+    const float inv_scale = H.inv_scale, step_size = H.step_size[S.lr_idx][S.group], bc2s = H.bc2_sqrt[S.group];
+    const uint32_t base = (blockIdx.x - S.blk_begin) * 1024u + threadIdx.x;
+    #pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t i = base + 256u * k;
+        if (i >= S.n) break;
+        uint32_t j = i;
+        if (S.cols != S.ld) { const uint32_t r = i / S.cols; j = r * S.ld + (i - r * S.cols); }
+        float p = S.p[i];
+        if (update) {
+            const float g = (float)S.g[j] * inv_scale;
+            float m = S.m[i], v = S.v[i];
+            m = m + A.one_minus_b1 * (g - m);
+            v = v * A.b2 + (A.one_minus_b2 * g) * g;
+            const float denom = sqrtf(v) / bc2s + A.eps;
+            p = p - step_size * (m / denom);
+            S.m[i] = m; S.v[i] = v; S.p[i] = p;
+            S.w16[j] = (_Float16)p;
+        }
+        if (S.zero_grad) S.g[j] = (_Float16)0;
+        if (S.ema) { const float e = S.ema[i]; S.ema[i] = e - (e - p) * A.ema_keep; }
+    }
+}
+
+// fp16 copies from the fp32 masters (sdn_train_refresh)
+__global__ void __launch_bounds__(256) k_train_copy16(AdamArgs A) {
+    uint32_t s = 0;
+    for (uint32_t k = 1; k < A.nseg; k++) s = blockIdx.x >= A.seg[k].blk_begin ? k : s;
+    const AdamSeg &S = A.seg[s];
+    const uint32_t base = (blockIdx.x - S.blk_begin) * 1024u + threadIdx.x;
+    #pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t i = base + 256u * k;
+        if (i >= S.n) break;
+        uint32_t j = i;
+        if (S.cols != S.ld) { const uint32_t r = i / S.cols; j = r * S.ld + (i - r * S.cols); }
+        S.w16[j] = (_Float16)S.p[i];
+    }
+}
+
+// parameter i of SDN_TRAIN_N_PARAMS -> its place in the fp16 copies / gradients
+uint32_t build_segments(const SdnTrainStep *s, const Layout &L, AdamArgs &A) {
+    unsigned char *ws = (unsigned char *)s->workspace;
+    auto H = [&](uint64_t off) { return (_Float16 *)(ws + off); };
+    struct Place { uint64_t w, g; uint32_t off, rows, cols, ld, lr, group; };
+    Place pl[SDN_TRAIN_N_PARAMS];
+    const uint32_t table_n = (uint32_t)s->grid_offsets[kLevels] * 2u;
+    pl[0] = {L.w_table, L.g_table, 0, table_n / 2, 2, 2, 0, 0};
+    pl[1] = {L.w_deform, L.g_deform, 0, kDefW, kDefCols, kDefIn, 1, 1};
+    for (uint32_t i = 1; i < kDefL; i++) pl[1 + i] = {L.w_deform, L.g_deform, kDefW * kDefIn + (i - 1) * kDefW * kDefW, kDefW, kDefW, kDefW, 1, 1};
+    pl[8] = {L.w_deform, L.g_deform, kDefW * kDefIn + (kDefL - 1) * kDefW * kDefW, 3, kDefW, kDefW, 1, 1};
+    pl[9] = {L.w_sigma0, L.g_sigma0, 0, kSigW, kSigIn, kSigIn, 1, 0};
+    pl[10] = {L.w_sigma1, L.g_sigma1, 0, kSigOut, kSigW, kSigW, 1, 0};
+    pl[11] = {L.w_color, L.g_color, 0, kColW, kColCols, kColIn, 1, 0};
+    pl[12] = {L.w_color, L.g_color, kColW * kColIn, kColW, kColW, kColW, 1, 0};
+    pl[13] = {L.w_color, L.g_color, kColW * kColIn + kColW * kColW, 3, kColW, kColW, 1, 0};
+    uint32_t blk = 0;
+    for (int i = 0; i < SDN_TRAIN_N_PARAMS; i++) {
+        const SdnTrainParam &q = s->params[i];
+        AdamSeg &S = A.seg[i];
+        S.p = q.param; S.m = q.exp_avg; S.v = q.exp_avg_sq; S.ema = q.ema;
+        S.g = H(pl[i].g) + pl[i].off; S.w16 = H(pl[i].w) + pl[i].off;
+        S.n = pl[i].rows * pl[i].cols; S.cols = pl[i].cols; S.ld = pl[i].ld;
+        S.lr_idx = pl[i].lr; S.group = pl[i].group; S.zero_grad = i == 0; S.frozen = 0; S.blk_begin = blk;
+        blk += sdn_div_up(S.n, 1024u);
+    }
+    A.nseg = SDN_TRAIN_N_PARAMS;
+    return blk;
+}
+
+bool step_ok(const SdnTrainStep *s) {
+    if (!s || !s->workspace || ((uintptr_t)s->workspace & 255u)) return false;
+    if (!s->rays_o || !s->rays_d || !s->target || !s->bitfield || !s->aabb || !s->counter || !s->loss_out) return false;
+    if (s->N == 0 || s->M == 0 || s->max_steps == 0 || s->bound <= 0) return false;
+    for (int i = 0; i < SDN_TRAIN_N_PARAMS; i++) if (!s->params[i].param) return false;
+    if (s->mode == 0) {
+        if (!s->adam_steps || !s->loss_scale || !s->growth_tracker) return false;
+        for (int i = 0; i < SDN_TRAIN_N_PARAMS; i++) if (!s->params[i].exp_avg || !s->params[i].exp_avg_sq) return false;
+    } else if (!s->loss_scale) {
+        return false;
+    }
+    const uint64_t expect[SDN_TRAIN_N_PARAMS] = {(uint64_t)s->grid_offsets[kLevels] * 2, kDefW * kDefCols, kDefW * kDefW, kDefW * kDefW, kDefW * kDefW, kDefW * kDefW,
+                                                 kDefW * kDefW, kDefW * kDefW, 3 * kDefW, kSigW * kSigIn, kSigOut * kSigW, kColW * kColCols, kColW * kColW, 3 * kColW};
+    for (int i = 0; i < SDN_TRAIN_N_PARAMS; i++) if (s->params[i].n != expect[i]) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sdn_train_layout(uint32_t N, uint32_t M, uint32_t max_steps, const int32_t *grid_offsets, SdnTrainLayout *out) {
+    if (!grid_offsets || !out || N == 0 || M == 0 || max_steps == 0 || grid_offsets[kLevels] <= 0) return SDN_E_BADARG;
+    const Layout L = make_layout(N, M, max_steps, (uint64_t)grid_offsets[kLevels] * 2);
+    out->total_bytes = L.total;
+    out->w_table = L.w_table; out->w_deform = L.w_deform; out->w_sigma0 = L.w_sigma0; out->w_sigma1 = L.w_sigma1; out->w_color = L.w_color;
+    out->g_table = L.g_table; out->g_deform = L.g_deform; out->g_sigma0 = L.g_sigma0; out->g_sigma1 = L.g_sigma1; out->g_color = L.g_color;
+    out->xyzs = L.pts; out->dirs = L.pts + (uint64_t)M * 12; out->deltas = L.pts + (uint64_t)M * 24; out->rays = L.rays;
+    out->sigmas = L.sigmas; out->rgbs = L.rgbs; out->weights_sum = L.weights_sum; out->depth = L.depth; out->image = L.image;
+    out->found_inf = L.hyper + offsetof(Hyper, found_inf);
+    return 0;
+}
+
+int sdn_train_refresh(const SdnTrainStep *s, void *stream) {
+    if (!s || !s->workspace || ((uintptr_t)s->workspace & 255u)) return SDN_E_BADARG;
+    for (int i = 0; i < SDN_TRAIN_N_PARAMS; i++) if (!s->params[i].param) return SDN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const Layout L = make_layout(s->N, s->M, s->max_steps, (uint64_t)s->grid_offsets[kLevels] * 2);
+    unsigned char *ws = (unsigned char *)s->workspace;
+    // zero padding of the flat networks, and the table's gradient accumulator
+    if (hipMemsetAsync(ws + L.w_deform, 0, kDefFlat * 2, st) != hipSuccess || hipMemsetAsync(ws + L.w_color, 0, kColFlat * 2, st) != hipSuccess ||
+        hipMemsetAsync(ws + L.g_table, 0, (uint64_t)s->grid_offsets[kLevels] * 4, st) != hipSuccess || hipMemsetAsync(ws + L.hyper, 0, sizeof(Hyper), st) != hipSuccess)
+        return sdn_launch_status();
+    AdamArgs A{};
+    const uint32_t blocks = build_segments(s, L, A);
+    hipLaunchKernelGGL(k_train_copy16, dim3(blocks), dim3(256), 0, st, A);
+    return sdn_launch_status();
+}
+
+int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
+    if (!step_ok(s)) return SDN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t N = s->N, M = s->M;
+    const Layout L = make_layout(N, M, s->max_steps, (uint64_t)s->grid_offsets[kLevels] * 2);
+    unsigned char *ws = (unsigned char *)s->workspace;
+    auto F = [&](uint64_t off) { return (float *)(ws + off); };
+    auto H = [&](uint64_t off) { return (_Float16 *)(ws + off); };
+    Hyper *hyper = (Hyper *)(ws + L.hyper);
+    const int zero_deform = s->time == 0.0f;
+    int rc;
+    #define SDN_TRY(x) do { rc = (x); if (rc) return rc; } while (0)
+
+    // ---- rays -> samples (renderer.py:283-304) ------------------------------------------------------------------------------------
+    hipLaunchKernelGGL(k_train_rays, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, F(L.noises), s->noises, N, s->noise_seed, s->perturb, s->counter, hyper);
+    SDN_TRY(sdn_near_far_from_aabb(s->rays_o, s->rays_d, s->aabb, N, s->min_near, F(L.nears), F(L.fars), st));
+    if (hipMemsetAsync(ws + L.pts, 0, (L.gflat - L.pts) + (uint64_t)M * 16, st) != hipSuccess) return sdn_launch_status();
+    if (s->mode != 0 && hipMemsetAsync(ws + L.g_table, 0, (uint64_t)s->grid_offsets[kLevels] * 4, st) != hipSuccess) return sdn_launch_status();
+    float *xyzs = F(L.pts), *dirs = xyzs + (size_t)M * 3, *deltas = xyzs + (size_t)M * 6;
+    SDN_TRY(sdn_march_rays_train(s->rays_o, s->rays_d, s->bitfield, s->bound, s->dt_gamma, s->max_steps, N, s->cascade, s->grid_size, M, F(L.nears),
+                                 F(L.fars), xyzs, dirs, deltas, (int32_t *)(ws + L.rays), s->counter, F(L.noises), ws + L.march, st));
+
+    // ---- this step's packed weights (both directions of both fused MLPs, one launch) ------------------------------------------------
+    const sdn_ffh::PackJob packs[4] = {{ws + L.w_deform, ws + L.pk_def_f, kDefIn, kDefW, kDefL, 0, 1}, {ws + L.w_deform, ws + L.pk_def_b, kDefIn, kDefW, kDefL, 1, 0},
+                                       {ws + L.w_color, ws + L.pk_col_f, kColIn, kColW, kColL, 0, 1}, {ws + L.w_color, ws + L.pk_col_b, kColIn, kColW, kColL, 1, 1}};
+    SDN_TRY(sdn_ffh::pack_many(packs, 4, st));
+
+    // ---- forward (network.py:123-169) ---------------------------------------------------------------------------------------------
+    hipLaunchKernelGGL(k_train_encode, dim3(sdn_div_up(M * 16u, 256u)), dim3(256), 0, st, xyzs, M, s->time, H(L.enc_in));
+    SDN_TRY(sdn_ffh::forward_packed(H(L.enc_in), ws + L.pk_def_f, M, kDefIn, kDefW, kDefL, ACT_RELU, H(L.def_hidden), H(L.def_out), st));
+    hipLaunchKernelGGL(k_train_xdef, dim3(sdn_div_up(M * 3u, 256u)), dim3(256), 0, st, xyzs, H(L.def_out), M, zero_deform, s->bound, F(L.xdef));
+    SDN_TRY(sdn_grid_encode_forward(F(L.xdef), ws + L.w_table, s->grid_offsets, ws + L.grid_out, M, 3, 2, kLevels, s->grid_S, s->grid_H, ws + L.dy_dx, 1, 0, 0,
+                                    SDN_F16, st));
+    const SigmaFwd sf{H(L.grid_out), H(L.w_sigma0), H(L.w_sigma1), dirs, H(L.enc_rm), H(L.h1), H(L.hout), H(L.col_in), F(L.sigmas), M, s->density_scale};
+    hipLaunchKernelGGL(k_train_sigma_fwd, dim3(sdn_div_up(M, 64u)), dim3(64), 0, st, sf);
+    SDN_TRY(sdn_ffh::forward_packed(H(L.col_in), ws + L.pk_col_f, M, kColIn, kColW, kColL, ACT_RELU, H(L.col_hidden), H(L.col_out), st));
+    hipLaunchKernelGGL(k_train_rgb, dim3(sdn_div_up(M * 3u, 256u)), dim3(256), 0, st, H(L.col_out), M, F(L.rgbs));
+
+    // ---- compositing, loss, and their gradients (renderer.py:309-318, utils.py:85-125) -----------------------------------------------
+    SDN_TRY(sdn_composite_rays_train_forward(F(L.sigmas), F(L.rgbs), deltas, (const int32_t *)(ws + L.rays), M, N, s->T_thresh, F(L.weights_sum), F(L.depth),
+                                             F(L.image), st));
+    hipLaunchKernelGGL(k_train_loss, dim3(1), dim3(1024), 0, st, F(L.image), F(L.weights_sum), s->bg_color, s->bg_value, s->target, N, s->loss_scale, s->loss_out,
+                       F(L.grad_image), F(L.grad_ws), s->image_out);
+    float *g_sigmas = F(L.gflat), *g_rgbs = g_sigmas + M;
+    SDN_TRY(sdn_composite_rays_train_backward(F(L.grad_ws), F(L.grad_image), F(L.sigmas), F(L.rgbs), deltas, (const int32_t *)(ws + L.rays), F(L.weights_sum),
+                                              F(L.image), M, N, s->T_thresh, g_sigmas, g_rgbs, st));
+
+    // ---- backward through the field ---------------------------------------------------------------------------------------------------
+    hipLaunchKernelGGL(k_train_colour_grad, dim3(sdn_div_up(M, 256u)), dim3(256), 0, st, F(L.gflat), H(L.col_out), H(L.hout), M, s->density_scale, H(L.dcol_out),
+                       H(L.dh0));
+    SDN_TRY(sdn_ffh::backward_packed(H(L.dcol_out), ws + L.pk_col_b, H(L.col_hidden), M, kColIn, kColW, kColL, ACT_RELU, 1, H(L.col_bwd), H(L.dcol_in), st));
+    const SigmaBwd sb{H(L.dh0), H(L.dcol_in), H(L.h1), H(L.w_sigma0), H(L.w_sigma1), H(L.dh), H(L.dh1), H(L.denc), M};
+    hipLaunchKernelGGL(k_train_sigma_bwd, dim3(sdn_div_up(M, 64u)), dim3(64), 0, st, sb);
+    SDN_TRY(sdn_grid_encode_backward(ws + L.denc, F(L.xdef), s->grid_offsets, ws + L.g_table, M, 3, 2, kLevels, s->grid_S, s->grid_H, zero_deform ? nullptr : ws + L.dy_dx,
+                                     zero_deform ? nullptr : ws + L.dx16, 1, 0, 0, SDN_F16, st));
+    sdn_ffh::DwJob jobs[16];
+    uint32_t nj = 0;
+    dw_job_list(L, ws, M, jobs, nj);
+    if (!zero_deform) {
+        hipLaunchKernelGGL(k_train_deform_grad, dim3(sdn_div_up(M, 256u)), dim3(256), 0, st, H(L.dx16), M, s->bound, H(L.ddef));
+        SDN_TRY(sdn_ffh::backward_packed(H(L.ddef), ws + L.pk_def_b, H(L.def_hidden), M, kDefIn, kDefW, kDefL, ACT_RELU, 0, H(L.def_bwd), nullptr, st));
+        SDN_TRY(sdn_ffh::dw_jobs(jobs, nj, M, ws + L.dw_partial, st));
+    } else {
+        SDN_TRY(sdn_ffh::dw_jobs(jobs + (kDefL + 1), nj - (kDefL + 1), M, ws + L.dw_partial, st));   // canonical frame: the deformation MLP has no gradient
+    }
+    if (s->mode != 0) return sdn_launch_status();
+
+    // ---- optimizer (nerf/utils.py:889-906) --------------------------------------------------------------------------------------------
+    const uint32_t table_n = (uint32_t)s->grid_offsets[kLevels] * 2u;
+    CheckArgs ck{};
+    ck.hyper = hyper;
+    ck.g[0] = H(L.g_table); ck.n8[0] = table_n / 8;
+    ck.g[1] = H(L.g_sigma0); ck.n8[1] = kSigW * kSigIn / 8;
+    ck.g[2] = H(L.g_sigma1); ck.n8[2] = kSigOut * kSigW / 8;
+    ck.g[3] = H(L.g_color); ck.n8[3] = kColFlat / 8;
+    ck.count = 4;
+    if (!zero_deform) { ck.g[4] = H(L.g_deform); ck.n8[4] = kDefFlat / 8; ck.count = 5; }
+    hipLaunchKernelGGL(k_train_check, dim3(1024), dim3(256), 0, st, ck);
+    const Prologue pr{hyper, s->adam_steps, s->loss_scale, s->growth_tracker, s->beta1, s->beta2, s->lr_table, s->lr_net, s->growth_factor, s->backoff_factor,
+                      s->growth_interval, !zero_deform};
+    hipLaunchKernelGGL(k_train_prologue, dim3(1), dim3(1), 0, st, pr);
+    AdamArgs A{};
+    const uint32_t blocks = build_segments(s, L, A);
+    if (zero_deform) for (uint32_t i = 1; i <= kDefL + 1; i++) A.seg[i].frozen = 1;
+    A.hyper = hyper;
+    A.one_minus_b1 = (float)(1.0 - s->beta1); A.b2 = (float)s->beta2; A.one_minus_b2 = (float)(1.0 - s->beta2); A.eps = (float)s->eps;
+    A.ema_keep = 1.0f - s->ema_decay;
+    hipLaunchKernelGGL(k_train_adam, dim3(blocks), dim3(256), 0, st, A);
+    #undef SDN_TRY
+    return sdn_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,190 @@
+"""A dnerf training step as ONE native call (`sdn_train_step_f16`, csrc/train.hip): ~35 kernel launches, no autograd graph, no
+host read-back.
+
+What the step is (dnerf/utils.py:38-125 `train_step` with `-O` inside nerf/utils.py:849-930 `train_one_epoch`): render the ray batch
+through the occupancy-grid path (`march_rays_train`, field network under fp16 autocast, `composite_rays_train`), MSE against the
+ground truth, GradScaler-scaled backward, Adam, optionally the EMA shadow update.  `GraphedTrainStep` (train_graph.py) replays the
+op-by-op step -- ~160 launches of autograd glue -- as one HIP graph; this class calls the native composition of the same
+operators' kernels instead and is the faster of the two.  Both train the SAME objects: the model's own parameters, the
+torch.optim.Adam instance's own moment tensors and the GradScaler's own scale, so eager steps, graphed steps, native steps,
+`update_extra_state`, checkpoint save / load can be mixed freely (call `refresh()` after anything else changed the parameters).
+
+Requirements: the occupancy-grid path with a known sample budget (`model.mean_count > 0`, the reference's steady state after the
+first `update_extra_state`), the default network geometry of dnerf/network.py, no background model.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+import sdn_backend as _sdn
+
+_PARAM_NAMES = (["encoder.embeddings"] + [f"deform_net.{i}.weight" for i in range(8)] + [f"sigma_net.{i}.weight" for i in range(2)]
+                + [f"color_net.{i}.weight" for i in range(3)])
+
+
+def _budget(mean_count, align=128):
+    """raymarching.py:200-203, including the `+ align` of an already aligned count."""
+    return mean_count + (align - mean_count % align)
+
+
+class NativeTrainStep:
+    def __init__(self, model, optimizer, scaler, n_rays, device, ema_decay=None, perturb=True, bg_color=1, dt_gamma=0.0, max_steps=1024,
+                 T_thresh=1e-4, seed=0):
+        """optimizer: a torch.optim.Adam over `model.get_params(lr, lr_net)` (or merged groups); scaler: torch.amp.GradScaler.
+        ema_decay: None, or the decay of a torch_ema-style shadow kept in `self.ema_shadow` (nerf/utils.py:906)."""
+        if not getattr(model, "cuda_ray", False) or model.mean_count <= 0:
+            raise ValueError("NativeTrainStep needs the occupancy-grid path with a known point budget (model.mean_count > 0)")
+        if getattr(model, "bg_radius", 0) > 0:
+            raise NotImplementedError("NativeTrainStep: the background model is not part of the native step")
+        if not isinstance(optimizer, torch.optim.Adam) or any(g.get("weight_decay", 0) or g.get("amsgrad") or g.get("maximize") for g in optimizer.param_groups):
+            raise ValueError("NativeTrainStep implements torch.optim.Adam without weight decay / amsgrad / maximize (main_dnerf.py:118)")
+        _sdn.require_device()
+        self.model, self.opt, self.scaler, self.device = model, optimizer, scaler, torch.device(device)
+        self.n_rays, self.perturb, self.bg_color = int(n_rays), bool(perturb), bg_color
+        self.dt_gamma, self.max_steps, self.T_thresh, self.seed = float(dt_gamma), int(max_steps), float(T_thresh), int(seed)
+        named = dict(model.named_parameters())
+        self.params = [named[n] for n in _PARAM_NAMES]
+        enc = model.encoder
+        if (enc.num_levels, enc.level_dim, enc.input_dim, enc.gridtype_id, bool(enc.align_corners), enc.interp_id) != (16, 2, 3, 1, False, 0):
+            raise ValueError("NativeTrainStep: the native step is built for the dnerf network's tiled 16 x 2 grid (dnerf/network.py:55-60)")
+        shapes = [tuple(p.shape) for p in self.params[1:]]
+        if shapes != [(128, 76)] + [(128, 128)] * 6 + [(3, 128), (64, 32), (16, 64), (64, 31), (64, 64), (3, 64)]:
+            raise ValueError(f"NativeTrainStep: network geometry {shapes} is not the default of dnerf/network.py:10-96")
+        for p in self.params:
+            if p.dtype != torch.float32 or not p.is_contiguous() or p.device.type != "cuda":
+                raise ValueError("NativeTrainStep: parameters must be contiguous fp32 tensors on the GPU")
+        f32 = torch.float32
+        self.rays_o = torch.zeros(n_rays, 3, dtype=f32, device=device)
+        self.rays_d = torch.zeros(n_rays, 3, dtype=f32, device=device)
+        self.rays_d[:, 2] = 1
+        self.target = torch.zeros(n_rays, 3, dtype=f32, device=device)
+        self.bg = torch.zeros(n_rays, 3, dtype=f32, device=device)
+        self.image = torch.zeros(n_rays, 3, dtype=f32, device=device)
+        self.loss = torch.zeros(1, dtype=f32, device=device)
+        self.adam_steps = torch.zeros(2, dtype=f32, device=device)
+        self.time = 0.5
+        self._offsets = (ctypes.c_int32 * 17)(*[int(v) for v in enc.offsets.cpu().tolist()])
+        # Adam state: the optimizer's own tensors (created here if it has not stepped yet)
+        steps = []
+        for p in self.params:
+            st = optimizer.state[p]
+            if "exp_avg" not in st:
+                st["step"] = torch.zeros((), dtype=f32, device=p.device) if optimizer.defaults.get("capturable") else torch.tensor(0.0, dtype=f32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            steps.append(float(st["step"]))
+        self.adam_steps[0], self.adam_steps[1] = steps[0], steps[1]
+        if scaler.is_enabled() and scaler._scale is None:
+            scaler._lazy_init_scale_growth_tracker(self.device)
+        if not scaler.is_enabled():
+            raise ValueError("NativeTrainStep is the fp16 (`-O`) training step: it needs an enabled GradScaler")
+        self.ema_decay, self.ema_updates = ema_decay, 0
+        self.ema_shadow = [p.detach().clone() for p in self.params] if ema_decay is not None else None
+        self.step_count, self._M, self._ws, self._rec = 0, None, None, None
+        self.noises = None          # optional [n_rays] f32 device tensor: the per-ray offsets of the next steps (instead of the generator)
+        self._lr_of = {}
+        for g in optimizer.param_groups:
+            for p in g["params"]:
+                self._lr_of[id(p)] = g
+
+    # ---- workspace / argument record ----------------------------------------------------------------------------------------------
+    def _build(self):
+        m = self.model
+        M = _budget(int(m.mean_count))
+        lay = _sdn.SdnTrainLayout()
+        _sdn.check(_sdn.lib.sdn_train_layout(self.n_rays, M, self.max_steps, self._offsets, ctypes.byref(lay)), "train_layout")
+        self.layout = lay
+        self._ws = torch.empty(int(lay.total_bytes) + 256, dtype=torch.uint8, device=self.device)
+        base = self._ws.data_ptr()
+        self._ws_ptr = (base + 255) // 256 * 256
+        r = _sdn.SdnTrainStep()
+        r.rays_o, r.rays_d, r.target = self.rays_o.data_ptr(), self.rays_d.data_ptr(), self.target.data_ptr()
+        r.N, r.M = self.n_rays, M
+        self._aabb = m.aabb_train.detach().to(self.device, torch.float32).contiguous()
+        r.aabb = self._aabb.data_ptr()
+        r.bound, r.min_near, r.dt_gamma = float(m.bound), float(m.min_near), self.dt_gamma
+        r.density_scale, r.T_thresh = float(m.density_scale), self.T_thresh
+        r.cascade, r.grid_size, r.max_steps = int(m.cascade), int(m.grid_size), self.max_steps
+        r.perturb = int(self.perturb)
+        for i in range(17):
+            r.grid_offsets[i] = self._offsets[i]
+        r.grid_S, r.grid_H = float(np.log2(m.encoder.per_level_scale)), int(m.encoder.base_resolution)
+        for i, p in enumerate(self.params):
+            st = self.opt.state[p]
+            q = r.params[i]
+            q.param, q.exp_avg, q.exp_avg_sq, q.n = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+            q.ema = self.ema_shadow[i].data_ptr() if self.ema_shadow is not None else None
+        r.adam_steps = self.adam_steps.data_ptr()
+        r.loss_scale, r.growth_tracker = self.scaler._scale.data_ptr(), self.scaler._growth_tracker.data_ptr()
+        r.growth_factor, r.backoff_factor = float(self.scaler.get_growth_factor()), float(self.scaler.get_backoff_factor())
+        r.growth_interval = int(self.scaler.get_growth_interval())
+        r.loss_out, r.image_out, r.workspace = self.loss.data_ptr(), self.image.data_ptr(), self._ws_ptr
+        self._rec, self._M = r, M
+        self.refresh()
+
+    def refresh(self):
+        """Re-derive the fp16 copies the kernels read from the fp32 parameters (after a checkpoint load, an eager step, ...)."""
+        if self._rec is None:
+            return self._build()
+        _sdn.check(_sdn.lib.sdn_train_refresh(ctypes.byref(self._rec), _sdn.stream()), "train_refresh")
+
+    def view(self, name, dtype, shape):
+        """A tensor view of a workspace buffer named in `SdnTrainLayout` (gradients `g_*`, fp16 parameter copies `w_*`, samples...)."""
+        off = int(getattr(self.layout, name)) + (self._ws_ptr - self._ws.data_ptr())
+        n = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size()
+        return self._ws[off:off + n].view(dtype).view(*shape)
+
+    # ---- one step -------------------------------------------------------------------------------------------------------------------
+    def load(self, rays_o, rays_d, target, time, bg_color=None):
+        self.rays_o.copy_(rays_o.reshape(self.rays_o.shape))
+        self.rays_d.copy_(rays_d.reshape(self.rays_d.shape))
+        self.target.copy_(target.reshape(self.target.shape))
+        self.time = float(np.float32(float(time.reshape(-1)[0]) if isinstance(time, torch.Tensor) else float(time)))
+        if bg_color is not None:
+            self.bg_color = bg_color
+
+    def __call__(self, rays_o=None, rays_d=None, target=None, time=None, bg_color=None, grads_only=False):
+        """One training step on the loaded batch (arguments, if given, are copied into the step's input buffers; `time` by value).
+        Returns the loss tensor (device, overwritten by the next step).  grads_only: forward + backward only -- gradients stay in the
+        workspace (`view("g_deform", ...)`), nothing is updated."""
+        if rays_o is not None:
+            self.load(rays_o, rays_d, target, time, bg_color)
+        m = self.model
+        if self._rec is None or self._M != _budget(int(m.mean_count)):
+            self._build()       # `update_extra_state` moved the budget (dnerf/renderer.py:550-552): new buffers, same parameters
+        r = self._rec
+        T = m.time_size
+        t_idx = int(min(max(np.floor(np.float32(self.time) * np.float32(T)), 0), T - 1))   # dnerf/renderer.py:285
+        r.time = self.time
+        r.bitfield = m.density_bitfield[t_idx].data_ptr()
+        counter = m.step_counter[m.local_step % 16]
+        r.counter = counter.data_ptr()
+        if isinstance(self.bg_color, torch.Tensor):
+            self.bg.copy_(self.bg_color.reshape(-1, 3).expand(self.n_rays, 3))
+            r.bg_color, r.bg_value = self.bg.data_ptr(), 0.0
+        else:
+            r.bg_color, r.bg_value = None, float(self.bg_color)
+        g_table, g_net = self._lr_of[id(self.params[0])], self._lr_of[id(self.params[1])]
+        r.lr_table, r.lr_net = float(g_table["lr"]), float(g_net["lr"])
+        r.beta1, r.beta2, r.eps = float(g_net["betas"][0]), float(g_net["betas"][1]), float(g_net["eps"])
+        r.noise_seed = (self.seed * 0x9E3779B1 + self.step_count) & 0xFFFFFFFFFFFFFFFF
+        if self.ema_decay is not None:
+            n = self.ema_updates + (0 if grads_only else 1)
+            r.ema_decay = min(self.ema_decay, (1 + n) / (10 + n))       # torch_ema: num_updates is incremented before use
+        r.noises = self.noises.data_ptr() if self.noises is not None else None
+        r.mode = 1 if grads_only else 0
+        _sdn.check(_sdn.lib.sdn_train_step_f16(ctypes.byref(r), _sdn.stream()), "train_step_f16")
+        m.local_step += 1
+        if not grads_only:
+            self.step_count += 1
+            self.ema_updates += 1
+        return self.loss
+
+    # ---- optimizer state the host owns ------------------------------------------------------------------------------------------------
+    def sync_optimizer_state(self):
+        """Writes the step counts the device keeps into the optimizer's per-parameter `step` entries (one host read-back): call before
+        `optimizer.state_dict()` / an eager `optimizer.step()`."""
+        main, deform = [float(v) for v in self.adam_steps.tolist()]
+        for i, p in enumerate(self.params):
+            self.opt.state[p]["step"].fill_(deform if 1 <= i <= 8 else main)

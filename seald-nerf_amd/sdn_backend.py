@@ -84,6 +84,42 @@ class SdnSealBox(ctypes.Structure):
                 ("rinv", _f32 * 9), ("scale", _f32 * 3), ("center", _f32 * 3), ("hsv", _f32 * 3), ("modify_hsv", ctypes.c_int32)]
 
 
+TRAIN_N_PARAMS = 14   # SDN_TRAIN_N_PARAMS
+
+
+class SdnTrainParam(ctypes.Structure):
+    """Mirror of `SdnTrainParam` in include/sdn_hip.h."""
+    _fields_ = [("param", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("ema", _vp), ("n", ctypes.c_uint64)]
+
+
+class SdnTrainStep(ctypes.Structure):
+    """Mirror of `SdnTrainStep` in include/sdn_hip.h (field order and types must match)."""
+    _fields_ = ([(n, _vp) for n in ("rays_o", "rays_d", "target", "bg_color")]
+                + [("bg_value", _f32), ("N", _u32), ("M", _u32), ("bitfield", _vp), ("aabb", _vp)]
+                + [(n, _f32) for n in ("bound", "min_near", "dt_gamma", "density_scale", "T_thresh", "time")]
+                + [(n, _u32) for n in ("cascade", "grid_size", "max_steps")]
+                + [("perturb", ctypes.c_int32), ("noise_seed", ctypes.c_uint64), ("noises", _vp), ("counter", _vp),
+                   ("grid_offsets", ctypes.c_int32 * 17), ("grid_S", _f32), ("grid_H", _u32),
+                   ("params", SdnTrainParam * TRAIN_N_PARAMS)]
+                + [(n, ctypes.c_double) for n in ("lr_table", "lr_net", "beta1", "beta2", "eps")]
+                + [("adam_steps", _vp), ("loss_scale", _vp), ("growth_tracker", _vp), ("growth_factor", _f32), ("backoff_factor", _f32),
+                   ("growth_interval", _u32), ("ema_decay", _f32), ("loss_out", _vp), ("image_out", _vp), ("workspace", _vp),
+                   ("mode", ctypes.c_int32), ("reserved_", ctypes.c_int32)])
+
+
+class SdnTrainLayout(ctypes.Structure):
+    """Mirror of `SdnTrainLayout` in include/sdn_hip.h."""
+    _fields_ = [(n, ctypes.c_uint64) for n in ("total_bytes", "w_table", "w_deform", "w_sigma0", "w_sigma1", "w_color", "g_table", "g_deform",
+                                                "g_sigma0", "g_sigma1", "g_color", "xyzs", "dirs", "deltas", "rays", "sigmas", "rgbs",
+                                                "weights_sum", "depth", "image", "found_inf")]
+
+
+PROTOTYPES.update({
+    "sdn_train_layout": [_u32, _u32, _u32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(SdnTrainLayout)],
+    "sdn_train_refresh": [ctypes.POINTER(SdnTrainStep), _vp],
+    "sdn_train_step_f16": [ctypes.POINTER(SdnTrainStep), _vp],
+})
+
 PROTOTYPES_U32 = {
     "sdn_field_weight_blocks": [],
     "sdn_cull_grid_bytes": [],
