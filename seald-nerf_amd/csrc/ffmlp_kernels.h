@@ -21,6 +21,33 @@ enum { ACT_RELU = 0, ACT_EXP = 1, ACT_SINE = 2, ACT_SIGMOID = 3, ACT_SQUAREPLUS 
 
 __device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
+// Rows of activations live one per lane PAIR: after a 32x32 MFMA chain lane n (h = 0) holds features 8q .. 8q+3 and lane n + 32
+// (h = 1) features 8q+4 .. 8q+7 of every 8-feature group q.  Stored as they are that is one 8-byte piece per lane per group: 64
+// different cache lines per store instruction, and the address pipe takes ~55 cycles for each (measured: 7 000 cycles per 128-wide
+// layer per workgroup, 3.5x the layer's MFMA time).  v_permlane32_swap exchanges the upper half-wave of one register with the
+// lower half-wave of another: for a pair of groups (q, q+1) the lower lanes end up with the 8 contiguous features of group q and
+// the upper lanes with those of group q+1 -- ONE 16-byte access per lane per pair, half the instructions, twice the run length.
+// The same exchange, applied to a 16-byte load, puts the features back where the MFMA layout wants them (it is an involution).
+// Must run with the whole wave active.
+__device__ __forceinline__ void half_wave_exchange(uint32_t &a, uint32_t &b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+struct PairRuns { half4 g0, g1; };   // this lane's 4-feature runs of groups q and q+1
+__device__ __forceinline__ uint4 pair_to_row16(half4 g0, half4 g1) {
+    uint2 a = __builtin_bit_cast(uint2, g0), b = __builtin_bit_cast(uint2, g1);
+    half_wave_exchange(a.x, b.x);
+    half_wave_exchange(a.y, b.y);
+    return uint4{a.x, a.y, b.x, b.y};
+}
+__device__ __forceinline__ PairRuns row16_to_pair(uint4 v) {
+    uint2 a{v.x, v.y}, b{v.z, v.w};
+    half_wave_exchange(a.x, b.x);
+    half_wave_exchange(a.y, b.y);
+    return PairRuns{__builtin_bit_cast(half4, a), __builtin_bit_cast(half4, b)};
+}
+
 // Activations act on one accumulator tile's 16 values per lane at a time, with the dispatch outside the element loops
 // (ARELU = true: compiled for ReLU only -- the hot case; false: run-time dispatch over the other six).
 // utils.h:425-470 (forward) on the fp16-rounded layer output.  The transcendental ones use the hardware
@@ -109,6 +136,15 @@ __device__ __forceinline__ void stage_wait_and_sync() {
     __syncthreads();
 }
 
+// Counted form: everything but the wave's N youngest vector-memory operations is done (MI355X_MICROARCH: loads, stores and LDS-DMA
+// count together in issue order).  The N youngest are the activation stores a wave issued AFTER the stage's direct-to-LDS loads:
+// they need not be waited for -- a plain vmcnt(0) exposes their write latency in front of every stage barrier.  Raw barrier:
+// `__syncthreads()` adds its own vmcnt(0).  Only valid when the wave really issued >= N such operations (see `counted` below).
+template <int N>
+__device__ __forceinline__ void stage_wait_counted_and_sync() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
 // Weight fragments reach the MFMAs through LDS in one of two ways:
 //   streamed (RES = false): <= 32 KiB stages, double-buffered, one barrier per stage, re-fetched (from L2) for every point tile;
 //   resident (RES = true): the whole packed network fits the LDS allocation, is loaded once per workgroup, and the workgroup
@@ -124,17 +160,23 @@ struct Stager {
         stage_load(g, lds + (cur ^ 1) * kStageBytes, nfrags, wave, lane, WV);
         g += (size_t)nfrags * 1024;
     }
-    // the stage (this_frags) prefetched last becomes current; start fetching the one after it (next_frags, 0 = none)
-    __device__ __forceinline__ void begin_stage(int this_frags, int next_frags) {
+    // the stage (this_frags) prefetched last becomes current; start fetching the one after it (next_frags, 0 = none).
+    // N / counted: the wave issued >= N vector-memory operations after the pending stage's loads that may stay in flight.
+    // between(): issued after the barrier and before the next stage's loads (global loads that must be OLDER than those).
+    template <int N, typename Fn>
+    __device__ __forceinline__ void begin_stage(int this_frags, int next_frags, bool counted, Fn between) {
         if (RES) {
             off = next_off;
             next_off += (uint32_t)this_frags * 1024u;
+            between();
         } else {
-            stage_wait_and_sync();
+            if (N > 0 && N < 64 && counted) stage_wait_counted_and_sync<(N > 0 && N < 64) ? N : 0>(); else stage_wait_and_sync();
             cur ^= 1;
+            between();
             if (next_frags) prefetch(next_frags);
         }
     }
+    __device__ __forceinline__ void begin_stage(int this_frags, int next_frags) { begin_stage<0>(this_frags, next_frags, false, [] {}); }
     __device__ __forceinline__ const unsigned char *buf() const { return RES ? lds + off : lds + cur * kStageBytes; }
 };
 
@@ -191,10 +233,36 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_ffmlp(FfArgs P) {
     }
 
     half8 fa[KS][NT], fb[KS][NT];
+    constexpr int NQ = WIDTH >= 32 ? 4 : 2;                              // 4-feature runs of a tile that exist (hidden 16: rows 0..15 only)
+    // The latency variant (OCC <= 2: twice the registers; picked by the host when a launch has no more workgroups than CUs, where
+    // occupancy buys nothing and every exposed latency is on the critical path of the whole launch):
+    //   * a whole M-tile of weight fragments is read from LDS while the previous M-tile's MFMAs run (the throughput variant reads
+    //     two fragments, waits, issues two MFMAs: the matrix pipe idles for an LDS round trip per pair);
+    //   * backward: the forward activations a layer's epilogues test are fetched at the START of the layer (all M-tiles at once,
+    //     older than the next stage's loads), not inside each epilogue (an exposed L2 / HBM round trip per M-tile per layer).
+    constexpr bool LA = OCC <= 2 && WIDTH <= 128 && !RES;
+    constexpr bool kPrefetchFwd = LA && MODE == 2;
+    uint4 fwraw[kPrefetchFwd ? MT : 1][NT][2];
+    auto fetch_fwd = [&](int k) __attribute__((always_inline)) {
+        if constexpr (kPrefetchFwd) {
+            #pragma unroll
+            for (int Mt = 0; Mt < MT; Mt++)
+                #pragma unroll
+                for (int t = 0; t < NT; t++)
+                    #pragma unroll
+                    for (int p = 0; p < NQ / 2; p++)
+                        fwraw[Mt][t][p] = *reinterpret_cast<const uint4 *>(P.fwd + ((size_t)(P.L - 1 - k) * P.B + pt[t]) * WIDTH + 32u * Mt + 16u * p + 8u * h);
+        }
+    };
+    // activation stores per M-tile epilogue, and whether this wave issues all of them (a wave without live points may skip them:
+    // then nothing may be assumed about its vector-memory queue and the stage waits drain it completely)
+    constexpr int kStoresPerTile = MODE != 0 ? (NQ / 2) * NT : 0;
+    bool wave_full = MODE != 0;
+    #pragma unroll
+    for (int t = 0; t < NT; t++) wave_full = wave_full && __builtin_amdgcn_ballot_w64(live[t]) != 0;
 
     // hidden-layer epilogue: accumulator tile -> next layer's B fragments (+ buffers)
     auto epilogue = [&](int k, int Mt, const f32x16 (&acc)[NT], half8 (&dst)[KS][NT]) __attribute__((always_inline)) {
-        constexpr int NQ = WIDTH >= 32 ? 4 : 2;                          // 4-feature runs of the tile that exist (hidden 16: rows 0..15 only)
         #pragma unroll
         for (int t = 0; t < NT; t++) {
             _Float16 v[16];
@@ -203,21 +271,27 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_ffmlp(FfArgs P) {
             if (MODE == 2) {
                 _Float16 fw[16];
                 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    half4 x = {0, 0, 0, 0};
-                    if (q < NQ) x = *reinterpret_cast<const half4 *>(P.fwd + ((size_t)(P.L - 1 - k) * P.B + pt[t]) * WIDTH + 32u * Mt + 8u * q + 4u * h);
+                for (int p = 0; p < 2; p++) {
+                    PairRuns x{{0, 0, 0, 0}, {0, 0, 0, 0}};
+                    if (p < NQ / 2) {
+                        uint4 raw;
+                        if constexpr (kPrefetchFwd) raw = fwraw[Mt][t][p];
+                        else raw = *reinterpret_cast<const uint4 *>(P.fwd + ((size_t)(P.L - 1 - k) * P.B + pt[t]) * WIDTH + 32u * Mt + 16u * p + 8u * h);
+                        x = row16_to_pair(raw);
+                    }
                     #pragma unroll
-                    for (int e = 0; e < 4; e++) fw[4 * q + e] = x[e];
+                    for (int e = 0; e < 4; e++) { fw[8 * p + e] = x.g0[e]; fw[8 * p + 4 + e] = x.g1[e]; }
                 }
                 act_backward16<ARELU>(P.act, v, fw);
             } else {
                 act_forward16<ARELU>(P.act, v);
             }
-            if (MODE != 0 && live[t]) {
+            if constexpr (MODE != 0) {
                 #pragma unroll
-                for (int q = 0; q < NQ; q++)
-                    *reinterpret_cast<half4 *>(P.buf + ((size_t)k * P.B + pt[t]) * WIDTH + 32u * Mt + 8u * q + 4u * h) =
-                        half4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                for (int p = 0; p < NQ / 2; p++) {
+                    const uint4 row16 = pair_to_row16(half4{v[8 * p], v[8 * p + 1], v[8 * p + 2], v[8 * p + 3]}, half4{v[8 * p + 4], v[8 * p + 5], v[8 * p + 6], v[8 * p + 7]});
+                    if (live[t]) *reinterpret_cast<uint4 *>(P.buf + ((size_t)k * P.B + pt[t]) * WIDTH + 32u * Mt + 16u * p + 8u * h) = row16;
+                }
             }
             #pragma unroll
             for (int s = 0; s < 2; s++)
@@ -236,8 +310,14 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_ffmlp(FfArgs P) {
                 const int ss = s < KS0 ? s : KS0 - 1;      // k-steps beyond K0 re-read the last one (never multiplied): keeps fb in registers
                 #pragma unroll
                 for (int t = 0; t < NT; t++) {
-                    const _Float16 *row = P.x + (size_t)pt[t] * P.K0 + 16 * ss + 4 * h;
-                    const half4 lo = *reinterpret_cast<const half4 *>(row), hi = *reinterpret_cast<const half4 *>(row + 8);
+                    half4 lo, hi;
+                    if constexpr (MODE != 0) {      // (the inference instantiation sits at its register limit: it keeps the 8-byte loads)
+                        const PairRuns r = row16_to_pair(*reinterpret_cast<const uint4 *>(P.x + (size_t)pt[t] * P.K0 + 16 * ss + 8 * h));
+                        lo = r.g0; hi = r.g1;
+                    } else {
+                        const _Float16 *row = P.x + (size_t)pt[t] * P.K0 + 16 * ss + 4 * h;
+                        lo = *reinterpret_cast<const half4 *>(row); hi = *reinterpret_cast<const half4 *>(row + 8);
+                    }
                     fb[s][t] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
             }
@@ -247,7 +327,8 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_ffmlp(FfArgs P) {
             if (Mt % g0 == 0) {
                 const int left = MT - Mt - g0;
                 const bool more = P.L > 1 || has_last;
-                S.begin_stage((MT - Mt < g0 ? MT - Mt : g0) * KS0, left > 0 ? (left < g0 ? left : g0) * KS0 : (more ? after : 0));
+                S.template begin_stage<0>((MT - Mt < g0 ? MT - Mt : g0) * KS0, left > 0 ? (left < g0 ? left : g0) * KS0 : (more ? after : 0), false,
+                                          [&]() __attribute__((always_inline)) { if (Mt == 0) fetch_fwd(0); });
             }
             const unsigned char *base = S.buf() + (size_t)(Mt % g0) * KS0 * 1024;
             f32x16 acc[NT];
@@ -280,19 +361,34 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_ffmlp(FfArgs P) {
     // ---- hidden layers 1 .. L-1: WIDTH x WIDTH, operands ping-pong between fa and fb ---------------------------------------------
     auto hidden = [&](int k, const half8 (&src)[KS][NT], half8 (&dst)[KS][NT]) __attribute__((always_inline)) {
         const int after = (k + 1 < (int)P.L) ? GM * KS : (has_last ? first_stage_frags(MTL, KS) : 0);
+        half8 ahead[LA ? 2 : 1][LA ? KS : 1];
         #pragma unroll
         for (int Mt = 0; Mt < MT; Mt++) {
             if (Mt % GM == 0) {
                 const int left = MT - Mt - GM;
-                S.begin_stage((MT - Mt < GM ? MT - Mt : GM) * KS, left > 0 ? (left < GM ? left : GM) * KS : after);
+                // the previous stage group's epilogues (of this layer, or of the hidden layer before it: k >= 2) left GM tiles' stores
+                S.template begin_stage<GM * kStoresPerTile>((MT - Mt < GM ? MT - Mt : GM) * KS, left > 0 ? (left < GM ? left : GM) * KS : after,
+                                                            wave_full && (Mt != 0 || k >= 2),
+                                                            [&]() __attribute__((always_inline)) { if (Mt == 0) fetch_fwd(k); });
+                if constexpr (LA) {
+                    #pragma unroll
+                    for (int s = 0; s < KS; s++) ahead[Mt & 1][s] = lds_frag(S.buf() + (size_t)(Mt % GM) * KS * 1024, s, lane);
+                }
             }
             const unsigned char *base = S.buf() + (size_t)(Mt % GM) * KS * 1024;
+            if constexpr (LA) {
+                if (Mt + 1 < MT && (Mt + 1) % GM != 0) {
+                    #pragma unroll
+                    for (int s = 0; s < KS; s++) ahead[(Mt + 1) & 1][s] = lds_frag(S.buf() + (size_t)((Mt + 1) % GM) * KS * 1024, s, lane);
+                }
+            }
             f32x16 acc[NT];
             #pragma unroll
             for (int t = 0; t < NT; t++) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             #pragma unroll
             for (int s = 0; s < KS; s++) {
-                const half8 a = lds_frag(base, s, lane);
+                half8 a;
+                if constexpr (LA) a = ahead[Mt & 1][s]; else a = lds_frag(base, s, lane);
                 #pragma unroll
                 for (int t = 0; t < NT; t++) acc[t] = mfma(a, src[s][t], acc[t]);
             }
@@ -305,7 +401,8 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_ffmlp(FfArgs P) {
         for (int Mt = 0; Mt < MTL; Mt++) {
             if (Mt % gl == 0) {
                 const int left = MTL - Mt - gl;
-                S.begin_stage((MTL - Mt < gl ? MTL - Mt : gl) * KS, left > 0 ? (left < gl ? left : gl) * KS : 0);
+                S.template begin_stage<GM * kStoresPerTile>((MTL - Mt < gl ? MTL - Mt : gl) * KS, left > 0 ? (left < gl ? left : gl) * KS : 0,
+                                                            wave_full && Mt == 0 && P.L >= 2, [] {});
             }
             const unsigned char *base = S.buf() + (size_t)(Mt % gl) * KS * 1024;
             f32x16 acc[NT];
@@ -388,6 +485,22 @@ int launch_width(const FfArgs &a, hipStream_t st) {
         hipLaunchKernelGGL((k_ffmlp<WIDTH, NT, MODE, true, OCC, RW, ARELU>), dim3(grid), dim3(64 * RW), lds, st, a);
     } else {
         const uint32_t ntiles = sdn_div_up(a.B, (uint32_t)(SW * 32 * NT));
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        if constexpr ((WIDTH == 64 || WIDTH == 128) && OCC > 2) {
+            // A launch with no more workgroups than CUs: the latency variant, and as few waves per workgroup as still leave at most two
+            // workgroups per CU -- the per-layer critical path (stage barrier, the workgroup's activation stores through ONE address
+            // pipe, the MFMAs of the waves sharing a SIMD) shrinks with the rows a workgroup owns; the weights come from L2 anyway.
+            if (ntiles <= (uint32_t)cus) {
+                if (sdn_div_up(a.B, (uint32_t)(2 * 32 * NT)) <= 2u * (uint32_t)cus)
+                    hipLaunchKernelGGL((k_ffmlp<WIDTH, NT, MODE, false, 2, 2, ARELU>), dim3(sdn_div_up(a.B, (uint32_t)(2 * 32 * NT))), dim3(128), 2 * kStageBytes, st, a);
+                else if (sdn_div_up(a.B, (uint32_t)(4 * 32 * NT)) <= 2u * (uint32_t)cus)
+                    hipLaunchKernelGGL((k_ffmlp<WIDTH, NT, MODE, false, 2, 4, ARELU>), dim3(sdn_div_up(a.B, (uint32_t)(4 * 32 * NT))), dim3(256), 2 * kStageBytes, st, a);
+                else
+                    hipLaunchKernelGGL((k_ffmlp<WIDTH, NT, MODE, false, 2, SW, ARELU>), dim3(ntiles), dim3(64 * SW), 2 * kStageBytes, st, a);
+                return sdn_launch_status();
+            }
+        }
         hipLaunchKernelGGL((k_ffmlp<WIDTH, NT, MODE, false, OCC, SW, ARELU>), dim3(ntiles), dim3(64 * SW), 2 * kStageBytes, st, a);
     }
     return sdn_launch_status();
