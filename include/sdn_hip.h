@@ -471,7 +471,7 @@ typedef struct SdnTrainLayout {
     uint64_t w_table, w_deform, w_sigma0, w_sigma1, w_color;   /* fp16 copies of the parameters */
     uint64_t g_table, g_deform, g_sigma0, g_sigma1, g_color;   /* fp16 gradients (scaled by the loss scale), same layouts */
     uint64_t xyzs, dirs, deltas, rays;                         /* march_rays_train outputs: [M,3] [M,3] [M,2] f32, [N,3] i32 */
-    uint64_t sigmas, rgbs;                                     /* [M] f32 (density_scale applied), [M,3] f32 */
+    uint64_t sigmas;                                           /* [M] f32 (density_scale applied) */
     uint64_t weights_sum, depth, image;                        /* [N] [N] [N,3] f32, before the background mix */
     uint64_t found_inf;                                        /* f32 [1] */
 } SdnTrainLayout;

@@ -55,10 +55,10 @@ struct Layout {
     uint64_t total;
     uint64_t w_table, w_deform, w_sigma0, w_sigma1, w_color, g_table, hyper;                 // persistent
     uint64_t pk_def_f, pk_def_b, pk_col_f, pk_col_b;
-    uint64_t nears, fars, noises, rays, pts, gflat, march;
-    uint64_t enc_in, def_hidden, def_out, xdef, grid_out, dy_dx, enc_rm, h1, hout, sigmas, col_in, col_hidden, col_out, rgbs;
-    uint64_t weights_sum, depth, image, grad_image, grad_ws;
-    uint64_t dcol_out, dh0, col_bwd, dcol_in, dh, dh1, denc, dx16, ddef, def_bwd;
+    uint64_t nears, fars, noises, rays, pts, dcol_out, dh0, march;
+    uint64_t enc_in, def_hidden, def_out, xdef, grid_out, dy_dx, enc_rm, h1, hout, sigmas, col_in, col_hidden, col_out;
+    uint64_t weights_sum, depth, image, sq_err;
+    uint64_t col_bwd, dcol_in, dh, dh1, denc, dx16, ddef, def_bwd;
     uint64_t g_deform, g_sigma0, g_sigma1, g_color, dw_partial;
 };
 
@@ -78,14 +78,15 @@ Layout make_layout(uint32_t N, uint32_t M, uint32_t max_steps, uint64_t table_en
     L.pk_col_b = take((uint64_t)sdn_ffh::total_frags(kColIn, kColW, kColL, 1, 1) * 1024);
     L.nears = take(n * 4);  L.fars = take(n * 4);  L.noises = take(n * 4);  L.rays = take(n * 12);
     L.pts = take(m * 32);                       // xyzs [M,3] | dirs [M,3] | deltas [M,2], zero-filled every step ...
-    L.gflat = take(m * 16);                     // ... together with grad_sigmas [M] | grad_rgbs [M,3] (must follow `pts`)
+    L.dcol_out = take(m * 32);                  // ... together with the gradient rows the compositing backward fills for the samples
+    L.dh0 = take(m * 2);                        //     rays own (must follow `pts`, in this order: one fill)
     L.march = take(sdn_march_rays_train_scratch_bytes(N, max_steps));
     L.enc_in = take(m * kDefIn * 2);  L.def_hidden = take(m * kDefL * kDefW * 2);  L.def_out = take(m * 32);
     L.xdef = take(m * 12);  L.grid_out = take(m * kLevels * 4);  L.dy_dx = take(m * kLevels * 12);
     L.enc_rm = take(m * kSigIn * 2);  L.h1 = take(m * kSigW * 2);  L.hout = take(m * kSigOut * 2);  L.sigmas = take(m * 4);
-    L.col_in = take(m * kColIn * 2);  L.col_hidden = take(m * kColL * kColW * 2);  L.col_out = take(m * 32);  L.rgbs = take(m * 12);
-    L.weights_sum = take(n * 4);  L.depth = take(n * 4);  L.image = take(n * 12);  L.grad_image = take(n * 12);  L.grad_ws = take(n * 4);
-    L.dcol_out = take(m * 32);  L.dh0 = take(m * 2);  L.col_bwd = take(m * kColL * kColW * 2);  L.dcol_in = take(m * kColIn * 2);
+    L.col_in = take(m * kColIn * 2);  L.col_hidden = take(m * kColL * kColW * 2);  L.col_out = take(m * 32);
+    L.weights_sum = take(n * 4);  L.depth = take(n * 4);  L.image = take(n * 12);  L.sq_err = take(n * 4);
+    L.col_bwd = take(m * kColL * kColW * 2);  L.dcol_in = take(m * kColIn * 2);
     L.dh = take(m * kSigOut * 2);  L.dh1 = take(m * kSigW * 2);  L.denc = take(m * kLevels * 4);  L.dx16 = take(m * 6);
     L.ddef = take(m * 32);  L.def_bwd = take(m * kDefL * kDefW * 2);
     L.g_deform = take(kDefFlat * 2);  L.g_sigma0 = take(kSigW * kSigIn * 2);  L.g_sigma1 = take(kSigOut * kSigW * 2);  L.g_color = take(kColFlat * 2);
@@ -243,42 +244,108 @@ __global__ void __launch_bounds__(64) k_train_sigma_fwd(SigmaFwd P) {
 
 __device__ __forceinline__ _Float16 sigmoid16(_Float16 c) { return (_Float16)(1.0f / (1.0f + expf(-(float)c))); }
 
-// rgb = sigmoid(colour MLP output) in fp16 (network.py:166), widened for composite_rays_train (cast_inputs float32)
-__global__ void __launch_bounds__(256) k_train_rgb(const _Float16 *__restrict__ col_out, uint32_t M, float *__restrict__ rgbs) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= M * 3) return;
-    const uint32_t b = t / 3, c = t - b * 3;
-    rgbs[t] = (float)sigmoid16(col_out[(size_t)b * 16 + c]);
+// ---- compositing, one WAVE per ray ------------------------------------------------------------------------------------------------
+// composite_rays_train (raymarching.cu:501-577 forward, :602-682 backward) walks a ray's samples one after the other; with one lane per
+// ray a batch of 4096 rays is 64 waves whose time is the longest ray's chain of dependent loads and double-precision exps (24 + 30 us
+// for ~9000 samples).  Here lane i of a wave takes sample i of the ray: alpha in parallel, transmittance as a prefix PRODUCT across
+// the lanes, the ray's sums as wave reductions.  The early stop `T < T_thresh` of the sequential loop becomes a per-sample predicate
+// (sample i is composited iff the transmittance in front of it is >= T_thresh: T never grows).  The sums are tree sums, so results
+// differ from the sequential operator's in the last bits (the public composite_rays_train op keeps the sequential order and the
+// bit-exact contract).  Folded in: the fp16 sigmoid of the colour MLP's output (network.py:166) in front, the background mix and
+// the MSE gradient per ray behind (renderer.py:318, utils.py:85), and in the backward kernel the gradients through sigmoid,
+// density_scale and trunc_exp (activation.py:12-17) down to the fp16 rows the MLP backward chains start from.
+__device__ __forceinline__ float wave_excl_product(float v, uint32_t lane) {   // exclusive prefix product over the 64 lanes
+    float inc = v;
+    #pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float u = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc *= u; }
+    const float up = __shfl_up(inc, 1);
+    return lane == 0 ? 1.0f : up;
+}
+__device__ __forceinline__ float wave_incl_sum(float v, uint32_t lane) {
+    #pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float u = __shfl_up(v, o); if (lane >= (uint32_t)o) v += u; }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
 }
 
-// pred = image + (1 - weights_sum) * bg (renderer.py:318); loss = mean over rays of the mean over channels of (pred - gt)^2
-// (utils.py:85, :125); gradients of scale * loss with respect to image and weights_sum.  ONE workgroup: the loss is a
-// deterministic tree sum, 4096 rays are 4 per thread.
-__global__ void __launch_bounds__(1024) k_train_loss(const float *__restrict__ image, const float *__restrict__ ws, const float *__restrict__ bg,
-                                                     float bg_value, const float *__restrict__ gt, uint32_t N, const float *__restrict__ loss_scale,
-                                                     float *__restrict__ loss_out, float *__restrict__ grad_image, float *__restrict__ grad_ws,
-                                                     float *__restrict__ image_out) {
-    __shared__ float s_part[16];
-    const float c = (*loss_scale / (float)N) / 3.0f;
-    float acc = 0.0f;
-    for (uint32_t r = threadIdx.x; r < N; r += 1024) {
-        const float one_minus = 1.0f - ws[r];
-        float sq = 0.0f, gws = 0.0f;
+struct CompositeArgs {
+    const float *sigmas, *deltas;        // [M] (density_scale applied), [M,2]
+    const _Float16 *col_out, *hout;      // [M,16] colour MLP output (pre-sigmoid), [M,16] sigma MLP output (column 0: log density)
+    const int32_t *rays;                 // [N,3]
+    const float *bg, *gt, *loss_scale;
+    float *weights_sum, *depth, *image, *image_out, *sq_err;   // per ray; sq_err [N]: sum over channels of (pred - gt)^2
+    _Float16 *dcol_out, *dh0;            // backward: [M,16], [M]
+    uint32_t M, N;
+    float T_thresh, bg_value, density_scale;
+};
+
+// one chunk of <= 64 samples of a ray: everything the forward AND the backward need about sample `i`
+struct SampleTerms { bool on; float alpha, T, weight, delta0, t, c[3]; };
+
+__device__ __forceinline__ SampleTerms sample_terms(const CompositeArgs &P, uint32_t idx, bool in_ray, float T_carry, float t_carry, uint32_t lane,
+                                                    float &T_next, float &t_next) {
+    SampleTerms s{};
+    float one_minus = 1.0f, d1 = 0.0f;
+    if (in_ray) {
+        s.delta0 = P.deltas[(size_t)idx * 2];
+        d1 = P.deltas[(size_t)idx * 2 + 1];
+        s.alpha = 1.0f - sdn_exp_cr(-P.sigmas[idx] * s.delta0);
+        one_minus = 1.0f - s.alpha;
+        #pragma unroll
+        for (int ch = 0; ch < 3; ch++) s.c[ch] = (float)sigmoid16(P.col_out[(size_t)idx * 16 + ch]);
+    }
+    s.T = T_carry * wave_excl_product(one_minus, lane);
+    s.t = t_carry + wave_incl_sum(d1, lane);
+    s.on = in_ray && s.T >= P.T_thresh;
+    s.weight = s.on ? s.alpha * s.T : 0.0f;
+    T_next = __shfl(s.T * one_minus, 63);
+    t_next = __shfl(s.t, 63);
+    return s;
+}
+
+__global__ void __launch_bounds__(256) k_train_composite_fwd(CompositeArgs P) {
+    const uint32_t lane = threadIdx.x & 63u, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= P.N) return;
+    const uint32_t index = (uint32_t)P.rays[n * 3], offset = (uint32_t)P.rays[n * 3 + 1], count = (uint32_t)P.rays[n * 3 + 2];
+    float ws = 0, d = 0, r = 0, g = 0, b = 0;
+    if (count != 0 && offset + count <= P.M) {
+        float T_carry = 1.0f, t_carry = 0.0f;
+        for (uint32_t c0 = 0; c0 < count && T_carry >= P.T_thresh; c0 += 64) {
+            float T_next, t_next;
+            const SampleTerms s = sample_terms(P, offset + c0 + lane, c0 + lane < count, T_carry, t_carry, lane, T_next, t_next);
+            ws += s.weight; d += s.weight * s.t;
+            r += s.weight * s.c[0]; g += s.weight * s.c[1]; b += s.weight * s.c[2];
+            T_carry = T_next; t_carry = t_next;
+        }
+        ws = wave_sum(ws); d = wave_sum(d); r = wave_sum(r); g = wave_sum(g); b = wave_sum(b);
+    }
+    if (lane == 0) {
+        P.weights_sum[index] = ws; P.depth[index] = d;
+        const float img[3] = {r, g, b};
+        float sq = 0.0f;
         #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            const float b = bg ? bg[(size_t)r * 3 + ch] : bg_value;
-            const float pred = image[(size_t)r * 3 + ch] + one_minus * b;
-            const float d = pred - gt[(size_t)r * 3 + ch];
-            const float g = (d * 2.0f) * c;
-            grad_image[(size_t)r * 3 + ch] = g;
-            gws -= g * b;
-            sq += d * d;
-            if (image_out) image_out[(size_t)r * 3 + ch] = pred;
+            P.image[(size_t)index * 3 + ch] = img[ch];
+            const float bgc = P.bg ? P.bg[(size_t)index * 3 + ch] : P.bg_value;
+            const float pred = img[ch] + (1.0f - ws) * bgc;          // renderer.py:318
+            const float e = pred - P.gt[(size_t)index * 3 + ch];
+            sq += e * e;
+            if (P.image_out) P.image_out[(size_t)index * 3 + ch] = pred;
         }
-        grad_ws[r] = gws;
-        acc += sq / 3.0f;
+        P.sq_err[index] = sq;
     }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+}
+
+// loss = mean over rays of the mean over channels of (pred - gt)^2 (utils.py:85, :125): a deterministic tree sum in ONE workgroup
+__global__ void __launch_bounds__(1024) k_train_loss(const float *__restrict__ sq_err, uint32_t N, float *__restrict__ loss_out) {
+    __shared__ float s_part[16];
+    float acc = 0.0f;
+    for (uint32_t r = threadIdx.x; r < N; r += 1024) acc += sq_err[r] / 3.0f;
+    acc = wave_sum(acc);
     if ((threadIdx.x & 63u) == 0) s_part[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -288,26 +355,50 @@ __global__ void __launch_bounds__(1024) k_train_loss(const float *__restrict__ i
     }
 }
 
-// backward of: composite's float32 cast (-> fp16), sigmoid (fp16, torch's a * (1 - y) * y in float), density_scale, trunc_exp
-// (g * exp(clamp(x, -15, 15)), then the cast back to fp16 of its float32 input)
-__global__ void __launch_bounds__(256) k_train_colour_grad(const float *__restrict__ gflat, const _Float16 *__restrict__ col_out,
-                                                           const _Float16 *__restrict__ hout, uint32_t M, float density_scale,
-                                                           _Float16 *__restrict__ dcol_out, _Float16 *__restrict__ dh0) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= M) return;
-    const float *g_sigma = gflat, *g_rgb = gflat + M;
-    _Float16 d[3];
+__global__ void __launch_bounds__(256) k_train_composite_bwd(CompositeArgs P) {
+    const uint32_t lane = threadIdx.x & 63u, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= P.N) return;
+    const uint32_t index = (uint32_t)P.rays[n * 3], offset = (uint32_t)P.rays[n * 3 + 1], count = (uint32_t)P.rays[n * 3 + 2];
+    if (count == 0 || offset + count > P.M) return;
+    // gradient of scale * loss with respect to this ray's image and weights_sum (MSE mean over 3 N values; the background mix)
+    const float ws_final = P.weights_sum[index];
+    const float cg = (*P.loss_scale / (float)P.N) / 3.0f;
+    float gi[3], fin[3], gws = 0.0f;
     #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const _Float16 g16 = (_Float16)g_rgb[(size_t)b * 3 + c];
-        const float y = (float)sigmoid16(col_out[(size_t)b * 16 + c]);
-        d[c] = (_Float16)(((float)g16 * (1.0f - y)) * y);
+    for (int ch = 0; ch < 3; ch++) {
+        fin[ch] = P.image[(size_t)index * 3 + ch];
+        const float bgc = P.bg ? P.bg[(size_t)index * 3 + ch] : P.bg_value;
+        const float pred = fin[ch] + (1.0f - ws_final) * bgc;
+        gi[ch] = ((pred - P.gt[(size_t)index * 3 + ch]) * 2.0f) * cg;
+        gws -= gi[ch] * bgc;
     }
-    h8 *row = reinterpret_cast<h8 *>(dcol_out + (size_t)b * 16);
-    row[0] = h8{d[0], d[1], d[2], 0, 0, 0, 0, 0};
-    row[1] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-    const float x = fminf(fmaxf((float)hout[(size_t)b * kSigOut], -15.0f), 15.0f);
-    dh0[b] = (_Float16)((g_sigma[b] * density_scale) * expf(x));
+    float T_carry = 1.0f, t_carry = 0.0f, acc_c[3] = {0, 0, 0};
+    for (uint32_t c0 = 0; c0 < count && T_carry >= P.T_thresh; c0 += 64) {
+        float T_next, t_next;
+        const uint32_t idx = offset + c0 + lane;
+        const SampleTerms s = sample_terms(P, idx, c0 + lane < count, T_carry, t_carry, lane, T_next, t_next);
+        // raymarching.cu:655-675: r, g, b are the running sums INCLUDING this sample, T the transmittance BEHIND it
+        float run[3];
+        #pragma unroll
+        for (int ch = 0; ch < 3; ch++) run[ch] = acc_c[ch] + wave_incl_sum(s.weight * s.c[ch], lane);
+        if (s.on) {
+            const float T_after = s.T * (1.0f - s.alpha);
+            const float g_sigma = s.delta0 * (gi[0] * (T_after * s.c[0] - (fin[0] - run[0])) + gi[1] * (T_after * s.c[1] - (fin[1] - run[1])) +
+                                              gi[2] * (T_after * s.c[2] - (fin[2] - run[2])) + gws * (1.0f - ws_final));
+            _Float16 dc[3];
+            #pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const _Float16 g16 = (_Float16)(gi[ch] * s.weight);                       // composite's float32 cast, backwards
+                dc[ch] = (_Float16)(((float)g16 * (1.0f - s.c[ch])) * s.c[ch]);             // sigmoid backward on fp16 (a * (1 - y) * y in float)
+            }
+            *reinterpret_cast<h8 *>(P.dcol_out + (size_t)idx * 16) = h8{dc[0], dc[1], dc[2], 0, 0, 0, 0, 0};
+            const float x = fminf(fmaxf((float)P.hout[(size_t)idx * kSigOut], -15.0f), 15.0f);
+            P.dh0[idx] = (_Float16)((g_sigma * P.density_scale) * expf(x));              // density_scale, trunc_exp backward, cast to fp16
+        }
+        #pragma unroll
+        for (int ch = 0; ch < 3; ch++) acc_c[ch] = __shfl(run[ch], 63);
+        T_carry = T_next; t_carry = t_next;
+    }
 }
 
 // sigma MLP backward: dh = [trunc_exp gradient | colour MLP's gradient of geo], dh1 = (dh W2) * relu', denc = dh1 W1 in the grid
@@ -563,7 +654,7 @@ int sdn_train_layout(uint32_t N, uint32_t M, uint32_t max_steps, const int32_t *
     out->w_table = L.w_table; out->w_deform = L.w_deform; out->w_sigma0 = L.w_sigma0; out->w_sigma1 = L.w_sigma1; out->w_color = L.w_color;
     out->g_table = L.g_table; out->g_deform = L.g_deform; out->g_sigma0 = L.g_sigma0; out->g_sigma1 = L.g_sigma1; out->g_color = L.g_color;
     out->xyzs = L.pts; out->dirs = L.pts + (uint64_t)M * 12; out->deltas = L.pts + (uint64_t)M * 24; out->rays = L.rays;
-    out->sigmas = L.sigmas; out->rgbs = L.rgbs; out->weights_sum = L.weights_sum; out->depth = L.depth; out->image = L.image;
+    out->sigmas = L.sigmas; out->weights_sum = L.weights_sum; out->depth = L.depth; out->image = L.image;
     out->found_inf = L.hyper + offsetof(Hyper, found_inf);
     return 0;
 }
@@ -600,7 +691,7 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     // ---- rays -> samples (renderer.py:283-304) ------------------------------------------------------------------------------------
     hipLaunchKernelGGL(k_train_rays, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, F(L.noises), s->noises, N, s->noise_seed, s->perturb, s->counter, hyper);
     SDN_TRY(sdn_near_far_from_aabb(s->rays_o, s->rays_d, s->aabb, N, s->min_near, F(L.nears), F(L.fars), st));
-    if (hipMemsetAsync(ws + L.pts, 0, (L.gflat - L.pts) + (uint64_t)M * 16, st) != hipSuccess) return sdn_launch_status();
+    if (hipMemsetAsync(ws + L.pts, 0, (L.dh0 - L.pts) + (uint64_t)M * 2, st) != hipSuccess) return sdn_launch_status();
     if (s->mode != 0 && hipMemsetAsync(ws + L.g_table, 0, (uint64_t)s->grid_offsets[kLevels] * 4, st) != hipSuccess) return sdn_launch_status();
     float *xyzs = F(L.pts), *dirs = xyzs + (size_t)M * 3, *deltas = xyzs + (size_t)M * 6;
     SDN_TRY(sdn_march_rays_train(s->rays_o, s->rays_d, s->bitfield, s->bound, s->dt_gamma, s->max_steps, N, s->cascade, s->grid_size, M, F(L.nears),
@@ -620,20 +711,14 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     const SigmaFwd sf{H(L.grid_out), H(L.w_sigma0), H(L.w_sigma1), dirs, H(L.enc_rm), H(L.h1), H(L.hout), H(L.col_in), F(L.sigmas), M, s->density_scale};
     hipLaunchKernelGGL(k_train_sigma_fwd, dim3(sdn_div_up(M, 64u)), dim3(64), 0, st, sf);
     SDN_TRY(sdn_ffh::forward_packed(H(L.col_in), ws + L.pk_col_f, M, kColIn, kColW, kColL, ACT_RELU, H(L.col_hidden), H(L.col_out), st));
-    hipLaunchKernelGGL(k_train_rgb, dim3(sdn_div_up(M * 3u, 256u)), dim3(256), 0, st, H(L.col_out), M, F(L.rgbs));
-
-    // ---- compositing, loss, and their gradients (renderer.py:309-318, utils.py:85-125) -----------------------------------------------
-    SDN_TRY(sdn_composite_rays_train_forward(F(L.sigmas), F(L.rgbs), deltas, (const int32_t *)(ws + L.rays), M, N, s->T_thresh, F(L.weights_sum), F(L.depth),
-                                             F(L.image), st));
-    hipLaunchKernelGGL(k_train_loss, dim3(1), dim3(1024), 0, st, F(L.image), F(L.weights_sum), s->bg_color, s->bg_value, s->target, N, s->loss_scale, s->loss_out,
-                       F(L.grad_image), F(L.grad_ws), s->image_out);
-    float *g_sigmas = F(L.gflat), *g_rgbs = g_sigmas + M;
-    SDN_TRY(sdn_composite_rays_train_backward(F(L.grad_ws), F(L.grad_image), F(L.sigmas), F(L.rgbs), deltas, (const int32_t *)(ws + L.rays), F(L.weights_sum),
-                                              F(L.image), M, N, s->T_thresh, g_sigmas, g_rgbs, st));
+    // ---- compositing, loss, and their gradients (renderer.py:309-318, utils.py:85-125), one wave per ray ----------------------------
+    const CompositeArgs ca{F(L.sigmas), deltas, H(L.col_out), H(L.hout), (const int32_t *)(ws + L.rays), s->bg_color, s->target, s->loss_scale, F(L.weights_sum),
+                           F(L.depth), F(L.image), s->image_out, F(L.sq_err), H(L.dcol_out), H(L.dh0), M, N, s->T_thresh, s->bg_value, s->density_scale};
+    hipLaunchKernelGGL(k_train_composite_fwd, dim3(sdn_div_up(N, 4u)), dim3(256), 0, st, ca);
+    hipLaunchKernelGGL(k_train_loss, dim3(1), dim3(1024), 0, st, F(L.sq_err), N, s->loss_out);
 
     // ---- backward through the field ---------------------------------------------------------------------------------------------------
-    hipLaunchKernelGGL(k_train_colour_grad, dim3(sdn_div_up(M, 256u)), dim3(256), 0, st, F(L.gflat), H(L.col_out), H(L.hout), M, s->density_scale, H(L.dcol_out),
-                       H(L.dh0));
+    hipLaunchKernelGGL(k_train_composite_bwd, dim3(sdn_div_up(N, 4u)), dim3(256), 0, st, ca);
     SDN_TRY(sdn_ffh::backward_packed(H(L.dcol_out), ws + L.pk_col_b, H(L.col_hidden), M, kColIn, kColW, kColL, ACT_RELU, 1, H(L.col_bwd), H(L.dcol_in), st));
     const SigmaBwd sb{H(L.dh0), H(L.dcol_in), H(L.h1), H(L.w_sigma0), H(L.w_sigma1), H(L.dh), H(L.dh1), H(L.denc), M};
     hipLaunchKernelGGL(k_train_sigma_bwd, dim3(sdn_div_up(M, 64u)), dim3(64), 0, st, sb);

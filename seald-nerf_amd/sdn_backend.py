@@ -110,7 +110,7 @@ class SdnTrainStep(ctypes.Structure):
 class SdnTrainLayout(ctypes.Structure):
     """Mirror of `SdnTrainLayout` in include/sdn_hip.h."""
     _fields_ = [(n, ctypes.c_uint64) for n in ("total_bytes", "w_table", "w_deform", "w_sigma0", "w_sigma1", "w_color", "g_table", "g_deform",
-                                                "g_sigma0", "g_sigma1", "g_color", "xyzs", "dirs", "deltas", "rays", "sigmas", "rgbs",
+                                                "g_sigma0", "g_sigma1", "g_color", "xyzs", "dirs", "deltas", "rays", "sigmas",
                                                 "weights_sum", "depth", "image", "found_inf")]
 
 
