@@ -428,6 +428,8 @@ typedef struct SdnTrainStep {
     uint32_t N, M;                  /* rays; sample budget = mean_count rounded as raymarching.py:200-203 */
     /* scene */
     const uint8_t *bitfield;        /* occupancy slice of `time` (dnerf/renderer.py:285) */
+    const void *cull_grid;          /* optional: sdn_build_cull_grid(bitfield) kept by the caller (a slice is marched many times between two
+                                     * density-grid updates); NULL = built inside every step */
     const float *aabb;              /* device, [6] (aabb_train) */
     float bound, min_near, dt_gamma, density_scale, T_thresh;
     float time;                     /* frame time by value; time == 0 is the canonical frame: no deformation, and the

@@ -1540,30 +1540,42 @@ int sdn_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
                          uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears,
                          const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
                          const float *noises, void *scratch, void *stream) {
+    return sdn_int::march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises,
+                                     scratch, nullptr, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// prebuilt_cull: the cull grid of `grid` from sdn_build_cull_grid (a caller that marches the same occupancy slice step after step
+// keeps it), or nullptr: built here into the scratch
+int sdn_int::march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma, uint32_t max_steps, uint32_t N,
+                              uint32_t C, uint32_t H, uint32_t M, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
+                              int32_t *rays, int32_t *counter, const float *noises, void *scratch, const void *prebuilt_cull, hipStream_t st) {
     if (N == 0) return 0;
     if (!rays_o || !rays_d || !grid || !nears || !fars || !xyzs || !dirs || !deltas || !rays || !counter || !noises || !scratch)
         return SDN_E_BADARG;
-    if (C == 0 || C > 16 || H == 0 || max_steps == 0 || ((uintptr_t)scratch & 15u)) return SDN_E_BADARG;
-    hipStream_t st = (hipStream_t)stream;
+    if (C == 0 || C > 16 || H == 0 || max_steps == 0 || ((uintptr_t)scratch & 15u) || ((uintptr_t)prebuilt_cull & 15u)) return SDN_E_BADARG;
     uint32_t *num_steps = (uint32_t *)scratch;
     const uint32_t nb = sdn_div_up(N, kScanBlock);
     uint32_t *block_totals = num_steps + N;
     uint32_t *base_out = block_totals + nb;
     const uint64_t head = (train_scratch_words(N) * sizeof(uint32_t) + 15u) & ~(uint64_t)15u;
     const uint64_t cull_bytes = ((uint64_t)(kCullWords + 8u) * sizeof(uint32_t) + 15u) & ~(uint64_t)15u;
-    uint32_t *cull = (uint32_t *)((unsigned char *)scratch + head);
+    const uint32_t *cull = (const uint32_t *)((unsigned char *)scratch + head);
     float *sample_t = (float *)((unsigned char *)scratch + head + cull_bytes);
     const bool fast = fast_config(bound, C, H);
     const bool use_cull = fast && H == 128;
-    if (use_cull) {
-        int rc = sdn_int::build_cull(grid, cull, st);
+    if (use_cull && prebuilt_cull) {
+        cull = (const uint32_t *)prebuilt_cull;
+    } else if (use_cull) {
+        int rc = sdn_int::build_cull(grid, (uint32_t *)((unsigned char *)scratch + head), st);
         if (rc) return rc;
     }
     if (fast && dt_gamma == 0.0f && H <= 256u)   // constant step: one WAVE per ray (k_march_train_count_wave), same samples bit for bit
         hipLaunchKernelGGL(k_march_train_count_wave, dim3(sdn_div_up(N, 4u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, max_steps, N, H, nears,
-                           fars, noises, num_steps, use_cull ? (const uint32_t *)cull : nullptr, sample_t);
+                           fars, noises, num_steps, use_cull ? cull : nullptr, sample_t);
     else if (fast) hipLaunchKernelGGL(k_march_train_count<true>, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
-                                 max_steps, N, C, H, nears, fars, noises, num_steps, use_cull ? (const uint32_t *)cull : nullptr, sample_t);
+                                 max_steps, N, C, H, nears, fars, noises, num_steps, use_cull ? cull : nullptr, sample_t);
     else hipLaunchKernelGGL(k_march_train_count<false>, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
                             max_steps, N, C, H, nears, fars, noises, num_steps, (const uint32_t *)nullptr, sample_t);
     hipLaunchKernelGGL(k_scan_block_totals, dim3(nb), dim3(kScanBlock), 0, st, num_steps, N, block_totals);
@@ -1577,6 +1589,8 @@ int sdn_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
     hipLaunchKernelGGL(k_march_train_finish, dim3(1), dim3(64), 0, st, counter, base_out, N);
     return sdn_launch_status();
 }
+
+extern "C" {
 
 int sdn_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, uint32_t M,
                                      uint32_t N, float T_thresh, float *weights_sum, float *depth, float *image, void *stream) {

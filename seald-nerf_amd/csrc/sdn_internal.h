@@ -39,6 +39,9 @@ int loop_finish(uint32_t N, const float *nears, const float *fars, const float *
                 float *image_out, float *depth_out, hipStream_t st);
 int render_begin(const SdnRenderCtx *c, void *mailbox, uint32_t frame_tag, hipStream_t st);
 int build_cull(const uint8_t *bitfield, uint32_t *cull_bits, hipStream_t st);
+int march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C,
+                     uint32_t H, uint32_t M, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
+                     const float *noises, void *scratch, const void *prebuilt_cull, hipStream_t st);
 int build_cull_group(const FrameSel &fs, uint32_t *cull_bits, hipStream_t st);   // one cull grid per frame of the group
 int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count, const int32_t *state,
                       uint32_t M, const void *weights, const float *bias0, const void *table, const int32_t *offsets_host, float S,

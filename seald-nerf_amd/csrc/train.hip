@@ -694,8 +694,8 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     if (hipMemsetAsync(ws + L.pts, 0, (L.dh0 - L.pts) + (uint64_t)M * 2, st) != hipSuccess) return sdn_launch_status();
     if (s->mode != 0 && hipMemsetAsync(ws + L.g_table, 0, (uint64_t)s->grid_offsets[kLevels] * 4, st) != hipSuccess) return sdn_launch_status();
     float *xyzs = F(L.pts), *dirs = xyzs + (size_t)M * 3, *deltas = xyzs + (size_t)M * 6;
-    SDN_TRY(sdn_march_rays_train(s->rays_o, s->rays_d, s->bitfield, s->bound, s->dt_gamma, s->max_steps, N, s->cascade, s->grid_size, M, F(L.nears),
-                                 F(L.fars), xyzs, dirs, deltas, (int32_t *)(ws + L.rays), s->counter, F(L.noises), ws + L.march, st));
+    SDN_TRY(sdn_int::march_rays_train(s->rays_o, s->rays_d, s->bitfield, s->bound, s->dt_gamma, s->max_steps, N, s->cascade, s->grid_size, M, F(L.nears),
+                                      F(L.fars), xyzs, dirs, deltas, (int32_t *)(ws + L.rays), s->counter, F(L.noises), ws + L.march, s->cull_grid, st));
 
     // ---- this step's packed weights (both directions of both fused MLPs, one launch) ------------------------------------------------
     const sdn_ffh::PackJob packs[4] = {{ws + L.w_deform, ws + L.pk_def_f, kDefIn, kDefW, kDefL, 0, 1}, {ws + L.w_deform, ws + L.pk_def_b, kDefIn, kDefW, kDefL, 1, 0},

@@ -82,6 +82,7 @@ class NativeTrainStep:
         self.ema_decay, self.ema_updates = ema_decay, 0
         self.ema_shadow = [p.detach().clone() for p in self.params] if ema_decay is not None else None
         self.step_count, self._M, self._ws, self._rec = 0, None, None, None
+        self._cull_cache, self._cull_epoch = {}, None
         self.noises = None          # optional [n_rays] f32 device tensor: the per-ray offsets of the next steps (instead of the generator)
         self._lr_of = {}
         for g in optimizer.param_groups:
@@ -123,6 +124,21 @@ class NativeTrainStep:
         self._rec, self._M = r, M
         self.refresh()
 
+    def _cull_grid(self, t_idx):
+        """The marcher's coarse skip grid of one occupancy slice, kept until the density grid is updated again (`iter_density` counts
+        the updates, dnerf/renderer.py:555)."""
+        m = self.model
+        if int(m.grid_size) != 128 or int(m.cascade) != 1:
+            return None
+        if self._cull_epoch != m.iter_density:
+            self._cull_cache, self._cull_epoch = {}, m.iter_density
+        hit = self._cull_cache.get(t_idx)
+        if hit is None:
+            hit = torch.empty(int(_sdn.lib.sdn_cull_grid_bytes()), dtype=torch.uint8, device=self.device)
+            _sdn.check(_sdn.lib.sdn_build_cull_grid(m.density_bitfield[t_idx].data_ptr(), 128, hit.data_ptr(), _sdn.stream()), "build_cull_grid")
+            self._cull_cache[t_idx] = hit
+        return hit.data_ptr()
+
     def refresh(self):
         """Re-derive the fp16 copies the kernels read from the fp32 parameters (after a checkpoint load, an eager step, ...)."""
         if self._rec is None:
@@ -158,6 +174,7 @@ class NativeTrainStep:
         t_idx = int(min(max(np.floor(np.float32(self.time) * np.float32(T)), 0), T - 1))   # dnerf/renderer.py:285
         r.time = self.time
         r.bitfield = m.density_bitfield[t_idx].data_ptr()
+        r.cull_grid = self._cull_grid(t_idx)
         counter = m.step_counter[m.local_step % 16]
         r.counter = counter.data_ptr()
         if isinstance(self.bg_color, torch.Tensor):

@@ -95,7 +95,7 @@ class SdnTrainParam(ctypes.Structure):
 class SdnTrainStep(ctypes.Structure):
     """Mirror of `SdnTrainStep` in include/sdn_hip.h (field order and types must match)."""
     _fields_ = ([(n, _vp) for n in ("rays_o", "rays_d", "target", "bg_color")]
-                + [("bg_value", _f32), ("N", _u32), ("M", _u32), ("bitfield", _vp), ("aabb", _vp)]
+                + [("bg_value", _f32), ("N", _u32), ("M", _u32), ("bitfield", _vp), ("cull_grid", _vp), ("aabb", _vp)]
                 + [(n, _f32) for n in ("bound", "min_near", "dt_gamma", "density_scale", "T_thresh", "time")]
                 + [(n, _u32) for n in ("cascade", "grid_size", "max_steps")]
                 + [("perturb", ctypes.c_int32), ("noise_seed", ctypes.c_uint64), ("noises", _vp), ("counter", _vp),
