@@ -178,12 +178,52 @@ __global__ void __launch_bounds__(256) k_train_xdef(const float *__restrict__ xy
     xdef[t] = (v + bound) / (2 * bound);
 }
 
-__device__ __forceinline__ float dot2(h2 a, h2 b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
+// ---- the sigma MLP on the matrix cores ------------------------------------------------------------------------------------------------
+// 32 -> 64 -> 16, 3 072 MACs per sample: one wave = 32 samples = N of v_mfma_f32_32x32x16_f16, weights are the A operand (M = output
+// features), 4 + 4 MFMAs forward, 2 + 4 backward.  As in the fused MLP kernels (ffmlp_kernels.h) a layer's accumulator (feature
+// rows 8(i>>2) + 4h + (i&3) of tile Mt in registers, the sample on the lane) converts in place into the next layer's B fragments,
+// and rows leave / enter as 16-byte pieces through the half-wave exchange.  (A first version ran one LANE per sample on v_dot2 with
+// the weights broadcast from LDS: 22 us forward / 13 us backward at 9 000 samples -- a chain of 1 536 dependent dot products per
+// lane at one wave per CU.)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void half_wave_exchange(uint32_t &a, uint32_t &b) {      // lanes 32-63 of a <-> lanes 0-31 of b (whole wave active)
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+// this lane's 4-feature runs of two neighbouring 8-feature groups <-> the 16 contiguous bytes of the row it stores / loaded
+__device__ __forceinline__ uint4 runs_to_row16(h4 g0, h4 g1) {
+    uint2 a = __builtin_bit_cast(uint2, g0), b = __builtin_bit_cast(uint2, g1);
+    half_wave_exchange(a.x, b.x);
+    half_wave_exchange(a.y, b.y);
+    return uint4{a.x, a.y, b.x, b.y};
+}
+__device__ __forceinline__ void row16_to_runs(uint4 v, h4 &g0, h4 &g1) {
+    uint2 a{v.x, v.y}, b{v.z, v.w};
+    half_wave_exchange(a.x, b.x);
+    half_wave_exchange(a.y, b.y);
+    g0 = __builtin_bit_cast(h4, a);
+    g1 = __builtin_bit_cast(h4, b);
+}
+__device__ __forceinline__ h8 join(h4 a, h4 b) { return h8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+// A fragment of a row-major weight matrix W[rows, ld]: lane (m, h) holds W[m][16 s + 8 (j >> 2) + 4 h + (j & 3)], rows >= n_rows are zero
+__device__ __forceinline__ h8 a_frag(const _Float16 *w, uint32_t ld, uint32_t n_rows, uint32_t m, uint32_t s, uint32_t h) {
+    if (m >= n_rows) return h8{0, 0, 0, 0, 0, 0, 0, 0};
+    const _Float16 *p = w + (size_t)m * ld + 16 * s + 4 * h;
+    return join(*reinterpret_cast<const h4 *>(p), *reinterpret_cast<const h4 *>(p + 8));
+}
+// A fragment of the TRANSPOSE: lane (m, h) holds W[16 s + 8 (j >> 2) + 4 h + (j & 3)][m]
+__device__ __forceinline__ h8 a_frag_t(const _Float16 *w, uint32_t ld, uint32_t m, uint32_t s, uint32_t h) {
+    h8 v;
+    #pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = w[(size_t)(16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) * ld + m];
+    return v;
+}
 
-// sigma MLP forward (32 -> 64 -> 16, ReLU), trunc_exp (activation.py:5-17) x density_scale, SH(d, 4), and the colour MLP's input
-// row [SH | geo | 0].  One lane per sample: the two weight matrices (6 KiB) sit in LDS and every lane reads the same address
-// (broadcast); fp16 products accumulate in fp32 (v_dot2_f32_f16) and round to fp16 once per layer, as the GEMMs of the Linear
-// layers do.  3 072 MACs per sample -- not worth a matrix-core kernel at 9 000 samples.
+// forward: grid features -> sigma MLP -> trunc_exp (activation.py:5-17) x density_scale; SH(d, 4); the colour MLP's input row
+// [SH 16 | sigma-MLP output 16] (the log-density column meets a zero weight column: `w_color` is kept in that order)
 struct SigmaFwd {
     const _Float16 *grid_out;   // [16][M][2]
     const _Float16 *w1, *w2;    // [64,32], [16,64]
@@ -195,51 +235,56 @@ struct SigmaFwd {
 };
 
 __global__ void __launch_bounds__(64) k_train_sigma_fwd(SigmaFwd P) {
-    __shared__ h2 s_w1[kSigW][kSigIn / 2];
-    __shared__ h2 s_w2[kSigOut][kSigW / 2];
-    for (uint32_t i = threadIdx.x; i < kSigW * kSigIn / 2; i += 64) (&s_w1[0][0])[i] = reinterpret_cast<const h2 *>(P.w1)[i];
-    for (uint32_t i = threadIdx.x; i < kSigOut * kSigW / 2; i += 64) (&s_w2[0][0])[i] = reinterpret_cast<const h2 *>(P.w2)[i];
-    __syncthreads();
-    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= P.M) return;
-    h2 x[kSigIn / 2];
+    const uint32_t lane = threadIdx.x, n = lane & 31u, h = lane >> 5;
+    const uint32_t b_raw = blockIdx.x * 32 + n;
+    const bool live = b_raw < P.M;
+    const uint32_t b = live ? b_raw : P.M - 1;
+    h8 B1[2];
     #pragma unroll
-    for (uint32_t l = 0; l < kLevels; l++) x[l] = reinterpret_cast<const h2 *>(P.grid_out)[(size_t)l * P.M + b];
-    h8 *erow = reinterpret_cast<h8 *>(P.enc_rm + (size_t)b * kSigIn);
-    #pragma unroll
-    for (int q = 0; q < 4; q++) erow[q] = h8{x[4 * q][0], x[4 * q][1], x[4 * q + 1][0], x[4 * q + 1][1], x[4 * q + 2][0], x[4 * q + 2][1], x[4 * q + 3][0], x[4 * q + 3][1]};
-    h2 hid[kSigW / 2];
-    #pragma unroll
-    for (uint32_t j = 0; j < kSigW; j++) {
-        float acc = 0.0f;
+    for (uint32_t s = 0; s < 2; s++) {
+        h2 e[4];
         #pragma unroll
-        for (uint32_t k = 0; k < kSigIn / 2; k++) acc = dot2(s_w1[j][k], x[k], acc);
-        _Float16 v = (_Float16)acc;
-        v = v > (_Float16)0 ? v : (_Float16)0;
-        hid[j >> 1][j & 1] = v;
+        for (uint32_t u = 0; u < 2; u++)
+            #pragma unroll
+            for (uint32_t v = 0; v < 2; v++) e[2 * u + v] = reinterpret_cast<const h2 *>(P.grid_out)[(size_t)(8 * s + 4 * u + 2 * h + v) * P.M + b];
+        B1[s] = h8{e[0][0], e[0][1], e[1][0], e[1][1], e[2][0], e[2][1], e[3][0], e[3][1]};
+        const uint4 row16 = runs_to_row16(h4{e[0][0], e[0][1], e[1][0], e[1][1]}, h4{e[2][0], e[2][1], e[3][0], e[3][1]});
+        if (live) *reinterpret_cast<uint4 *>(P.enc_rm + (size_t)b * kSigIn + 16 * s + 8 * h) = row16;
     }
-    h8 *hrow = reinterpret_cast<h8 *>(P.h1 + (size_t)b * kSigW);
+    h8 B2[4];
     #pragma unroll
-    for (int q = 0; q < 8; q++) hrow[q] = h8{hid[4 * q][0], hid[4 * q][1], hid[4 * q + 1][0], hid[4 * q + 1][1], hid[4 * q + 2][0], hid[4 * q + 2][1], hid[4 * q + 3][0], hid[4 * q + 3][1]};
-    _Float16 o[kSigOut];
-    #pragma unroll
-    for (uint32_t r = 0; r < kSigOut; r++) {
-        float acc = 0.0f;
+    for (uint32_t Mt = 0; Mt < 2; Mt++) {
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         #pragma unroll
-        for (uint32_t k = 0; k < kSigW / 2; k++) acc = dot2(s_w2[r][k], hid[k], acc);
-        o[r] = (_Float16)acc;
+        for (uint32_t s = 0; s < 2; s++) acc = mfma16(a_frag(P.w1, kSigIn, kSigW, 32 * Mt + n, s, h), B1[s], acc);
+        _Float16 v[16];
+        #pragma unroll
+        for (int i = 0; i < 16; i++) { const _Float16 x = (_Float16)acc[i]; v[i] = x > (_Float16)0 ? x : (_Float16)0; }
+        #pragma unroll
+        for (uint32_t p = 0; p < 2; p++) {
+            const h4 g0{v[8 * p], v[8 * p + 1], v[8 * p + 2], v[8 * p + 3]}, g1{v[8 * p + 4], v[8 * p + 5], v[8 * p + 6], v[8 * p + 7]};
+            B2[2 * Mt + p] = join(g0, g1);
+            const uint4 row16 = runs_to_row16(g0, g1);
+            if (live) *reinterpret_cast<uint4 *>(P.h1 + (size_t)b * kSigW + 32 * Mt + 16 * p + 8 * h) = row16;
+        }
     }
-    h8 *orow = reinterpret_cast<h8 *>(P.hout + (size_t)b * kSigOut);
-    orow[0] = h8{o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]};
-    orow[1] = h8{o[8], o[9], o[10], o[11], o[12], o[13], o[14], o[15]};
-    P.sigmas[b] = P.density_scale * expf((float)o[0]);
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    #pragma unroll
+    for (uint32_t s = 0; s < 4; s++) acc = mfma16(a_frag(P.w2, kSigW, kSigOut, n, s, h), B2[s], acc);
+    // rows 0..15 of the output tile: this lane holds o[4h .. 4h+3] (i = 0..3) and o[8+4h .. 8+4h+3] (i = 4..7)
+    const h4 o0{(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]}, o1{(_Float16)acc[4], (_Float16)acc[5], (_Float16)acc[6], (_Float16)acc[7]};
+    const uint4 orow = runs_to_row16(o0, o1);
     float sh[16], u0[1], u1[1], u2[1];
     sh_eval<4, false>(P.dirs[(size_t)b * 3], P.dirs[(size_t)b * 3 + 1], P.dirs[(size_t)b * 3 + 2], sh, u0, u1, u2);
-    h8 *crow = reinterpret_cast<h8 *>(P.col_in + (size_t)b * kColIn);
-    crow[0] = h8{(_Float16)sh[0], (_Float16)sh[1], (_Float16)sh[2], (_Float16)sh[3], (_Float16)sh[4], (_Float16)sh[5], (_Float16)sh[6], (_Float16)sh[7]};
-    crow[1] = h8{(_Float16)sh[8], (_Float16)sh[9], (_Float16)sh[10], (_Float16)sh[11], (_Float16)sh[12], (_Float16)sh[13], (_Float16)sh[14], (_Float16)sh[15]};
-    crow[2] = h8{o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8]};
-    crow[3] = h8{o[9], o[10], o[11], o[12], o[13], o[14], o[15], (_Float16)0};
+    if (live) {
+        *reinterpret_cast<uint4 *>(P.hout + (size_t)b * kSigOut + 8 * h) = orow;
+        *reinterpret_cast<uint4 *>(P.col_in + (size_t)b * kColIn + 16 + 8 * h) = orow;
+        h8 shh;
+        #pragma unroll
+        for (int j = 0; j < 8; j++) shh[j] = (_Float16)(h ? sh[8 + j] : sh[j]);
+        *reinterpret_cast<h8 *>(P.col_in + (size_t)b * kColIn + 8 * h) = shh;
+        if (h == 0) P.sigmas[b] = P.density_scale * expf((float)o0[0]);
+    }
 }
 
 __device__ __forceinline__ _Float16 sigmoid16(_Float16 c) { return (_Float16)(1.0f / (1.0f + expf(-(float)c))); }
@@ -401,8 +446,8 @@ __global__ void __launch_bounds__(256) k_train_composite_bwd(CompositeArgs P) {
     }
 }
 
-// sigma MLP backward: dh = [trunc_exp gradient | colour MLP's gradient of geo], dh1 = (dh W2) * relu', denc = dh1 W1 in the grid
-// encoder's [level][sample][2] layout; dh and dh1 also row-major for the weight-gradient products.
+// sigma MLP backward: dh = [trunc_exp gradient | colour MLP's gradient of columns 17..31 of its input], dh1 = (W2^T dh) * relu',
+// denc = W1^T dh1 in the grid encoder's [level][sample][2] layout; dh and dh1 also row-major for the weight-gradient products.
 struct SigmaBwd {
     const _Float16 *dh0, *dcol_in, *h1, *w1, *w2;
     _Float16 *dh, *dh1, *denc;
@@ -410,49 +455,48 @@ struct SigmaBwd {
 };
 
 __global__ void __launch_bounds__(64) k_train_sigma_bwd(SigmaBwd P) {
-    __shared__ h2 s_w2t[kSigW][kSigOut / 2];     // [j][o/2] = (W2[o][j], W2[o+1][j])
-    __shared__ h2 s_w1t[kSigIn][kSigW / 2];      // [k][j/2] = (W1[j][k], W1[j+1][k])
-    for (uint32_t i = threadIdx.x; i < kSigW * kSigOut / 2; i += 64) {
-        const uint32_t j = i / (kSigOut / 2), o = 2 * (i % (kSigOut / 2));
-        s_w2t[j][o >> 1] = h2{P.w2[o * kSigW + j], P.w2[(o + 1) * kSigW + j]};
-    }
-    for (uint32_t i = threadIdx.x; i < kSigIn * kSigW / 2; i += 64) {
-        const uint32_t k = i / (kSigW / 2), j = 2 * (i % (kSigW / 2));
-        s_w1t[k][j >> 1] = h2{P.w1[j * kSigIn + k], P.w1[(j + 1) * kSigIn + k]};
-    }
-    __syncthreads();
-    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= P.M) return;
-    const h8 *ci = reinterpret_cast<const h8 *>(P.dcol_in + (size_t)b * kColIn);
-    const h8 g0 = ci[2], g1 = ci[3];             // columns 16..31 of the colour MLP's input gradient: geo 0..14, pad
-    const _Float16 d0 = P.dh0[b];
-    const h8 da = h8{d0, g0[0], g0[1], g0[2], g0[3], g0[4], g0[5], g0[6]}, db = h8{g0[7], g1[0], g1[1], g1[2], g1[3], g1[4], g1[5], g1[6]};
-    h8 *dhrow = reinterpret_cast<h8 *>(P.dh + (size_t)b * kSigOut);
-    dhrow[0] = da; dhrow[1] = db;
-    const h2 dh[8] = {h2{da[0], da[1]}, h2{da[2], da[3]}, h2{da[4], da[5]}, h2{da[6], da[7]}, h2{db[0], db[1]}, h2{db[2], db[3]}, h2{db[4], db[5]}, h2{db[6], db[7]}};
-    const h8 *hrow = reinterpret_cast<const h8 *>(P.h1 + (size_t)b * kSigW);
-    h2 d1[kSigW / 2];
+    const uint32_t lane = threadIdx.x, n = lane & 31u, h = lane >> 5;
+    const uint32_t b_raw = blockIdx.x * 32 + n;
+    const bool live = b_raw < P.M;
+    const uint32_t b = live ? b_raw : P.M - 1;
+    // columns 16..31 of the colour MLP's input gradient are d(sigma-MLP output); column 16 (log density: zero weights there) is
+    // replaced by the compositing's gradient through trunc_exp
+    uint4 raw = *reinterpret_cast<const uint4 *>(P.dcol_in + (size_t)b * kColIn + 16 + 8 * h);
+    if (h == 0) raw.x = (raw.x & 0xFFFF0000u) | (uint32_t)__builtin_bit_cast(unsigned short, P.dh0[b]);
+    if (live) *reinterpret_cast<uint4 *>(P.dh + (size_t)b * kSigOut + 8 * h) = raw;
+    h4 d0, d1;
+    row16_to_runs(raw, d0, d1);
+    const h8 Bd = join(d0, d1);
+    h8 B2[4];
     #pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const h8 hv = hrow[q];
+    for (uint32_t Mt = 0; Mt < 2; Mt++) {
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc = mfma16(a_frag_t(P.w2, kSigW, 32 * Mt + n, 0, h), Bd, acc);
         #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const uint32_t j = 8 * q + e;
-            float acc = 0.0f;
+        for (uint32_t p = 0; p < 2; p++) {
+            h4 f0, f1;
+            row16_to_runs(*reinterpret_cast<const uint4 *>(P.h1 + (size_t)b * kSigW + 32 * Mt + 16 * p + 8 * h), f0, f1);
+            h4 g0, g1;
             #pragma unroll
-            for (uint32_t o = 0; o < kSigOut / 2; o++) acc = dot2(s_w2t[j][o], dh[o], acc);
-            d1[j >> 1][j & 1] = hv[e] > (_Float16)0 ? (_Float16)acc : (_Float16)0;
+            for (int e = 0; e < 4; e++) {
+                g0[e] = f0[e] > (_Float16)0 ? (_Float16)acc[8 * p + e] : (_Float16)0;
+                g1[e] = f1[e] > (_Float16)0 ? (_Float16)acc[8 * p + 4 + e] : (_Float16)0;
+            }
+            B2[2 * Mt + p] = join(g0, g1);
+            const uint4 row16 = runs_to_row16(g0, g1);
+            if (live) *reinterpret_cast<uint4 *>(P.dh1 + (size_t)b * kSigW + 32 * Mt + 16 * p + 8 * h) = row16;
         }
     }
-    h8 *d1row = reinterpret_cast<h8 *>(P.dh1 + (size_t)b * kSigW);
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     #pragma unroll
-    for (int q = 0; q < 8; q++) d1row[q] = h8{d1[4 * q][0], d1[4 * q][1], d1[4 * q + 1][0], d1[4 * q + 1][1], d1[4 * q + 2][0], d1[4 * q + 2][1], d1[4 * q + 3][0], d1[4 * q + 3][1]};
-    #pragma unroll
-    for (uint32_t l = 0; l < kLevels; l++) {
-        float a0 = 0.0f, a1 = 0.0f;
+    for (uint32_t s = 0; s < 4; s++) acc = mfma16(a_frag_t(P.w1, kSigIn, n, s, h), B2[s], acc);
+    // row m = 8 q + 4 h + (i & 3) of the tile is grid feature m = 2 level + channel
+    if (live) {
         #pragma unroll
-        for (uint32_t j = 0; j < kSigW / 2; j++) { a0 = dot2(s_w1t[2 * l][j], d1[j], a0); a1 = dot2(s_w1t[2 * l + 1][j], d1[j], a1); }
-        reinterpret_cast<h2 *>(P.denc)[(size_t)l * P.M + b] = h2{(_Float16)a0, (_Float16)a1};
+        for (uint32_t q = 0; q < 4; q++) {
+            reinterpret_cast<h2 *>(P.denc)[(size_t)(4 * q + 2 * h) * P.M + b] = h2{(_Float16)acc[4 * q], (_Float16)acc[4 * q + 1]};
+            reinterpret_cast<h2 *>(P.denc)[(size_t)(4 * q + 2 * h + 1) * P.M + b] = h2{(_Float16)acc[4 * q + 2], (_Float16)acc[4 * q + 3]};
+        }
     }
 }
 
@@ -535,7 +579,7 @@ struct AdamSeg {
     float *p, *m, *v, *ema;
     _Float16 *g;        // fp16 gradient, element (r, c) at r * ld + c
     _Float16 *w16;      // fp16 copy, same layout
-    uint32_t n, cols, ld;
+    uint32_t n, cols, ld, split;      // columns >= split sit one column further right (the colour MLP's input layer: [SH 16 | 0 | geo 15])
     uint32_t lr_idx, group, zero_grad, frozen, blk_begin;
 };
 struct AdamArgs {
@@ -563,7 +607,7 @@ __global__ void __launch_bounds__(256) k_train_adam(AdamArgs A) {
         const uint32_t i = base + 256u * k;
         if (i >= S.n) break;
         uint32_t j = i;
-        if (S.cols != S.ld) { const uint32_t r = i / S.cols; j = r * S.ld + (i - r * S.cols); }
+        if (S.cols != S.ld) { const uint32_t r = i / S.cols, c = i - r * S.cols; j = r * S.ld + c + (c >= S.split ? 1u : 0u); }
         float p = S.p[i];
         if (update) {
             const float g = (float)S.g[j] * inv_scale;
@@ -591,7 +635,7 @@ __global__ void __launch_bounds__(256) k_train_copy16(AdamArgs A) {
         const uint32_t i = base + 256u * k;
         if (i >= S.n) break;
         uint32_t j = i;
-        if (S.cols != S.ld) { const uint32_t r = i / S.cols; j = r * S.ld + (i - r * S.cols); }
+        if (S.cols != S.ld) { const uint32_t r = i / S.cols, c = i - r * S.cols; j = r * S.ld + c + (c >= S.split ? 1u : 0u); }
         S.w16[j] = (_Float16)S.p[i];
     }
 }
@@ -618,7 +662,7 @@ uint32_t build_segments(const SdnTrainStep *s, const Layout &L, AdamArgs &A) {
         AdamSeg &S = A.seg[i];
         S.p = q.param; S.m = q.exp_avg; S.v = q.exp_avg_sq; S.ema = q.ema;
         S.g = H(pl[i].g) + pl[i].off; S.w16 = H(pl[i].w) + pl[i].off;
-        S.n = pl[i].rows * pl[i].cols; S.cols = pl[i].cols; S.ld = pl[i].ld;
+        S.n = pl[i].rows * pl[i].cols; S.cols = pl[i].cols; S.ld = pl[i].ld; S.split = i == 11 ? 16u : 0xFFFFFFFFu;
         S.lr_idx = pl[i].lr; S.group = pl[i].group; S.zero_grad = i == 0; S.frozen = 0; S.blk_begin = blk;
         blk += sdn_div_up(S.n, 1024u);
     }
@@ -709,7 +753,7 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     SDN_TRY(sdn_grid_encode_forward(F(L.xdef), ws + L.w_table, s->grid_offsets, ws + L.grid_out, M, 3, 2, kLevels, s->grid_S, s->grid_H, ws + L.dy_dx, 1, 0, 0,
                                     SDN_F16, st));
     const SigmaFwd sf{H(L.grid_out), H(L.w_sigma0), H(L.w_sigma1), dirs, H(L.enc_rm), H(L.h1), H(L.hout), H(L.col_in), F(L.sigmas), M, s->density_scale};
-    hipLaunchKernelGGL(k_train_sigma_fwd, dim3(sdn_div_up(M, 64u)), dim3(64), 0, st, sf);
+    hipLaunchKernelGGL(k_train_sigma_fwd, dim3(sdn_div_up(M, 32u)), dim3(64), 0, st, sf);
     SDN_TRY(sdn_ffh::forward_packed(H(L.col_in), ws + L.pk_col_f, M, kColIn, kColW, kColL, ACT_RELU, H(L.col_hidden), H(L.col_out), st));
     // ---- compositing, loss, and their gradients (renderer.py:309-318, utils.py:85-125), one wave per ray ----------------------------
     const CompositeArgs ca{F(L.sigmas), deltas, H(L.col_out), H(L.hout), (const int32_t *)(ws + L.rays), s->bg_color, s->target, s->loss_scale, F(L.weights_sum),
@@ -721,7 +765,7 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     hipLaunchKernelGGL(k_train_composite_bwd, dim3(sdn_div_up(N, 4u)), dim3(256), 0, st, ca);
     SDN_TRY(sdn_ffh::backward_packed(H(L.dcol_out), ws + L.pk_col_b, H(L.col_hidden), M, kColIn, kColW, kColL, ACT_RELU, 1, H(L.col_bwd), H(L.dcol_in), st));
     const SigmaBwd sb{H(L.dh0), H(L.dcol_in), H(L.h1), H(L.w_sigma0), H(L.w_sigma1), H(L.dh), H(L.dh1), H(L.denc), M};
-    hipLaunchKernelGGL(k_train_sigma_bwd, dim3(sdn_div_up(M, 64u)), dim3(64), 0, st, sb);
+    hipLaunchKernelGGL(k_train_sigma_bwd, dim3(sdn_div_up(M, 32u)), dim3(64), 0, st, sb);
     SDN_TRY(sdn_grid_encode_backward(ws + L.denc, F(L.xdef), s->grid_offsets, ws + L.g_table, M, 3, 2, kLevels, s->grid_S, s->grid_H, zero_deform ? nullptr : ws + L.dy_dx,
                                      zero_deform ? nullptr : ws + L.dx16, 1, 0, 0, SDN_F16, st));
     sdn_ffh::DwJob jobs[16];

@@ -56,8 +56,10 @@ def _native_grads(step, model):
     g = {"encoder.embeddings": step.view("g_table", torch.float16, (rows, 2)).float()}
     for i, w in enumerate(_flat_to_layers(step.view("g_deform", torch.float16, (128 * 80 + 6 * 128 * 128 + 16 * 128,)), 76, 80, 128, 7, 3)):
         g[f"deform_net.{i}.weight"] = w.float()
-    for i, w in enumerate(_flat_to_layers(step.view("g_color", torch.float16, (64 * 32 + 64 * 64 + 16 * 64,)), 31, 32, 64, 2, 3)):
-        g[f"color_net.{i}.weight"] = w.float()
+    # the colour MLP's input layer is kept as [SH 16 | one zero column under the log-density | geo 15] (csrc/train.hip: the input row is
+    # [SH | sigma-MLP output])
+    for i, w in enumerate(_flat_to_layers(step.view("g_color", torch.float16, (64 * 32 + 64 * 64 + 16 * 64,)), 32, 32, 64, 2, 3)):
+        g[f"color_net.{i}.weight"] = (torch.cat([w[:, :16], w[:, 17:]], dim=1) if i == 0 else w).float()
     g["sigma_net.0.weight"] = step.view("g_sigma0", torch.float16, (64, 32)).float()
     g["sigma_net.1.weight"] = step.view("g_sigma1", torch.float16, (16, 64)).float()
     return g
