@@ -470,7 +470,24 @@ __global__ void __launch_bounds__(256) k_march_train_count(const float *__restri
 // ---------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float lane_lattice(float base, float dt, uint32_t lane, float &next_base) {
     // L_{lane} of the lattice starting at base, by `lane` successive additions (float addition is not associative: the values
-    // must come from the recurrence); also returns L_64
+    // must come from the recurrence); also returns L_64.
+    // Closed form for the common case.  While L stays in one binade every L_k is a multiple of the binade's ulp U, so
+    // fl(L_k + dt) = L_k + c with the SAME c = round(dt / U) U for every k -- unless dt / U sits exactly between two integers (a tie
+    // rounds to even, which depends on L_k).  Then L_k = base + k c exactly (k c and the sum are multiples of U below 2^24 U).  All
+    // conditions are wave-uniform; anything else (binade crossing inside the window, a tie, a tiny base) takes the recurrence.
+    {
+        const float first = base + dt;
+        const float c = first - base;                               // exact (Sterbenz-like: both multiples of U, |c| << base)
+        const float err = dt - c;                                   // rounding error of base + dt (FastTwoSum, exact for base >= dt)
+        const float last = base + 64.0f * c;
+        const uint32_t eb = __float_as_uint(base) >> 23, el = __float_as_uint(last) >> 23;     // sign bit clear: t > 0
+        const bool normal = base >= dt && dt > 0.0f && eb > 30u && eb < 255u;
+        const float half_ulp = __uint_as_float((eb - 24u) << 23), c_cap = __uint_as_float((eb - 5u) << 23);   // U / 2, 2^18 U
+        if (normal && eb == el && fabsf(err) != half_ulp && c < c_cap) {
+            next_base = last;
+            return base + (float)lane * c;
+        }
+    }
     float v = base, mine = base;
     #pragma unroll 8
     for (uint32_t i = 0; i < 64; i++) {
