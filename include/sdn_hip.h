@@ -462,7 +462,12 @@ typedef struct SdnTrainStep {
     void *workspace;                /* sdn_train_layout().total_bytes, 256-byte aligned; persistent (holds the fp16 copies of the
                                      * parameters that the kernels read): call sdn_train_refresh once before the first step and
                                      * after every outside change of the parameters */
-    int32_t mode;                   /* 0: full step; 1: forward + backward only (gradients stay in the workspace) */
+    int32_t mode;                   /* 0: full step; 1: forward + backward only (gradients stay in the workspace); 2: optimizer only, on
+                                     * the gradients in the workspace.  Data-parallel training is 1 -> all-reduce of the fp16 gradient
+                                     * buffers (g_table, g_deform .. g_color) -> 2 with grad_divisor = world size */
+    int32_t keep_deform;            /* modes 1 / 2 under data parallelism: the deformation MLP takes part in the optimizer step whatever
+                                     * `time` is (another rank's batch may carry its gradient); mode 1 then clears its gradient at time == 0 */
+    float grad_divisor;             /* gradients are divided by this on top of the loss scale (0 is read as 1) */
     int32_t reserved_;
 } SdnTrainStep;
 

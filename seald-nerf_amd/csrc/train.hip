@@ -539,6 +539,7 @@ struct Prologue {
     float growth, backoff;
     uint32_t interval;
     int deform_active;
+    float divisor;
 };
 
 // One thread: the skip decision, bias corrections in double as torch's Adam computes them on the host (adam.py _single_tensor_adam:
@@ -548,7 +549,7 @@ __global__ void k_train_prologue(Prologue P) {
     const bool found = h->found_inf != 0.0f;
     const float scale = *P.scale;
     h->skip = found ? 1 : 0;
-    h->inv_scale = (float)(1.0 / (double)scale);
+    h->inv_scale = (float)(1.0 / ((double)scale * (double)P.divisor));
     if (!found) {
         P.steps[0] += 1.0f;
         if (P.deform_active) P.steps[1] += 1.0f;
@@ -672,10 +673,11 @@ uint32_t build_segments(const SdnTrainStep *s, const Layout &L, AdamArgs &A) {
 
 bool step_ok(const SdnTrainStep *s) {
     if (!s || !s->workspace || ((uintptr_t)s->workspace & 255u)) return false;
-    if (!s->rays_o || !s->rays_d || !s->target || !s->bitfield || !s->aabb || !s->counter || !s->loss_out) return false;
+    if (s->mode < 0 || s->mode > 2) return false;
+    if (s->mode != 2 && (!s->rays_o || !s->rays_d || !s->target || !s->bitfield || !s->aabb || !s->counter || !s->loss_out)) return false;
     if (s->N == 0 || s->M == 0 || s->max_steps == 0 || s->bound <= 0) return false;
     for (int i = 0; i < SDN_TRAIN_N_PARAMS; i++) if (!s->params[i].param) return false;
-    if (s->mode == 0) {
+    if (s->mode != 1) {
         if (!s->adam_steps || !s->loss_scale || !s->growth_tracker) return false;
         for (int i = 0; i < SDN_TRAIN_N_PARAMS; i++) if (!s->params[i].exp_avg || !s->params[i].exp_avg_sq) return false;
     } else if (!s->loss_scale) {
@@ -729,14 +731,16 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     auto H = [&](uint64_t off) { return (_Float16 *)(ws + off); };
     Hyper *hyper = (Hyper *)(ws + L.hyper);
     const int zero_deform = s->time == 0.0f;
+    const int freeze_deform = zero_deform && !s->keep_deform;
     int rc;
     #define SDN_TRY(x) do { rc = (x); if (rc) return rc; } while (0)
+    if (s->mode != 2) {
 
     // ---- rays -> samples (renderer.py:283-304) ------------------------------------------------------------------------------------
     hipLaunchKernelGGL(k_train_rays, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, F(L.noises), s->noises, N, s->noise_seed, s->perturb, s->counter, hyper);
     SDN_TRY(sdn_near_far_from_aabb(s->rays_o, s->rays_d, s->aabb, N, s->min_near, F(L.nears), F(L.fars), st));
     if (hipMemsetAsync(ws + L.pts, 0, (L.dh0 - L.pts) + (uint64_t)M * 2, st) != hipSuccess) return sdn_launch_status();
-    if (s->mode != 0 && hipMemsetAsync(ws + L.g_table, 0, (uint64_t)s->grid_offsets[kLevels] * 4, st) != hipSuccess) return sdn_launch_status();
+    if (s->mode == 1 && hipMemsetAsync(ws + L.g_table, 0, (uint64_t)s->grid_offsets[kLevels] * 4, st) != hipSuccess) return sdn_launch_status();
     float *xyzs = F(L.pts), *dirs = xyzs + (size_t)M * 3, *deltas = xyzs + (size_t)M * 6;
     SDN_TRY(sdn_int::march_rays_train(s->rays_o, s->rays_d, s->bitfield, s->bound, s->dt_gamma, s->max_steps, N, s->cascade, s->grid_size, M, F(L.nears),
                                       F(L.fars), xyzs, dirs, deltas, (int32_t *)(ws + L.rays), s->counter, F(L.noises), ws + L.march, s->cull_grid, st));
@@ -778,7 +782,9 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     } else {
         SDN_TRY(sdn_ffh::dw_jobs(jobs + (kDefL + 1), nj - (kDefL + 1), M, ws + L.dw_partial, st));   // canonical frame: the deformation MLP has no gradient
     }
-    if (s->mode != 0) return sdn_launch_status();
+    if (zero_deform && s->keep_deform && hipMemsetAsync(ws + L.g_deform, 0, kDefFlat * 2, st) != hipSuccess) return sdn_launch_status();
+    }   // mode != 2
+    if (s->mode == 1) return sdn_launch_status();
 
     // ---- optimizer (nerf/utils.py:889-906) --------------------------------------------------------------------------------------------
     const uint32_t table_n = (uint32_t)s->grid_offsets[kLevels] * 2u;
@@ -789,14 +795,14 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     ck.g[2] = H(L.g_sigma1); ck.n8[2] = kSigOut * kSigW / 8;
     ck.g[3] = H(L.g_color); ck.n8[3] = kColFlat / 8;
     ck.count = 4;
-    if (!zero_deform) { ck.g[4] = H(L.g_deform); ck.n8[4] = kDefFlat / 8; ck.count = 5; }
+    if (!freeze_deform) { ck.g[4] = H(L.g_deform); ck.n8[4] = kDefFlat / 8; ck.count = 5; }
     hipLaunchKernelGGL(k_train_check, dim3(1024), dim3(256), 0, st, ck);
     const Prologue pr{hyper, s->adam_steps, s->loss_scale, s->growth_tracker, s->beta1, s->beta2, s->lr_table, s->lr_net, s->growth_factor, s->backoff_factor,
-                      s->growth_interval, !zero_deform};
+                      s->growth_interval, !freeze_deform, s->grad_divisor > 0.0f ? s->grad_divisor : 1.0f};
     hipLaunchKernelGGL(k_train_prologue, dim3(1), dim3(1), 0, st, pr);
     AdamArgs A{};
     const uint32_t blocks = build_segments(s, L, A);
-    if (zero_deform) for (uint32_t i = 1; i <= kDefL + 1; i++) A.seg[i].frozen = 1;
+    if (freeze_deform) for (uint32_t i = 1; i <= kDefL + 1; i++) A.seg[i].frozen = 1;
     A.hyper = hyper;
     A.one_minus_b1 = (float)(1.0 - s->beta1); A.b2 = (float)s->beta2; A.one_minus_b2 = (float)(1.0 - s->beta2); A.eps = (float)s->eps;
     A.ema_keep = 1.0f - s->ema_decay;

@@ -30,9 +30,12 @@ def _budget(mean_count, align=128):
 
 class NativeTrainStep:
     def __init__(self, model, optimizer, scaler, n_rays, device, ema_decay=None, perturb=True, bg_color=1, dt_gamma=0.0, max_steps=1024,
-                 T_thresh=1e-4, seed=0):
+                 T_thresh=1e-4, seed=0, grad_sync=None):
         """optimizer: a torch.optim.Adam over `model.get_params(lr, lr_net)` (or merged groups); scaler: torch.amp.GradScaler.
-        ema_decay: None, or the decay of a torch_ema-style shadow kept in `self.ema_shadow` (nerf/utils.py:906)."""
+        ema_decay: None, or the decay of a torch_ema-style shadow kept in `self.ema_shadow` (nerf/utils.py:906).
+        grad_sync: a `dnerf_amd.dist.GradSync` for data-parallel training -- every rank runs forward + backward on its own batch, the
+        fp16 gradient buffers of the step (24 MB table gradient + one 250 KB block with every MLP's) are all-reduced over RCCL, and
+        the optimizer pass divides by the world size on top of the loss scale."""
         if not getattr(model, "cuda_ray", False) or model.mean_count <= 0:
             raise ValueError("NativeTrainStep needs the occupancy-grid path with a known point budget (model.mean_count > 0)")
         if getattr(model, "bg_radius", 0) > 0:
@@ -83,6 +86,7 @@ class NativeTrainStep:
         self.ema_shadow = [p.detach().clone() for p in self.params] if ema_decay is not None else None
         self.step_count, self._M, self._ws, self._rec = 0, None, None, None
         self._cull_cache, self._cull_epoch = {}, None
+        self.grad_sync = grad_sync
         self.noises = None          # optional [n_rays] f32 device tensor: the per-ray offsets of the next steps (instead of the generator)
         self._lr_of = {}
         for g in optimizer.param_groups:
@@ -151,6 +155,15 @@ class NativeTrainStep:
         n = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size()
         return self._ws[off:off + n].view(dtype).view(*shape)
 
+    def gradient_buffers(self):
+        """The step's fp16 gradients as two flat tensors: the table's, and the block g_deform .. g_color (alignment gaps included)."""
+        rows = self.params[0].shape[0]
+        lay = self.layout
+        end = int(lay.g_color) + (64 * 32 + 64 * 64 + 16 * 64) * 2
+        base = self._ws_ptr - self._ws.data_ptr()
+        small = self._ws[base + int(lay.g_deform):base + end].view(torch.float16)
+        return [self.view("g_table", torch.float16, (rows * 2,)), small]
+
     # ---- one step -------------------------------------------------------------------------------------------------------------------
     def load(self, rays_o, rays_d, target, time, bg_color=None):
         self.rays_o.copy_(rays_o.reshape(self.rays_o.shape))
@@ -190,7 +203,15 @@ class NativeTrainStep:
             n = self.ema_updates + (0 if grads_only else 1)
             r.ema_decay = min(self.ema_decay, (1 + n) / (10 + n))       # torch_ema: num_updates is incremented before use
         r.noises = self.noises.data_ptr() if self.noises is not None else None
-        r.mode = 1 if grads_only else 0
+        if self.grad_sync is not None and not grads_only:
+            # data parallel: backward | all-reduce of the gradient buffers (sums; the optimizer divides) | optimizer
+            r.mode, r.keep_deform, r.grad_divisor = 1, 1, float(self.grad_sync.world)
+            _sdn.check(_sdn.lib.sdn_train_step_f16(ctypes.byref(r), _sdn.stream()), "train_step_f16")
+            for g in self.gradient_buffers():
+                self.grad_sync._reduce(g)
+            r.mode = 2
+        else:
+            r.mode, r.keep_deform, r.grad_divisor = (1 if grads_only else 0), 0, 1.0
         _sdn.check(_sdn.lib.sdn_train_step_f16(ctypes.byref(r), _sdn.stream()), "train_step_f16")
         m.local_step += 1
         if not grads_only:

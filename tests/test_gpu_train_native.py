@@ -231,3 +231,58 @@ def test_reference_training_fixture_gradients():
     finally:
         model.eval()
         model.mean_count, model.local_step = 0, 0
+
+
+def _dp_rank(rank, world, port, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # one-GPU rehearsal: both ranks on cuda:0, gradients staged through the host
+    try:
+        import tests_support  # noqa: F401
+        from dnerf_amd.bench_scene import build_scene
+        from dnerf_amd.dist import GradSync
+        from dnerf_amd.network import NeRFNetwork
+        from dnerf_amd.train_native import NativeTrainStep
+        sc = build_scene(H=64, W=64, device="cuda", seed=0)
+        idx = torch.randint(0, sc.rays_o.shape[0], (N_RAYS,), generator=torch.Generator().manual_seed(rank)).cuda()   # own batch per rank
+        rays_o, rays_d = sc.rays_o[idx].contiguous(), sc.rays_d[idx].contiguous()
+        target = torch.rand(N_RAYS, 3, generator=torch.Generator().manual_seed(50 + rank)).cuda()
+        m = NeRFNetwork(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1).cuda().train()
+        m.load_state_dict(sc.model.state_dict())
+        with torch.no_grad():
+            m.deform_net[0].weight.mul_(1 + 0.01 * rank)            # replicas start different; the broadcast makes them equal
+        sync = GradSync(m)
+        sync.broadcast_parameters()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            m.render(rays_o[None], rays_d[None], sc.time, staged=False, perturb=False, bg_color=1, force_all_rays=False, max_steps=1024)
+        m.mean_count = int(m.step_counter[0, 0].item()) + 256       # headroom: the ranks' batches differ
+        m.local_step = 0
+        opt = torch.optim.Adam(m.get_params(1e-2, 1e-3), betas=(0.9, 0.99), eps=1e-15)
+        step = NativeTrainStep(m, opt, torch.amp.GradScaler("cuda"), N_RAYS, "cuda", perturb=False, grad_sync=sync)
+        # rank 1 trains the canonical frame in its third step: its deformation MLP has no gradient of its own then, rank 0's arrives
+        times = [0.5, 0.5, 0.0 if rank == 1 else 0.5, 0.5, 0.5]
+        losses = [float(step(rays_o, rays_d, target, t)) for t in times]
+        flat = torch.cat([p.detach().float().reshape(-1) for p in m.parameters()]).cpu()
+        parts = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(parts, flat)
+        same = all(torch.equal(parts[0], q) for q in parts)
+        np.save(os.path.join(out_dir, f"dp_{rank}.npy"), np.array([float(same), losses[0], losses[-1], float(step.adam_steps[1])]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_native_step_keeps_replicas_identical(tmp_path):
+    """Two ranks (both on this one GPU, gloo with host staging: mechanics only) train on different ray batches: backward, all-reduce
+    of the fp16 gradient buffers, optimizer pass with the world size as divisor.  Parameters stay bit-identical across the ranks, the
+    loss goes down, and the deformation MLP is stepped every time (also when one rank's batch is the canonical frame)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        same, first, last, deform_steps = np.load(tmp_path / f"dp_{r}.npy")
+        assert same == 1.0 and deform_steps == 5.0, (same, deform_steps)
+    assert np.load(tmp_path / "dp_0.npy")[2] < np.load(tmp_path / "dp_0.npy")[1]
