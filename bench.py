@@ -206,8 +206,8 @@ def seald_mode(args):
 def seald_train_mode(args):
     """SealD-NeRF edit-training step (StudentTrainer.train_gui, SealDNeRF/utils.py:667-777) on 4096 rays of the 800x800
     camera: the teacher renders the edited scene (bbox seal mapper, T_thresh 1e-4), the student -- deformation network frozen --
-    trains on it.  Native: teacher through the device loop with the fused field + seal kernels, student step as one HIP graph
-    (dnerf_amd/seald_train.py).  Reference-shaped: `SealDNeRFTeacher.render` op by op + an eager autocast step on the nn.Linear
+    trains on it.  Native: teacher through the device loop with the fused field + seal kernels, student step as one native call
+    (dnerf_amd/seald_train.py -> train_native.NativeTrainStep).  Reference-shaped: `SealDNeRFTeacher.render` op by op + an eager autocast step on the nn.Linear
     network with torch's Adam.  One JSON line."""
     assert torch.cuda.is_available()
     dev = torch.device("cuda", 0)
@@ -290,7 +290,7 @@ def seald_train_mode(args):
                       "reference_shaped_ms_per_step": ms_ref, "speedup": ms_ref / ms_pipelined, "rays_per_s": n_rays * 1e3 / ms_pipelined,
                       "higher_is_better": True, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "dtype": "f16", "data": "synthetic",
                       "config": {"workload": "SURVEY 3.4 / BASELINE config 4 in training: StudentTrainer.train_gui step", "rays": n_rays,
-                                 "student": "NeRFNetworkFF, deform_net frozen, one HIP graph per step",
+                                 "student": "deform_net frozen, one native call per step (sdn_train_step_f16, deform_frozen)",
                                  "teacher": "device loop + fused field + seal kernels, T_thresh 1e-4",
                                  "reference_shaped": "SealDNeRFTeacher.render op by op + eager nn.Linear student step, torch Adam"}}))
 

@@ -468,7 +468,8 @@ typedef struct SdnTrainStep {
     int32_t keep_deform;            /* modes 1 / 2 under data parallelism: the deformation MLP takes part in the optimizer step whatever
                                      * `time` is (another rank's batch may carry its gradient); mode 1 then clears its gradient at time == 0 */
     float grad_divisor;             /* gradients are divided by this on top of the loss scale (0 is read as 1) */
-    int32_t reserved_;
+    int32_t deform_frozen;          /* 1: the deformation MLP is evaluated but not trained (SealD-NeRF's edit training,
+                                     * SealDNeRF/utils.py:692-694): no gradient through it, left out of the optimizer step */
 } SdnTrainStep;
 
 /* Byte offsets into the workspace of what a caller or a test may want to look at.  fp16 "flat" networks are laid out as the fused

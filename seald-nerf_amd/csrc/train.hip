@@ -731,7 +731,8 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     auto H = [&](uint64_t off) { return (_Float16 *)(ws + off); };
     Hyper *hyper = (Hyper *)(ws + L.hyper);
     const int zero_deform = s->time == 0.0f;
-    const int freeze_deform = zero_deform && !s->keep_deform;
+    const int no_deform_grad = zero_deform || s->deform_frozen;           // nothing flows back through x + deform
+    const int freeze_deform = (zero_deform && !s->keep_deform) || s->deform_frozen;
     int rc;
     #define SDN_TRY(x) do { rc = (x); if (rc) return rc; } while (0)
     if (s->mode != 2) {
@@ -754,8 +755,8 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     hipLaunchKernelGGL(k_train_encode, dim3(sdn_div_up(M * 16u, 256u)), dim3(256), 0, st, xyzs, M, s->time, H(L.enc_in));
     SDN_TRY(sdn_ffh::forward_packed(H(L.enc_in), ws + L.pk_def_f, M, kDefIn, kDefW, kDefL, ACT_RELU, H(L.def_hidden), H(L.def_out), st));
     hipLaunchKernelGGL(k_train_xdef, dim3(sdn_div_up(M * 3u, 256u)), dim3(256), 0, st, xyzs, H(L.def_out), M, zero_deform, s->bound, F(L.xdef));
-    SDN_TRY(sdn_grid_encode_forward(F(L.xdef), ws + L.w_table, s->grid_offsets, ws + L.grid_out, M, 3, 2, kLevels, s->grid_S, s->grid_H, ws + L.dy_dx, 1, 0, 0,
-                                    SDN_F16, st));
+    SDN_TRY(sdn_grid_encode_forward(F(L.xdef), ws + L.w_table, s->grid_offsets, ws + L.grid_out, M, 3, 2, kLevels, s->grid_S, s->grid_H,
+                                    no_deform_grad ? nullptr : ws + L.dy_dx, 1, 0, 0, SDN_F16, st));
     const SigmaFwd sf{H(L.grid_out), H(L.w_sigma0), H(L.w_sigma1), dirs, H(L.enc_rm), H(L.h1), H(L.hout), H(L.col_in), F(L.sigmas), M, s->density_scale};
     hipLaunchKernelGGL(k_train_sigma_fwd, dim3(sdn_div_up(M, 32u)), dim3(64), 0, st, sf);
     SDN_TRY(sdn_ffh::forward_packed(H(L.col_in), ws + L.pk_col_f, M, kColIn, kColW, kColL, ACT_RELU, H(L.col_hidden), H(L.col_out), st));
@@ -770,19 +771,19 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     SDN_TRY(sdn_ffh::backward_packed(H(L.dcol_out), ws + L.pk_col_b, H(L.col_hidden), M, kColIn, kColW, kColL, ACT_RELU, 1, H(L.col_bwd), H(L.dcol_in), st));
     const SigmaBwd sb{H(L.dh0), H(L.dcol_in), H(L.h1), H(L.w_sigma0), H(L.w_sigma1), H(L.dh), H(L.dh1), H(L.denc), M};
     hipLaunchKernelGGL(k_train_sigma_bwd, dim3(sdn_div_up(M, 32u)), dim3(64), 0, st, sb);
-    SDN_TRY(sdn_grid_encode_backward(ws + L.denc, F(L.xdef), s->grid_offsets, ws + L.g_table, M, 3, 2, kLevels, s->grid_S, s->grid_H, zero_deform ? nullptr : ws + L.dy_dx,
-                                     zero_deform ? nullptr : ws + L.dx16, 1, 0, 0, SDN_F16, st));
+    SDN_TRY(sdn_grid_encode_backward(ws + L.denc, F(L.xdef), s->grid_offsets, ws + L.g_table, M, 3, 2, kLevels, s->grid_S, s->grid_H,
+                                     no_deform_grad ? nullptr : ws + L.dy_dx, no_deform_grad ? nullptr : ws + L.dx16, 1, 0, 0, SDN_F16, st));
     sdn_ffh::DwJob jobs[16];
     uint32_t nj = 0;
     dw_job_list(L, ws, M, jobs, nj);
-    if (!zero_deform) {
+    if (!no_deform_grad) {
         hipLaunchKernelGGL(k_train_deform_grad, dim3(sdn_div_up(M, 256u)), dim3(256), 0, st, H(L.dx16), M, s->bound, H(L.ddef));
         SDN_TRY(sdn_ffh::backward_packed(H(L.ddef), ws + L.pk_def_b, H(L.def_hidden), M, kDefIn, kDefW, kDefL, ACT_RELU, 0, H(L.def_bwd), nullptr, st));
         SDN_TRY(sdn_ffh::dw_jobs(jobs, nj, M, ws + L.dw_partial, st));
     } else {
         SDN_TRY(sdn_ffh::dw_jobs(jobs + (kDefL + 1), nj - (kDefL + 1), M, ws + L.dw_partial, st));   // canonical frame: the deformation MLP has no gradient
     }
-    if (zero_deform && s->keep_deform && hipMemsetAsync(ws + L.g_deform, 0, kDefFlat * 2, st) != hipSuccess) return sdn_launch_status();
+    if (no_deform_grad && s->keep_deform && !s->deform_frozen && hipMemsetAsync(ws + L.g_deform, 0, kDefFlat * 2, st) != hipSuccess) return sdn_launch_status();
     }   // mode != 2
     if (s->mode == 1) return sdn_launch_status();
 

@@ -4,9 +4,10 @@ The reference's step (`StudentTrainer.train_gui`, SealDNeRF/utils.py:667-777; SU
 TEACHER renders the edited scene -- inference branch, seal mapper between marcher and network, `T_thresh` 1e-4, no perturbation
 (`proxy_truth`, utils.py:632-656) -- and its colours replace the ground truth; the STUDENT then takes a normal training step on
 them with its deformation network frozen (utils.py:692-694).  Here the teacher's render is the native loop with the fused field
-kernel and the seal kernels inside the frame driver (`DeviceLoop(..., mapper=)`), and the student's step is the captured graph of
-`train_graph.GraphedTrainStep` (student = `NeRFNetworkFF`; with the deformation MLP frozen its forward is the inference kernel and
-the grid encoder needs no input gradients).
+kernel and the seal kernels inside the frame driver (`DeviceLoop(..., mapper=)`), and the student's step is the native training step
+(`train_native.NativeTrainStep(train_deform=False)`: one call, ~30 launches; the frozen deformation MLP is evaluated, nothing flows
+back through it, the grid encoder computes no input gradients) -- or, with `native=False`, the captured graph of the op-by-op step
+(`train_graph.GraphedTrainStep`, student = `NeRFNetworkFF`).
 """
 import torch
 
@@ -23,11 +24,16 @@ def freeze_deformation(student):
 
 
 class EditTrainStep:
-    def __init__(self, teacher, student, mapper, optimizer, scaler, n_rays, device, time, **render_kw):
+    def __init__(self, teacher, student, mapper, optimizer, scaler, n_rays, device, time, native=True, **render_kw):
         self.teacher, self.student = teacher, student
         self.field = fused.FusedField(teacher, time, fp16=True)
         self.loop = DeviceLoop(teacher, self.field, n_rays, device, T_thresh=1e-4, mapper=mapper)
-        self.step = GraphedTrainStep(student, optimizer, scaler, n_rays, device, **render_kw)
+        if native:
+            from .train_native import NativeTrainStep
+            kw = {k: v for k, v in render_kw.items() if k in ("perturb", "bg_color", "dt_gamma", "max_steps", "T_thresh", "seed", "ema_decay")}
+            self.step = NativeTrainStep(student, optimizer, scaler, n_rays, device, train_deform=False, **kw)
+        else:
+            self.step = GraphedTrainStep(student, optimizer, scaler, n_rays, device, **render_kw)
 
     @torch.no_grad()
     def proxy_truth(self, rays_o, rays_d, time, bg_color=1.0):
@@ -53,7 +59,7 @@ class EditTrainStep:
         cur = next(it, None)
         if cur is None:
             return 0
-        if self.step.graph is None:            # capture before anything runs beside it
+        if hasattr(self.step, "capture") and self.step.graph is None:            # capture before anything runs beside it
             self.step.load(cur[0], cur[1], torch.zeros_like(self.loop.image_out), cur[2])
             self.step.capture()
         side.wait_stream(main)

@@ -30,9 +30,11 @@ def _budget(mean_count, align=128):
 
 class NativeTrainStep:
     def __init__(self, model, optimizer, scaler, n_rays, device, ema_decay=None, perturb=True, bg_color=1, dt_gamma=0.0, max_steps=1024,
-                 T_thresh=1e-4, seed=0, grad_sync=None):
+                 T_thresh=1e-4, seed=0, grad_sync=None, train_deform=True):
         """optimizer: a torch.optim.Adam over `model.get_params(lr, lr_net)` (or merged groups); scaler: torch.amp.GradScaler.
         ema_decay: None, or the decay of a torch_ema-style shadow kept in `self.ema_shadow` (nerf/utils.py:906).
+        train_deform=False: the deformation MLP is evaluated but not trained (SealD-NeRF's edit training, SealDNeRF/utils.py:692-694;
+        the optimizer then need not hold its parameters).
         grad_sync: a `dnerf_amd.dist.GradSync` for data-parallel training -- every rank runs forward + backward on its own batch, the
         fp16 gradient buffers of the step (24 MB table gradient + one 250 KB block with every MLP's) are all-reduced over RCCL, and
         the optimizer pass divides by the world size on top of the loss scale."""
@@ -86,7 +88,7 @@ class NativeTrainStep:
         self.ema_shadow = [p.detach().clone() for p in self.params] if ema_decay is not None else None
         self.step_count, self._M, self._ws, self._rec = 0, None, None, None
         self._cull_cache, self._cull_epoch = {}, None
-        self.grad_sync = grad_sync
+        self.grad_sync, self.train_deform = grad_sync, bool(train_deform)
         self.noises = None          # optional [n_rays] f32 device tensor: the per-ray offsets of the next steps (instead of the generator)
         self._lr_of = {}
         for g in optimizer.param_groups:
@@ -195,7 +197,7 @@ class NativeTrainStep:
             r.bg_color, r.bg_value = self.bg.data_ptr(), 0.0
         else:
             r.bg_color, r.bg_value = None, float(self.bg_color)
-        g_table, g_net = self._lr_of[id(self.params[0])], self._lr_of[id(self.params[1])]
+        g_table, g_net = self._lr_of[id(self.params[0])], self._lr_of[id(self.params[9])]       # encoder.embeddings, sigma_net.0
         r.lr_table, r.lr_net = float(g_table["lr"]), float(g_net["lr"])
         r.beta1, r.beta2, r.eps = float(g_net["betas"][0]), float(g_net["betas"][1]), float(g_net["eps"])
         r.noise_seed = (self.seed * 0x9E3779B1 + self.step_count) & 0xFFFFFFFFFFFFFFFF
@@ -203,6 +205,7 @@ class NativeTrainStep:
             n = self.ema_updates + (0 if grads_only else 1)
             r.ema_decay = min(self.ema_decay, (1 + n) / (10 + n))       # torch_ema: num_updates is incremented before use
         r.noises = self.noises.data_ptr() if self.noises is not None else None
+        r.deform_frozen = 0 if self.train_deform else 1
         if self.grad_sync is not None and not grads_only:
             # data parallel: backward | all-reduce of the gradient buffers (sums; the optimizer divides) | optimizer
             r.mode, r.keep_deform, r.grad_divisor = 1, 1, float(self.grad_sync.world)

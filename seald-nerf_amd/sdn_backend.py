@@ -104,7 +104,7 @@ class SdnTrainStep(ctypes.Structure):
                 + [(n, ctypes.c_double) for n in ("lr_table", "lr_net", "beta1", "beta2", "eps")]
                 + [("adam_steps", _vp), ("loss_scale", _vp), ("growth_tracker", _vp), ("growth_factor", _f32), ("backoff_factor", _f32),
                    ("growth_interval", _u32), ("ema_decay", _f32), ("loss_out", _vp), ("image_out", _vp), ("workspace", _vp),
-                   ("mode", ctypes.c_int32), ("keep_deform", ctypes.c_int32), ("grad_divisor", _f32), ("reserved_", ctypes.c_int32)])
+                   ("mode", ctypes.c_int32), ("keep_deform", ctypes.c_int32), ("grad_divisor", _f32), ("deform_frozen", ctypes.c_int32)])
 
 
 class SdnTrainLayout(ctypes.Structure):
