@@ -245,6 +245,36 @@ def test_c_abi_exports_every_declared_symbol():
     assert set(names) == declared, sorted(set(names) ^ declared)
 
 
+def test_ctypes_records_match_the_c_header(tmp_path):
+    """The Python mirrors of the C records (sdn_backend.py) against the header itself: a C program compiled from include/sdn_hip.h
+    prints sizeof and the offset of every field; a record whose mirror drifts would hand the library misplaced pointers."""
+    import ctypes
+    import subprocess
+    import sdn_backend as B
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    records = {"SdnFrameTime": B.SdnFrameTime, "SdnRenderCtx": B.SdnRenderCtx, "SdnSealBox": B.SdnSealBox, "SdnTrainParam": B.SdnTrainParam,
+               "SdnTrainStep": B.SdnTrainStep, "SdnTrainLayout": B.SdnTrainLayout}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "sdn_hip.h"', 'int main(void) {']
+    for name, rec in records.items():
+        lines.append(f'  printf("{name} size %zu\\n", sizeof({name}));')
+        for field, _ in rec._fields_:
+            lines.append(f'  printf("{name} {field} %zu\\n", offsetof({name}, {field}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    seen = 0
+    for line in filter(None, out):
+        name, field, value = line.split()
+        rec = records[name]
+        want = ctypes.sizeof(rec) if field == "size" else getattr(rec, field).offset
+        assert int(value) == want, (name, field, int(value), want)
+        seen += 1
+    assert seen == sum(len(r._fields_) + 1 for r in records.values())
+
+
 def test_ops_fail_loudly_without_a_device():
     import torch
     if torch.cuda.is_available():

@@ -22,7 +22,8 @@ python3 bench.py --steps 20 --static-frame --no-cpu-baseline > $OUT/bench_static
 python3 bench.py --steps 20 --scene lego --no-cpu-baseline > $OUT/bench_lego.json 2>/dev/null
 stats default --steps 20 --warmup 3 --no-cpu-baseline; echo "stats default done"
 stats sequential --steps 20 --warmup 3 --pipeline 0 --no-cpu-baseline
-stats train --mode train --steps 30
+stats train --mode train --steps 100 --warmup 10
+stats train_graph --mode train --train-native 0 --steps 30
 stats ops_f16 --field ops --steps 5 --warmup 1 --static-frame --no-cpu-baseline
 echo "stats done"
 # PMC: one static frame rendered 8 times (1 count + 1 warm-up + 2 warm stream + 2 timed + 2 latency)
@@ -40,7 +41,9 @@ python3 tools/grid_bwd_speed.py > $OUT/grid_bwd_speed.txt 2>/dev/null
 for cfg in "--emulate-rank-of 8 --group-frames 8 --steps 96" "--emulate-rank-of 8 --group-frames 1 --steps 96" "--emulate-rank-of 8 --group-frames 5 --steps 20" "--emulate-rank-of 4 --group-frames 4 --steps 96" "--emulate-rank-of 2 --group-frames 2 --steps 96" "--steps 96" "--steps 20"; do
   python3 bench.py $cfg --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], '| ms/frame', round(d['ms_per_step'],4), 'latency ms/loop', round(d['latency_ms_one_loop_at_a_time'],3), 'points/s', '%.4g'%d['value'], 'rays/loop', d['config']['rays_per_loop_on_this_gpu'])" "$cfg" >> $OUT/frame_groups_one_gpu.txt
 done
-python3 bench.py --mode train --steps 30 > $OUT/bench_train.json 2>/dev/null
+python3 bench.py --mode train --steps 200 --warmup 10 > $OUT/bench_train.json 2>/dev/null
+python3 bench.py --mode train --train-native 0 --steps 50 > $OUT/bench_train_graph.json 2>/dev/null
+python3 tools/ffmlp_speed.py --iters 10 > $OUT/ffmlp_speed.jsonl 2>/dev/null
 python3 bench.py --mode seald --steps 20 > $OUT/bench_seald.json 2>/dev/null
 python3 bench.py --mode density --steps 8 > $OUT/bench_density.json 2>/dev/null
 python3 bench.py --mode seald-train --steps 20 > $OUT/bench_seald_train.json 2>/dev/null
