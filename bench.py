@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--train-native", type=int, default=1, help="--mode train: the step as ONE native call (sdn_train_step_f16, "
                                                                  "dnerf_amd/train_native.py); 0 = the autograd step (graphed or eager)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-side", type=int, default=96, help="side of the CPU-baseline sample image")
+    ap.add_argument("--cpu-baseline-side", type=int, default=224, help="side of the CPU-baseline sample image (224: ~15 s of CPU work)")
     return ap.parse_args()
 
 
