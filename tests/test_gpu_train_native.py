@@ -286,3 +286,53 @@ def test_data_parallel_native_step_keeps_replicas_identical(tmp_path):
         same, first, last, deform_steps = np.load(tmp_path / f"dp_{r}.npy")
         assert same == 1.0 and deform_steps == 5.0, (same, deform_steps)
     assert np.load(tmp_path / "dp_0.npy")[2] < np.load(tmp_path / "dp_0.npy")[1]
+
+
+def test_per_ray_background_budget_overflow_and_rebuild():
+    """Per-ray background colours (utils.py:74) against the autograd step; a sample budget smaller than the batch needs (the rays
+    past it are dropped, raymarching.py:200-233, the step stays finite); a changed `mean_count` re-sizes the step's buffers without
+    losing the parameters' fp16 copies; a changed learning rate is picked up from the optimizer's groups."""
+    from dnerf_amd.train_native import NativeTrainStep
+    sc, model, opt, scaler, target = _setup()
+    bg = torch.rand(N_RAYS, 3, generator=torch.Generator().manual_seed(9)).cuda()
+    out, loss = _eager_backward(model, sc, target, scaler, bg_color=bg[None])
+    ref = {k: v.grad.detach().clone() for k, v in model.named_parameters()}
+    model.local_step = 0
+    step = NativeTrainStep(model, opt, scaler, N_RAYS, "cuda", perturb=False, bg_color=bg)
+    got = step(sc.rays_o, sc.rays_d, target, sc.time, grads_only=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(got), float(loss), rtol=1e-3)
+    grads = _native_grads(step, model)
+    for k in ("color_net.2.weight", "sigma_net.0.weight", "deform_net.3.weight"):
+        assert _rel(grads[k], ref[k].float()) < 2e-2, k
+    # overflow: a budget of about a third of the samples
+    full = int(model.step_counter[(model.local_step - 1) % 16, 0])
+    model.mean_count = max(128, full // 3)
+    before = model.sigma_net[0].weight.detach().clone()
+    l2 = step(sc.rays_o, sc.rays_d, target, sc.time)
+    torch.cuda.synchronize()
+    assert step._M == model.mean_count + (128 - model.mean_count % 128) and np.isfinite(float(l2))
+    kept = step.view("rays", torch.int32, (N_RAYS, 3))
+    assert int((kept[:, 1] + kept[:, 2] <= step._M).sum()) < N_RAYS            # some rays did not fit ...
+    assert not torch.equal(model.sigma_net[0].weight.detach(), before)          # ... the others trained
+    assert torch.equal(step.view("w_sigma0", torch.float16, (64, 32)), model.sigma_net[0].weight.detach().half())
+    # learning rate 0 for the MLPs: only the table moves
+    for g in opt.param_groups:
+        if any(p is model.sigma_net[0].weight or p is model.deform_net[0].weight or p is model.color_net[0].weight for p in g["params"]):
+            g["lr"] = 0.0
+    mid = {k: v.detach().clone() for k, v in model.named_parameters()}
+    step(sc.rays_o, sc.rays_d, target, sc.time)
+    torch.cuda.synchronize()
+    for k, v in model.named_parameters():
+        assert torch.equal(v.detach(), mid[k]) == (k != "encoder.embeddings"), k
+
+
+def test_perturbed_steps_are_reproducible_and_differ_by_seed():
+    from dnerf_amd.train_native import NativeTrainStep
+    losses = []
+    for seed in (1, 1, 2):
+        sc, model, opt, scaler, target = _setup()
+        step = NativeTrainStep(model, opt, scaler, N_RAYS, "cuda", perturb=True, seed=seed)
+        losses.append([float(step(sc.rays_o, sc.rays_d, target, sc.time, grads_only=True)) for _ in range(2)])
+    assert losses[0] == losses[1] and losses[0] != losses[2]
+    assert losses[0][0] == losses[0][1]             # grads_only does not advance the noise stream (same step index)
