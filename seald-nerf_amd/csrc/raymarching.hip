@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(256) k_march_train_count(const float *__restri
 // waves busy for as long as its longest ray.  Occupancy bits and cull marks are read from global memory (L2-resident, 256 KiB +
 // 4 KiB): a probe round is one parallel load, an LDS image per 4-ray workgroup would cost more than it saves.
 // ---------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float lane_lattice(float base, float dt, uint32_t lane, float &next_base) {
+__device__ __forceinline__ float lane_lattice(float base, float dt, uint32_t lane, float &next_base, float &closed_step) {
     // L_{lane} of the lattice starting at base, by `lane` successive additions (float addition is not associative: the values
     // must come from the recurrence); also returns L_64.
     // Closed form for the common case.  While L stays in one binade every L_k is a multiple of the binade's ulp U, so
@@ -485,9 +485,11 @@ __device__ __forceinline__ float lane_lattice(float base, float dt, uint32_t lan
         const float half_ulp = __uint_as_float((eb - 24u) << 23), c_cap = __uint_as_float((eb - 5u) << 23);   // U / 2, 2^18 U
         if (normal && eb == el && fabsf(err) != half_ulp && c < c_cap) {
             next_base = last;
+            closed_step = c;                                        // L_k = base + k c holds for k = 0 .. 64
             return base + (float)lane * c;
         }
     }
+    closed_step = 0.0f;
     float v = base, mine = base;
     #pragma unroll 8
     for (uint32_t i = 0; i < 64; i++) {
@@ -545,8 +547,8 @@ __global__ void __launch_bounds__(256) k_march_train_count_wave(const float *__r
             bool hit = false, ended = false;
             float base = s0;
             for (int round = 0; round < 2 && !ended; round++) {   // 96 scan positions: lanes 0..63, then 0..31
-                float nb;
-                const float s = lane_lattice(base, ds, lane, nb);
+                float nb, unused_step;
+                const float s = lane_lattice(base, ds, lane, nb, unused_step);
                 base = nb;
                 const bool in_range = round == 0 || lane < 32u;
                 const float ss = fminf(s, s1);
@@ -574,19 +576,33 @@ __global__ void __launch_bounds__(256) k_march_train_count_wave(const float *__r
     float *ts = sample_t + (size_t)n * max_steps;
     float base = t0;
     float carry_tt = -__FLT_MAX__;      // exit parameter of an empty voxel whose successor lies beyond the previous window
-    while (go && num_steps < max_steps) {
-        float nb;
-        const float t = lane_lattice(base, dt, lane, nb);
-        const bool act = t < far && t < t_end;      // the loop condition of the sequential marcher at this lattice point
+    // One window = 64 consecutive lattice points, one per lane.  A window's occupancy bytes are loaded while the window BEFORE it is
+    // walked (the lattice does not depend on the walk), and for every lattice point, marked by the cull grid or not: the two
+    // dependent loads per window of the first version (cull word, then occupancy byte: two L2 round trips with nothing to hide them
+    // but three sibling waves doing the same) were the kernel's time.  An unmarked cull cell has no occupied voxel, so reading the
+    // voxel's own bit gives the same answer.
+    struct Window { float t, nb, cstep, x, y, z; int nx, ny, nz; uint32_t byte, bit; bool act; };
+    auto fetch = [&](float from) __attribute__((always_inline)) {
+        Window w;
+        w.t = lane_lattice(from, dt, lane, w.nb, w.cstep);
+        w.act = w.t < far && w.t < t_end;           // the loop condition of the sequential marcher at this lattice point
         // occupancy and (for an empty voxel) the exit parameter, with MarcherT<true>::probe's expressions
-        const float x = clampf_(m.ox + t * m.dx, -bound, bound), y = clampf_(m.oy + t * m.dy, -bound, bound), z = clampf_(m.oz + t * m.dz, -bound, bound);
-        const int nx = (int)clampf_((x + 1) * m.halfH, 0.0f, m.Hm1), ny = (int)clampf_((y + 1) * m.halfH, 0.0f, m.Hm1),
-                  nz = (int)clampf_((z + 1) * m.halfH, 0.0f, m.Hm1);
-        bool occ = false;
-        if (act && (!cull || cull_marked(cull, nx >> 2, ny >> 2, nz >> 2))) {
-            const uint32_t index = morton3D_8bit((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
-            occ = grid[index >> 3] & (1u << (index & 7u));
-        }
+        w.x = clampf_(m.ox + w.t * m.dx, -bound, bound); w.y = clampf_(m.oy + w.t * m.dy, -bound, bound); w.z = clampf_(m.oz + w.t * m.dz, -bound, bound);
+        w.nx = (int)clampf_((w.x + 1) * m.halfH, 0.0f, m.Hm1); w.ny = (int)clampf_((w.y + 1) * m.halfH, 0.0f, m.Hm1);
+        w.nz = (int)clampf_((w.z + 1) * m.halfH, 0.0f, m.Hm1);
+        const uint32_t index = morton3D_8bit((uint32_t)w.nx, (uint32_t)w.ny, (uint32_t)w.nz);
+        w.byte = grid[index >> 3];                  // positions are clamped: a valid address for every lattice point
+        w.bit = index & 7u;
+        return w;
+    };
+    Window cur_w{};
+    if (go) cur_w = fetch(base);
+    while (go && num_steps < max_steps) {
+        const Window nxt_w = fetch(cur_w.nb);
+        const float t = cur_w.t, nb = cur_w.nb, cstep = cur_w.cstep, x = cur_w.x, y = cur_w.y, z = cur_w.z;
+        const int nx = cur_w.nx, ny = cur_w.ny, nz = cur_w.nz;
+        const bool act = cur_w.act;
+        const bool occ = act && ((cur_w.byte >> cur_w.bit) & 1u);
         const float tx = ((((float)nx + m.ex) * m.twoRH - 1) - x) * m.rdx;
         const float ty = ((((float)ny + m.ey) * m.twoRH - 1) - y) * m.rdy;
         const float tz = ((((float)nz + m.ez) * m.twoRH - 1) - z) * m.rdz;
@@ -596,48 +612,69 @@ __global__ void __launch_bounds__(256) k_march_train_count_wave(const float *__r
         // (a 128^3 voxel is crossed in at most 8 steps of dt_min; longer crossings walk on)
         uint32_t nxt = lane + 1u;
         const bool empty = act && !occ;
-        for (int k = 0; k < 64; k++) {
-            const float lv = __shfl(t, (int)(nxt & 63u), 64);
-            const bool more = empty && nxt < 64u && lv < tt;
-            if (!__any(more)) break;
-            if (more) nxt++;
+        if (cstep > 0.0f) {
+            // closed-form window (wave-uniform): the lattice values are base + j cstep exactly, so the successor is an index
+            // computation per lane -- an estimate by division, then exact comparisons against the lattice values themselves
+            if (empty) {
+                const float q = (tt - base) / cstep;
+                int j = q < 64.0f ? (int)ceilf(q) : 64;
+                if (j < (int)lane + 1) j = (int)lane + 1;
+                while (j > (int)lane + 1 && base + (float)(j - 1) * cstep >= tt) j--;
+                while (j < 64 && base + (float)j * cstep < tt) j++;
+                nxt = (uint32_t)j;
+            }
+        } else {
+            for (int k = 0; k < 64; k++) {
+                const float lv = __shfl(t, (int)(nxt & 63u), 64);
+                const bool more = empty && nxt < 64u && lv < tt;
+                if (!__any(more)) break;
+                if (more) nxt++;
+            }
         }
         // entry point of the chain into this window
-        uint32_t cur = 0;
+        uint32_t cur0 = 0;
         float new_carry = -__FLT_MAX__;
         if (carry_tt != -__FLT_MAX__) {
             const unsigned long long ge = __ballot(t >= carry_tt);
-            cur = ge ? (uint32_t)__builtin_ctzll(ge) : 64u;
+            cur0 = ge ? (uint32_t)__builtin_ctzll(ge) : 64u;
             if (!ge) new_carry = carry_tt;      // the voxel's exit lies beyond this window too: keep walking
         }
-        unsigned long long emit = 0ull;
-        uint32_t budget = max_steps - num_steps;
+        // The walk itself is a SCALAR loop: position, masks, budget and the emitted set live in SGPRs (pinned with readfirstlane --
+        // the compiler's uniformity analysis does not see through the loop-carried values and otherwise runs the loop as divergent
+        // vector code under exec masks: measured 440 cycles per hop, 55 000 of a long ray's 81 000 cycles).
+        uint32_t cur = __builtin_amdgcn_readfirstlane(cur0);
+        uint32_t budget = __builtin_amdgcn_readfirstlane(max_steps - num_steps);
+        uint32_t emit_lo = 0, emit_hi = 0;
         bool done = false;
         while (cur < 64u) {
-            if (!((act_m >> cur) & 1ull)) { done = true; break; }          // t >= far or t >= t_end: the ray is finished
-            if ((occ_m >> cur) & 1ull) {
+            const unsigned long long am = act_m >> cur, om = occ_m >> cur;
+            if (!(am & 1ull)) { done = true; break; }                      // t >= far or t >= t_end: the ray is finished
+            if (om & 1ull) {
                 // a run of occupied lattice points: every one is visited and sampled
-                const unsigned long long rest = ~(occ_m >> cur);
+                const unsigned long long rest = ~om;
                 uint32_t run = rest ? (uint32_t)__builtin_ctzll(rest) : 64u - cur;
                 if (run > 64u - cur) run = 64u - cur;
                 if (run >= budget) { run = budget; done = true; }
-                emit |= ((run >= 64u) ? ~0ull : ((1ull << run) - 1ull)) << cur;
-                budget -= run;
-                cur += run;
+                const unsigned long long bits = ((run >= 64u) ? ~0ull : ((1ull << run) - 1ull)) << cur;
+                emit_lo = __builtin_amdgcn_readfirstlane(emit_lo | (uint32_t)bits);
+                emit_hi = __builtin_amdgcn_readfirstlane(emit_hi | (uint32_t)(bits >> 32));
+                budget = __builtin_amdgcn_readfirstlane(budget - run);
+                cur = __builtin_amdgcn_readfirstlane(cur + run);
                 if (done) break;
             } else {
-                // (cur is wave-uniform: v_readlane with a scalar lane index, not an LDS-latency ds_bpermute)
-                const uint32_t cur_s = __builtin_amdgcn_readfirstlane(cur);
-                const uint32_t to = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)cur_s);
-                if (to >= 64u) new_carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tt), (int)cur_s));
+                // (v_readlane with a scalar lane index, not an LDS-latency ds_bpermute)
+                const uint32_t to = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)cur);
+                if (to >= 64u) new_carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tt), (int)cur));
                 cur = to;
             }
         }
+        const unsigned long long emit = ((unsigned long long)emit_hi << 32) | emit_lo;
         if ((emit >> lane) & 1ull) ts[num_steps + (uint32_t)__popcll(emit & ((1ull << lane) - 1ull))] = t;
-        num_steps += (uint32_t)__popcll(emit);
+        num_steps = __builtin_amdgcn_readfirstlane(num_steps + (uint32_t)__popcll(emit));
         if (done) break;
         carry_tt = new_carry;
         base = nb;
+        cur_w = nxt_w;
     }
     if (lane == 0) num_steps_out[n] = num_steps;
 }
