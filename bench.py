@@ -66,6 +66,7 @@ def parse():
                                                                 "graph (dnerf_amd/train_graph.py); 0 = launch it from Python")
     ap.add_argument("--train-native", type=int, default=1, help="--mode train: the step as ONE native call (sdn_train_step_f16, "
                                                                  "dnerf_amd/train_native.py); 0 = the autograd step (graphed or eager)")
+    ap.add_argument("--train-prefetch", type=int, default=1, help="--mode train, native step: march batch k+1 on a second stream beside step k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-side", type=int, default=224, help="side of the CPU-baseline sample image (224: ~15 s of CPU work)")
     return ap.parse_args()
@@ -119,7 +120,14 @@ def train_mode(args):
         from dnerf_amd.train_native import NativeTrainStep
         nstep = NativeTrainStep(model, opt, scaler, n_rays, dev, perturb=True, bg_color=1)
         nstep.load(rays_o, rays_d, target, sc.time)
-        step = nstep  # noqa: F811  (inputs stay in the step's buffers, as with the graph)
+        if args.train_prefetch:
+            # the next batch is marched on a second stream beside the running step (a loader knows it one step early)
+            def step():  # noqa: F811
+                loss = nstep(rays_o, rays_d, target, sc.time)
+                nstep.prefetch(rays_o, rays_d, sc.time)
+                return loss
+        else:
+            step = nstep  # noqa: F811  (inputs stay in the step's buffers, as with the graph)
     if graphed:
         from dnerf_amd.train_graph import GraphedTrainStep
         gstep = GraphedTrainStep(model, opt, scaler, n_rays, dev)
@@ -150,7 +158,7 @@ def train_mode(args):
                                                       "mean_count": model.mean_count,
                                                       "mlps": ("deform + colour MLPs on the fused-MLP kernels, density MLP in a per-sample dot2 kernel" if native else
                                                                "deform + colour MLPs on the fused-MLP operator (ffmlp), density MLP hipBLASLt" if type(model).__name__ == "NeRFNetworkFF" else "nn.Linear stack (hipBLASLt GEMMs)"),
-                                                      "launch": ("one native call per step (sdn_train_step_f16: ~35 launches, Adam + fp16 copies + gradient clear in one pass)" if native
+                                                      "launch": ("one native call per step (sdn_train_step_f16: ~30 launches, Adam + fp16 copies + gradient clear in one pass)" + ("; the next batch's rays are marched on a second stream beside the running step" if args.train_prefetch else "") if native
                                                                  else "one captured HIP graph per step (fused capturable Adam)" if graphed else "eager (Python launches)")},
                       "kernel_times": summ}))
 

@@ -470,6 +470,11 @@ typedef struct SdnTrainStep {
     float grad_divisor;             /* gradients are divided by this on top of the loss scale (0 is read as 1) */
     int32_t deform_frozen;          /* 1: the deformation MLP is evaluated but not trained (SealD-NeRF's edit training,
                                      * SealDNeRF/utils.py:692-694): no gradient through it, left out of the optimizer step */
+    int32_t phase;                  /* 0: rays -> samples AND the step on them; 1: rays -> samples only (into sample set `sample_set`);
+                                     * 2: the step on the samples already in `sample_set`.  Marching needs nothing of the network, so a
+                                     * caller that knows the next batch early runs phase 1 for batch k+1 on a second stream beside
+                                     * phase 2 of batch k (the optimizer pass and the marcher do not compete for the same unit) */
+    int32_t sample_set;             /* 0 / 1: which of the workspace's two sample buffers */
 } SdnTrainStep;
 
 /* Byte offsets into the workspace of what a caller or a test may want to look at.  fp16 "flat" networks are laid out as the fused
@@ -478,7 +483,8 @@ typedef struct SdnTrainLayout {
     uint64_t total_bytes;
     uint64_t w_table, w_deform, w_sigma0, w_sigma1, w_color;   /* fp16 copies of the parameters */
     uint64_t g_table, g_deform, g_sigma0, g_sigma1, g_color;   /* fp16 gradients (scaled by the loss scale), same layouts */
-    uint64_t xyzs, dirs, deltas, rays;                         /* march_rays_train outputs: [M,3] [M,3] [M,2] f32, [N,3] i32 */
+    uint64_t xyzs, dirs, deltas, rays;                         /* march_rays_train outputs: [M,3] [M,3] [M,2] f32, [N,3] i32 (sample set 0) */
+    uint64_t sample_set_stride;                                /* sample set 1 = the same offsets + this */
     uint64_t sigmas;                                           /* [M] f32 (density_scale applied) */
     uint64_t weights_sum, depth, image;                        /* [N] [N] [N,3] f32, before the background mix */
     uint64_t found_inf;                                        /* f32 [1] */

@@ -55,7 +55,9 @@ struct Layout {
     uint64_t total;
     uint64_t w_table, w_deform, w_sigma0, w_sigma1, w_color, g_table, hyper;                 // persistent
     uint64_t pk_def_f, pk_def_b, pk_col_f, pk_col_b;
-    uint64_t nears, fars, noises, rays, pts, dcol_out, dh0, march;
+    uint64_t nears, fars, noises, rays, pts, march;     // sample set 0 ...
+    uint64_t set_stride;                                //  ... set 1 = + set_stride
+    uint64_t dcol_out, dh0;
     uint64_t enc_in, def_hidden, def_out, xdef, grid_out, dy_dx, enc_rm, h1, hout, sigmas, col_in, col_hidden, col_out;
     uint64_t weights_sum, depth, image, sq_err;
     uint64_t col_bwd, dcol_in, dh, dh1, denc, dx16, ddef, def_bwd;
@@ -76,11 +78,14 @@ Layout make_layout(uint32_t N, uint32_t M, uint32_t max_steps, uint64_t table_en
     L.pk_def_b = take((uint64_t)sdn_ffh::total_frags(kDefIn, kDefW, kDefL, 1, 0) * 1024);
     L.pk_col_f = take((uint64_t)sdn_ffh::total_frags(kColIn, kColW, kColL, 0, 1) * 1024);
     L.pk_col_b = take((uint64_t)sdn_ffh::total_frags(kColIn, kColW, kColL, 1, 1) * 1024);
+    // two sets of sample buffers (phase 1 of the next batch runs beside phase 2 of this one)
     L.nears = take(n * 4);  L.fars = take(n * 4);  L.noises = take(n * 4);  L.rays = take(n * 12);
-    L.pts = take(m * 32);                       // xyzs [M,3] | dirs [M,3] | deltas [M,2], zero-filled every step ...
-    L.dcol_out = take(m * 32);                  // ... together with the gradient rows the compositing backward fills for the samples
-    L.dh0 = take(m * 2);                        //     rays own (must follow `pts`, in this order: one fill)
+    L.pts = take(m * 32);                       // xyzs [M,3] | dirs [M,3] | deltas [M,2], zero-filled by every march
     L.march = take(sdn_march_rays_train_scratch_bytes(N, max_steps));
+    L.set_stride = at - L.nears;
+    at += L.set_stride;
+    L.dcol_out = take(m * 32);                  // the gradient rows the compositing backward fills for the samples rays own:
+    L.dh0 = take(m * 2);                        // zero-filled by every step (dh0 must follow dcol_out: one fill)
     L.enc_in = take(m * kDefIn * 2);  L.def_hidden = take(m * kDefL * kDefW * 2);  L.def_out = take(m * 32);
     L.xdef = take(m * 12);  L.grid_out = take(m * kLevels * 4);  L.dy_dx = take(m * kLevels * 12);
     L.enc_rm = take(m * kSigIn * 2);  L.h1 = take(m * kSigW * 2);  L.hout = take(m * kSigOut * 2);  L.sigmas = take(m * 4);
@@ -131,16 +136,17 @@ __device__ __forceinline__ float u01(uint64_t seed, uint32_t i) {   // splitmix6
 }
 
 __global__ void __launch_bounds__(256) k_train_rays(float *__restrict__ noises, const float *__restrict__ given, uint32_t N, uint64_t seed, int perturb,
-                                                    int32_t *counter, Hyper *hyper) {
+                                                    int32_t *counter) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { counter[0] = 0; counter[1] = 0; hyper->found_inf = 0.0f; }    // renderer.py:296-298 counter.zero_()
+    if (i == 0) { counter[0] = 0; counter[1] = 0; }                              // renderer.py:296-298 counter.zero_()
     if (i < N) noises[i] = perturb ? (given ? given[i] : u01(seed, i)) : 0.0f;
 }
 
 // freq(x, 10) ++ freq(t, 6) as the fp16 input rows of the deformation MLP (freqencoder.cu:30-58's formula; the autocast cast of
 // F.linear's input).  One thread per (sample, 16th of a row).
-__global__ void __launch_bounds__(256) k_train_encode(const float *__restrict__ xyzs, uint32_t M, float time, _Float16 *__restrict__ enc) {
+__global__ void __launch_bounds__(256) k_train_encode(const float *__restrict__ xyzs, uint32_t M, float time, _Float16 *__restrict__ enc, Hyper *hyper) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) hyper->found_inf = 0.0f;       // first kernel of a step's own phase: the non-finite flag of this step's gradients
     const uint32_t b = t >> 4, j = t & 15u;
     if (b >= M) return;
     _Float16 *row = enc + (size_t)b * kDefIn;
@@ -674,7 +680,9 @@ uint32_t build_segments(const SdnTrainStep *s, const Layout &L, AdamArgs &A) {
 bool step_ok(const SdnTrainStep *s) {
     if (!s || !s->workspace || ((uintptr_t)s->workspace & 255u)) return false;
     if (s->mode < 0 || s->mode > 2) return false;
-    if (s->mode != 2 && (!s->rays_o || !s->rays_d || !s->target || !s->bitfield || !s->aabb || !s->counter || !s->loss_out)) return false;
+    if (s->phase < 0 || s->phase > 2 || (s->mode == 2 && s->phase != 0)) return false;
+    if (s->mode != 2 && s->phase != 2 && (!s->rays_o || !s->rays_d || !s->bitfield || !s->aabb || !s->counter)) return false;
+    if (s->mode != 2 && s->phase != 1 && (!s->target || !s->loss_out)) return false;
     if (s->N == 0 || s->M == 0 || s->max_steps == 0 || s->bound <= 0) return false;
     for (int i = 0; i < SDN_TRAIN_N_PARAMS; i++) if (!s->params[i].param) return false;
     if (s->mode != 1) {
@@ -700,6 +708,7 @@ int sdn_train_layout(uint32_t N, uint32_t M, uint32_t max_steps, const int32_t *
     out->w_table = L.w_table; out->w_deform = L.w_deform; out->w_sigma0 = L.w_sigma0; out->w_sigma1 = L.w_sigma1; out->w_color = L.w_color;
     out->g_table = L.g_table; out->g_deform = L.g_deform; out->g_sigma0 = L.g_sigma0; out->g_sigma1 = L.g_sigma1; out->g_color = L.g_color;
     out->xyzs = L.pts; out->dirs = L.pts + (uint64_t)M * 12; out->deltas = L.pts + (uint64_t)M * 24; out->rays = L.rays;
+    out->sample_set_stride = L.set_stride;
     out->sigmas = L.sigmas; out->weights_sum = L.weights_sum; out->depth = L.depth; out->image = L.image;
     out->found_inf = L.hyper + offsetof(Hyper, found_inf);
     return 0;
@@ -735,16 +744,22 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     const int freeze_deform = (zero_deform && !s->keep_deform) || s->deform_frozen;
     int rc;
     #define SDN_TRY(x) do { rc = (x); if (rc) return rc; } while (0)
+    const uint64_t set_off = s->sample_set ? L.set_stride : 0;
+    float *xyzs = F(L.pts + set_off), *dirs = xyzs + (size_t)M * 3, *deltas = xyzs + (size_t)M * 6;
+    const int32_t *ray_table = (const int32_t *)(ws + L.rays + set_off);
+    if (s->mode != 2 && s->phase != 2) {
+        // ---- rays -> samples (renderer.py:283-304) --------------------------------------------------------------------------------
+        hipLaunchKernelGGL(k_train_rays, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, F(L.noises + set_off), s->noises, N, s->noise_seed, s->perturb, s->counter);
+        SDN_TRY(sdn_near_far_from_aabb(s->rays_o, s->rays_d, s->aabb, N, s->min_near, F(L.nears + set_off), F(L.fars + set_off), st));
+        if (hipMemsetAsync(ws + L.pts + set_off, 0, (uint64_t)M * 32, st) != hipSuccess) return sdn_launch_status();
+        SDN_TRY(sdn_int::march_rays_train(s->rays_o, s->rays_d, s->bitfield, s->bound, s->dt_gamma, s->max_steps, N, s->cascade, s->grid_size, M,
+                                          F(L.nears + set_off), F(L.fars + set_off), xyzs, dirs, deltas, (int32_t *)(ws + L.rays + set_off), s->counter,
+                                          F(L.noises + set_off), ws + L.march + set_off, s->cull_grid, st));
+    }
+    if (s->phase == 1) return sdn_launch_status();
     if (s->mode != 2) {
-
-    // ---- rays -> samples (renderer.py:283-304) ------------------------------------------------------------------------------------
-    hipLaunchKernelGGL(k_train_rays, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, F(L.noises), s->noises, N, s->noise_seed, s->perturb, s->counter, hyper);
-    SDN_TRY(sdn_near_far_from_aabb(s->rays_o, s->rays_d, s->aabb, N, s->min_near, F(L.nears), F(L.fars), st));
-    if (hipMemsetAsync(ws + L.pts, 0, (L.dh0 - L.pts) + (uint64_t)M * 2, st) != hipSuccess) return sdn_launch_status();
+    if (hipMemsetAsync(ws + L.dcol_out, 0, (L.dh0 - L.dcol_out) + (uint64_t)M * 2, st) != hipSuccess) return sdn_launch_status();
     if (s->mode == 1 && hipMemsetAsync(ws + L.g_table, 0, (uint64_t)s->grid_offsets[kLevels] * 4, st) != hipSuccess) return sdn_launch_status();
-    float *xyzs = F(L.pts), *dirs = xyzs + (size_t)M * 3, *deltas = xyzs + (size_t)M * 6;
-    SDN_TRY(sdn_int::march_rays_train(s->rays_o, s->rays_d, s->bitfield, s->bound, s->dt_gamma, s->max_steps, N, s->cascade, s->grid_size, M, F(L.nears),
-                                      F(L.fars), xyzs, dirs, deltas, (int32_t *)(ws + L.rays), s->counter, F(L.noises), ws + L.march, s->cull_grid, st));
 
     // ---- this step's packed weights (both directions of both fused MLPs, one launch) ------------------------------------------------
     const sdn_ffh::PackJob packs[4] = {{ws + L.w_deform, ws + L.pk_def_f, kDefIn, kDefW, kDefL, 0, 1}, {ws + L.w_deform, ws + L.pk_def_b, kDefIn, kDefW, kDefL, 1, 0},
@@ -752,7 +767,7 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     SDN_TRY(sdn_ffh::pack_many(packs, 4, st));
 
     // ---- forward (network.py:123-169) ---------------------------------------------------------------------------------------------
-    hipLaunchKernelGGL(k_train_encode, dim3(sdn_div_up(M * 16u, 256u)), dim3(256), 0, st, xyzs, M, s->time, H(L.enc_in));
+    hipLaunchKernelGGL(k_train_encode, dim3(sdn_div_up(M * 16u, 256u)), dim3(256), 0, st, xyzs, M, s->time, H(L.enc_in), hyper);
     SDN_TRY(sdn_ffh::forward_packed(H(L.enc_in), ws + L.pk_def_f, M, kDefIn, kDefW, kDefL, ACT_RELU, H(L.def_hidden), H(L.def_out), st));
     hipLaunchKernelGGL(k_train_xdef, dim3(sdn_div_up(M * 3u, 256u)), dim3(256), 0, st, xyzs, H(L.def_out), M, zero_deform, s->bound, F(L.xdef));
     SDN_TRY(sdn_grid_encode_forward(F(L.xdef), ws + L.w_table, s->grid_offsets, ws + L.grid_out, M, 3, 2, kLevels, s->grid_S, s->grid_H,
@@ -761,7 +776,7 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     hipLaunchKernelGGL(k_train_sigma_fwd, dim3(sdn_div_up(M, 32u)), dim3(64), 0, st, sf);
     SDN_TRY(sdn_ffh::forward_packed(H(L.col_in), ws + L.pk_col_f, M, kColIn, kColW, kColL, ACT_RELU, H(L.col_hidden), H(L.col_out), st));
     // ---- compositing, loss, and their gradients (renderer.py:309-318, utils.py:85-125), one wave per ray ----------------------------
-    const CompositeArgs ca{F(L.sigmas), deltas, H(L.col_out), H(L.hout), (const int32_t *)(ws + L.rays), s->bg_color, s->target, s->loss_scale, F(L.weights_sum),
+    const CompositeArgs ca{F(L.sigmas), deltas, H(L.col_out), H(L.hout), ray_table, s->bg_color, s->target, s->loss_scale, F(L.weights_sum),
                            F(L.depth), F(L.image), s->image_out, F(L.sq_err), H(L.dcol_out), H(L.dh0), M, N, s->T_thresh, s->bg_value, s->density_scale};
     hipLaunchKernelGGL(k_train_composite_fwd, dim3(sdn_div_up(N, 4u)), dim3(256), 0, st, ca);
     hipLaunchKernelGGL(k_train_loss, dim3(1), dim3(1024), 0, st, F(L.sq_err), N, s->loss_out);

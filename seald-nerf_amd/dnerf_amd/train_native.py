@@ -60,9 +60,10 @@ class NativeTrainStep:
             if p.dtype != torch.float32 or not p.is_contiguous() or p.device.type != "cuda":
                 raise ValueError("NativeTrainStep: parameters must be contiguous fp32 tensors on the GPU")
         f32 = torch.float32
-        self.rays_o = torch.zeros(n_rays, 3, dtype=f32, device=device)
-        self.rays_d = torch.zeros(n_rays, 3, dtype=f32, device=device)
-        self.rays_d[:, 2] = 1
+        self._rays = [(torch.zeros(n_rays, 3, dtype=f32, device=device), torch.zeros(n_rays, 3, dtype=f32, device=device)) for _ in range(2)]
+        for _, d in self._rays:
+            d[:, 2] = 1
+        self.rays_o, self.rays_d = self._rays[0]           # the input buffers of the next step (sample set 0 unless prefetching)
         self.target = torch.zeros(n_rays, 3, dtype=f32, device=device)
         self.bg = torch.zeros(n_rays, 3, dtype=f32, device=device)
         self.image = torch.zeros(n_rays, 3, dtype=f32, device=device)
@@ -88,6 +89,7 @@ class NativeTrainStep:
         self.ema_shadow = [p.detach().clone() for p in self.params] if ema_decay is not None else None
         self.step_count, self._M, self._ws, self._rec = 0, None, None, None
         self._cull_cache, self._cull_epoch = {}, None
+        self._set, self._pending, self._side, self._before_step = 0, None, None, None
         self.grad_sync, self.train_deform = grad_sync, bool(train_deform)
         self.noises = None          # optional [n_rays] f32 device tensor: the per-ray offsets of the next steps (instead of the generator)
         self._lr_of = {}
@@ -106,8 +108,9 @@ class NativeTrainStep:
         base = self._ws.data_ptr()
         self._ws_ptr = (base + 255) // 256 * 256
         r = _sdn.SdnTrainStep()
-        r.rays_o, r.rays_d, r.target = self.rays_o.data_ptr(), self.rays_d.data_ptr(), self.target.data_ptr()
+        r.target = self.target.data_ptr()
         r.N, r.M = self.n_rays, M
+        self._pending = None                              # samples marched for another budget are of no use
         self._aabb = m.aabb_train.detach().to(self.device, torch.float32).contiguous()
         r.aabb = self._aabb.data_ptr()
         r.bound, r.min_near, r.dt_gamma = float(m.bound), float(m.min_near), self.dt_gamma
@@ -167,13 +170,66 @@ class NativeTrainStep:
         return [self.view("g_table", torch.float16, (rows * 2,)), small]
 
     # ---- one step -------------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _time_value(time):
+        return float(np.float32(float(time.reshape(-1)[0]) if isinstance(time, torch.Tensor) else float(time)))
+
     def load(self, rays_o, rays_d, target, time, bg_color=None):
-        self.rays_o.copy_(rays_o.reshape(self.rays_o.shape))
-        self.rays_d.copy_(rays_d.reshape(self.rays_d.shape))
+        if self._pending is None:                         # (a prefetched batch already has its rays in place and its samples marched)
+            self.rays_o.copy_(rays_o.reshape(self.rays_o.shape))
+            self.rays_d.copy_(rays_d.reshape(self.rays_d.shape))
+            self.time = self._time_value(time)
+        elif self._time_value(time) != self._pending["time"]:
+            raise ValueError("NativeTrainStep: this call's time differs from the prefetched batch's")
         self.target.copy_(target.reshape(self.target.shape))
-        self.time = float(np.float32(float(time.reshape(-1)[0]) if isinstance(time, torch.Tensor) else float(time)))
         if bg_color is not None:
             self.bg_color = bg_color
+
+    def _fill_scene(self, r, time_value, local_step):
+        """Everything of the argument record that marching needs (phase 0 / 1)."""
+        m = self.model
+        T = m.time_size
+        t_idx = int(min(max(np.floor(np.float32(time_value) * np.float32(T)), 0), T - 1))   # dnerf/renderer.py:285
+        r.bitfield = m.density_bitfield[t_idx].data_ptr()
+        r.cull_grid = self._cull_grid(t_idx)
+        r.counter = m.step_counter[local_step % 16].data_ptr()
+        r.noise_seed = (self.seed * 0x9E3779B1 + self.step_count) & 0xFFFFFFFFFFFFFFFF
+        r.noises = self.noises.data_ptr() if self.noises is not None else None
+
+    def prefetch(self, rays_o, rays_d, time):
+        """March the NEXT batch now, on a side stream, beside whatever step is still running: call it right after `step(...)` with the
+        batch of the following call (which then skips its own march; its `rays_o` / `rays_d` / `time` arguments are taken as given
+        here; the rays must exist by the time that preceding `step(...)` was called).  Marching reads the occupancy grid only, so nothing of the running step is touched; the samples go to the workspace's
+        second sample buffer.  Results are those of the un-prefetched sequence bit for bit (same noise stream, same counter slots)."""
+        m = self.model
+        if self._rec is None or self._M != _budget(int(m.mean_count)):
+            self._build()
+        if self._pending is not None:
+            raise RuntimeError("NativeTrainStep.prefetch(): one batch is already marched ahead")
+        q = 1 - self._set
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        side = self._side
+        # Ordering: the march may start once everything enqueued BEFORE the step still running has finished -- that covers the last
+        # step that read sample set q.  It does not wait for the running step itself (that is the point), so the rays handed in here
+        # must not be produced by work enqueued on the current stream after that step's call.
+        if self._before_step is not None:
+            side.wait_event(self._before_step)
+        else:
+            side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ro, rd = self._rays[q]
+            ro.copy_(rays_o.reshape(ro.shape))
+            rd.copy_(rays_d.reshape(rd.shape))
+            r = self._rec
+            tv = self._time_value(time)
+            r.time, r.rays_o, r.rays_d = tv, ro.data_ptr(), rd.data_ptr()
+            self._fill_scene(r, tv, m.local_step)
+            r.mode, r.phase, r.sample_set = 0, 1, q
+            _sdn.check(_sdn.lib.sdn_train_step_f16(ctypes.byref(r), _sdn.stream()), "train_step_f16 (march ahead)")
+            done = torch.cuda.Event()
+            done.record(side)
+        self._pending = {"set": q, "event": done, "time": tv, "local_step": m.local_step, "step_count": self.step_count}
 
     def __call__(self, rays_o=None, rays_d=None, target=None, time=None, bg_color=None, grads_only=False):
         """One training step on the loaded batch (arguments, if given, are copied into the step's input buffers; `time` by value).
@@ -185,13 +241,22 @@ class NativeTrainStep:
         if self._rec is None or self._M != _budget(int(m.mean_count)):
             self._build()       # `update_extra_state` moved the budget (dnerf/renderer.py:550-552): new buffers, same parameters
         r = self._rec
-        T = m.time_size
-        t_idx = int(min(max(np.floor(np.float32(self.time) * np.float32(T)), 0), T - 1))   # dnerf/renderer.py:285
-        r.time = self.time
-        r.bitfield = m.density_bitfield[t_idx].data_ptr()
-        r.cull_grid = self._cull_grid(t_idx)
-        counter = m.step_counter[m.local_step % 16]
-        r.counter = counter.data_ptr()
+        self._before_step = torch.cuda.Event()
+        self._before_step.record()
+        pend = self._pending
+        if pend is not None and (pend["local_step"] != m.local_step or pend["step_count"] != self.step_count or grads_only or self.grad_sync is not None):
+            pend = self._pending = None                   # not the batch this call is about: march again
+        if pend is not None:
+            torch.cuda.current_stream().wait_event(pend["event"])
+            self._set, self.time = pend["set"], pend["time"]
+            self.rays_o, self.rays_d = self._rays[self._set]
+            self._pending = None
+            r.phase = 2
+        else:
+            r.phase = 0
+        r.sample_set = self._set
+        r.time, r.rays_o, r.rays_d = self.time, self.rays_o.data_ptr(), self.rays_d.data_ptr()
+        self._fill_scene(r, self.time, m.local_step)
         if isinstance(self.bg_color, torch.Tensor):
             self.bg.copy_(self.bg_color.reshape(-1, 3).expand(self.n_rays, 3))
             r.bg_color, r.bg_value = self.bg.data_ptr(), 0.0
@@ -200,11 +265,9 @@ class NativeTrainStep:
         g_table, g_net = self._lr_of[id(self.params[0])], self._lr_of[id(self.params[9])]       # encoder.embeddings, sigma_net.0
         r.lr_table, r.lr_net = float(g_table["lr"]), float(g_net["lr"])
         r.beta1, r.beta2, r.eps = float(g_net["betas"][0]), float(g_net["betas"][1]), float(g_net["eps"])
-        r.noise_seed = (self.seed * 0x9E3779B1 + self.step_count) & 0xFFFFFFFFFFFFFFFF
         if self.ema_decay is not None:
             n = self.ema_updates + (0 if grads_only else 1)
             r.ema_decay = min(self.ema_decay, (1 + n) / (10 + n))       # torch_ema: num_updates is incremented before use
-        r.noises = self.noises.data_ptr() if self.noises is not None else None
         r.deform_frozen = 0 if self.train_deform else 1
         if self.grad_sync is not None and not grads_only:
             # data parallel: backward | all-reduce of the gradient buffers (sums; the optimizer divides) | optimizer

@@ -104,13 +104,13 @@ class SdnTrainStep(ctypes.Structure):
                 + [(n, ctypes.c_double) for n in ("lr_table", "lr_net", "beta1", "beta2", "eps")]
                 + [("adam_steps", _vp), ("loss_scale", _vp), ("growth_tracker", _vp), ("growth_factor", _f32), ("backoff_factor", _f32),
                    ("growth_interval", _u32), ("ema_decay", _f32), ("loss_out", _vp), ("image_out", _vp), ("workspace", _vp),
-                   ("mode", ctypes.c_int32), ("keep_deform", ctypes.c_int32), ("grad_divisor", _f32), ("deform_frozen", ctypes.c_int32)])
+                   ("mode", ctypes.c_int32), ("keep_deform", ctypes.c_int32), ("grad_divisor", _f32), ("deform_frozen", ctypes.c_int32), ("phase", ctypes.c_int32), ("sample_set", ctypes.c_int32)])
 
 
 class SdnTrainLayout(ctypes.Structure):
     """Mirror of `SdnTrainLayout` in include/sdn_hip.h."""
     _fields_ = [(n, ctypes.c_uint64) for n in ("total_bytes", "w_table", "w_deform", "w_sigma0", "w_sigma1", "w_color", "g_table", "g_deform",
-                                                "g_sigma0", "g_sigma1", "g_color", "xyzs", "dirs", "deltas", "rays", "sigmas",
+                                                "g_sigma0", "g_sigma1", "g_color", "xyzs", "dirs", "deltas", "rays", "sample_set_stride", "sigmas",
                                                 "weights_sum", "depth", "image", "found_inf")]
 
 

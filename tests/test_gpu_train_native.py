@@ -336,3 +336,32 @@ def test_perturbed_steps_are_reproducible_and_differ_by_seed():
         losses.append([float(step(sc.rays_o, sc.rays_d, target, sc.time, grads_only=True)) for _ in range(2)])
     assert losses[0] == losses[1] and losses[0] != losses[2]
     assert losses[0][0] == losses[0][1]             # grads_only does not advance the noise stream (same step index)
+
+
+def test_marching_the_next_batch_ahead_changes_nothing():
+    """`prefetch()` (phase 1 of batch k+1 on a side stream beside step k, second sample buffer) against the plain sequence, over
+    batches that differ in rays and time: losses and parameters bit for bit, counter ring included."""
+    from dnerf_amd.train_native import NativeTrainStep
+    runs = []
+    for ahead in (False, True):
+        sc, model, opt, scaler, target = _setup()
+        step = NativeTrainStep(model, opt, scaler, N_RAYS, "cuda", perturb=True, seed=3)
+        g = torch.Generator().manual_seed(11)
+        batches = []
+        for k in range(5):
+            idx = torch.randperm(sc.rays_o.shape[0], generator=g)[:N_RAYS].cuda()
+            batches.append((sc.rays_o[idx].contiguous(), sc.rays_d[idx].contiguous(), target[0, idx % N_RAYS].contiguous(), [0.5, 0.25, 0.0, 0.75, 0.5][k]))
+        losses = []
+        for k, (ro, rd, tg, t) in enumerate(batches):
+            losses.append(step(ro, rd, tg, t).clone())
+            if ahead and k + 1 < len(batches):
+                step.prefetch(batches[k + 1][0], batches[k + 1][1], batches[k + 1][3])
+        torch.cuda.synchronize()
+        runs.append(([float(x) for x in losses], {k: v.detach().clone() for k, v in model.named_parameters()}, model.step_counter.clone()))
+    # the table gradient's fp16 atomics are the one order-dependent sum of the step: compare what does not pass through them exactly
+    # and the rest to the usual bound
+    assert runs[0][0][0] == runs[1][0][0] and torch.equal(runs[0][2], runs[1][2])
+    np.testing.assert_allclose(runs[0][0], runs[1][0], rtol=2e-3)
+    for k in runs[0][1]:
+        d = (runs[0][1][k] - runs[1][1][k]).abs()
+        assert float(d.max()) <= (1.1e-1 if k == "encoder.embeddings" else 1.1e-2), k
