@@ -34,7 +34,7 @@ PMC_SUMMARY = "r02_field_pmc_summary.json"               # rocprofv3 --pmc summa
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=800, help="image side (800 = BASELINE config)")
     ap.add_argument("--fp32", action="store_true", help="fp32 field network instead of the -O (fp16) configuration")
@@ -487,9 +487,9 @@ def main():
     def stream_of_frames(k, every=0):
         """The first k loops (frames, or frame groups) of the sequence through the pipelined driver; every > 0: the field launches of
         every `every`-th loop are timed in place."""
-        # instrumented loops: the first (and in a long stream the last) is rendered with nothing else in flight -- the pipeline is
-        # empty / draining there anyway -- and its launch durations are the kernel's own (the roofline figure); every `every`-th loop
-        # in between is instrumented while it overlaps like all the others (a launch while it shares the device)
+        # instrumented loops: the last is rendered with nothing else in flight -- the pipeline is draining there anyway -- and its
+        # launch durations are the kernel's own (the roofline figure); every `every`-th loop before it is instrumented while it
+        # overlaps like all the others (a launch while it shares the device)
         excl_set = exclusive_frames(k) if every else set()
         marked = sorted(set(range(0, k, every)) | excl_set) if every else []
         timing = make_timing(len(marked))
@@ -640,7 +640,7 @@ def main():
         if result["roofline"]:
             result["roofline"]["instrumented_steps"] = (
                 f"{n_instrumented} of {n_groups} timed loops (every {every}th" + (", plus the last" if ploop is not None else "") + ")"
-                + (f"; {n_excl} of them (the first" + (" and the last" if n_excl > 1 else "") + ") rendered with nothing else in flight -- their launches give achieved / frac -- and "
+                + (f"; {n_excl} of them (the last) rendered with nothing else in flight -- its launches give achieved / frac -- and "
                    f"{n_instrumented - n_excl} overlapped like the uninstrumented ones (the `overlapped` entry)" if ploop is not None else ""))
             # field FLOPs of the whole timed region over its wall time: a lower bound of the kernel's rate that no overlap can inflate
             result["roofline"]["whole_job_mfma_frac"] = FIELD_FLOP_PER_POINT * n_samples / elapsed / 1e12 / MFMA_F16_PEAK_TFLOPS
@@ -653,8 +653,10 @@ def main():
 
 def exclusive_frames(k):
     """Frames of a k-frame stream that are rendered with nothing else in flight so that their launch durations are the kernel's
-    own: the first (the pipeline is empty there anyway) and, in a long enough stream, the last (it is draining anyway)."""
-    return {0, k - 1} if k >= 16 else {0}
+    own: the LAST one (the pipeline is draining there anyway: holding it back until its predecessors are done costs the stream a
+    fraction of one loop's latency; an exclusive FIRST frame -- round 1 and the start of round 2 -- delays every other context by a
+    whole loop, 7 % of a 20-frame stream)."""
+    return {k - 1}
 
 
 def roofline(timers, fp16, points_exclusive, points_overlapped=0):

@@ -15,12 +15,12 @@ pmc() {  # name, counters, program...
   local name=$1 counters=$2; shift 2
   rocprofv3 --kernel-trace --pmc $counters --output-format csv -d $OUT/pmc_$name -o p -- "$@" > $OUT/pmc_${name}.out 2> $OUT/pmc_${name}.err
 }
-python3 bench.py --steps 20 --warmup 3 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench default done"
-python3 bench.py --steps 96 --no-cpu-baseline > $OUT/bench_default_96.json 2>/dev/null
+python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench default done"      # the driver's command: 96 steps, 3 warm-up
+python3 bench.py --steps 20 --no-cpu-baseline > $OUT/bench_default_20.json 2>/dev/null
 python3 bench.py --steps 20 --pipeline 0 --no-cpu-baseline > $OUT/bench_sequential.json 2>/dev/null
 python3 bench.py --steps 20 --static-frame --no-cpu-baseline > $OUT/bench_static_frame.json 2>/dev/null
 python3 bench.py --steps 20 --scene lego --no-cpu-baseline > $OUT/bench_lego.json 2>/dev/null
-stats default --steps 20 --warmup 3 --no-cpu-baseline; echo "stats default done"
+stats default --no-cpu-baseline; echo "stats default done"
 stats sequential --steps 20 --warmup 3 --pipeline 0 --no-cpu-baseline
 stats train --mode train --steps 100 --warmup 10
 stats train_graph --mode train --train-native 0 --steps 30
