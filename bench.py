@@ -299,7 +299,7 @@ def seald_train_mode(args):
                       "higher_is_better": True, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "dtype": "f16", "data": "synthetic",
                       "config": {"workload": "SURVEY 3.4 / BASELINE config 4 in training: StudentTrainer.train_gui step", "rays": n_rays,
                                  "student": "deform_net frozen, one native call per step (sdn_train_step_f16, deform_frozen)",
-                                 "teacher": "device loop + fused field + seal kernels, T_thresh 1e-4",
+                                 "teacher": "one-pass ray-batch render (march, one fused-field launch, whole-ray compositing; the loop's image bit for bit) + seal kernels, T_thresh 1e-4",
                                  "reference_shaped": "SealDNeRFTeacher.render op by op + eager nn.Linear student step, torch Adam"}}))
 
 

@@ -99,6 +99,15 @@ int sdn_composite_rays_train_backward(const float *grad_weights_sum, const float
                                       uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas,
                                       float *grad_rgbs, void *stream);
 
+/* Whole-ray inference compositing (no counterpart in the reference's ABI; the arithmetic is raymarching.h:17 composite_rays'):
+ * samples in march_rays_train's (offset, count) layout, composited with the INFERENCE rules (transmittance = 1 - weights_sum,
+ * stop when the transmittance in front of a sample is < T_thresh, t running from nears[ray]).  march_rays_train (no perturbation)
+ * -> field network -> this call renders a small ray batch in one pass; image and weights_sum equal the iteration loop's
+ * (dnerf/renderer.py:333-381) bit for bit, depth to fp32 rounding (the loop re-bases t at every iteration). */
+int sdn_composite_whole_rays(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,
+                             const float *nears, uint32_t M, uint32_t N, float T_thresh, float *weights_sum,
+                             float *depth, float *image, void *stream);
+
 /* raymarching.h:16  march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma,
  *                              max_steps, C, H, grid, nears, fars, xyzs, dirs, deltas, noises)
  * xyzs, dirs [>= n_alive*n_step, 3], deltas [.., 2] zero-filled by the caller. */

@@ -821,6 +821,40 @@ __global__ void __launch_bounds__(256) k_composite_train_fwd(const float *__rest
     image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
 }
 
+// The INFERENCE compositing arithmetic (kernel_composite_rays, raymarching.cu:819-905: transmittance as 1 - weights_sum, the stop
+// test on the transmittance IN FRONT of a sample, t running from the ray's near bound) over ALL samples of a ray at once, in the
+// (offset, count) layout of march_rays_train.  With a ray's samples listed up front the iteration loop of the inference branch
+// (dnerf/renderer.py:333-381) collapses into march -> field -> this kernel: per ray the same additions in the same order, so image and
+// weights_sum are those of the loop bit for bit; the loop only exists to stop marching terminated rays early, which pays for a
+// frame of 640 000 rays and costs a chain of ~30 dependent launches for a batch of 4 096.
+__global__ void __launch_bounds__(256) k_composite_whole_rays(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                                              const float *__restrict__ deltas, const int32_t *__restrict__ rays,
+                                                              const float *__restrict__ nears, uint32_t M, uint32_t N, float T_thresh,
+                                                              float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    float weight_sum = 0, d = 0, r = 0, g = 0, b = 0;
+    if (num_steps != 0 && offset + num_steps <= M) {
+        const float *s = sigmas + offset, *c = rgbs + (size_t)offset * 3, *dl = deltas + (size_t)offset * 2;
+        float t = nears[index];
+        for (uint32_t step = 0; step < num_steps; step++) {
+            if (dl[0] == 0) break;
+            const float alpha = 1.0f - sdn_exp_cr(-s[0] * dl[0]);
+            const float T = 1 - weight_sum;
+            const float weight = alpha * T;
+            weight_sum += weight;
+            t += dl[1];
+            d += weight * t;
+            r += weight * c[0]; g += weight * c[1]; b += weight * c[2];
+            if (T < T_thresh) break;
+            s++; c += 3; dl += 2;
+        }
+    }
+    weights_sum[index] = weight_sum; depth[index] = d;
+    image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
+}
+
 // raymarching.cu:602-682
 __global__ void __launch_bounds__(256) k_composite_train_bwd(const float *__restrict__ grad_weights_sum, const float *__restrict__ grad_image,
                                                              const float *__restrict__ sigmas, const float *__restrict__ rgbs,
@@ -1651,6 +1685,15 @@ int sdn_composite_rays_train_forward(const float *sigmas, const float *rgbs, con
     if (N == 0) return 0;
     if (!sigmas || !rgbs || !deltas || !rays || !weights_sum || !depth || !image) return SDN_E_BADARG;
     hipLaunchKernelGGL(k_composite_train_fwd, dim3(sdn_div_up(N, 256u)), dim3(256), 0, (hipStream_t)stream, sigmas, rgbs, deltas, rays, M, N,
+                       T_thresh, weights_sum, depth, image);
+    return sdn_launch_status();
+}
+
+int sdn_composite_whole_rays(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, const float *nears, uint32_t M,
+                             uint32_t N, float T_thresh, float *weights_sum, float *depth, float *image, void *stream) {
+    if (N == 0) return 0;
+    if (!sigmas || !rgbs || !deltas || !rays || !nears || !weights_sum || !depth || !image) return SDN_E_BADARG;
+    hipLaunchKernelGGL(k_composite_whole_rays, dim3(sdn_div_up(N, 256u)), dim3(256), 0, (hipStream_t)stream, sigmas, rgbs, deltas, rays, nears, M, N,
                        T_thresh, weights_sum, depth, image);
     return sdn_launch_status();
 }

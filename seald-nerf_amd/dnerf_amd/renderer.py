@@ -771,3 +771,77 @@ class PipelinedDeviceLoop:
                   file=sys.stderr)
         return outputs, [int(v) for v in iters]
 
+
+
+class RayBatchRenderer:
+    """A SMALL ray batch (a training batch's proxy render, SealDNeRF/utils.py:632-656; a preview; an error-map pass) rendered in one
+    pass instead of through the iteration loop.
+
+    The inference branch (dnerf/renderer.py:333-381) marches `n_step` samples per alive ray, evaluates, composites, compacts, ~12-16
+    times: the point of the loop is to stop marching rays that have terminated, which pays for a frame of 640 000 rays.  For 4 096
+    rays it is a chain of ~30 dependent launches of almost no work (0.96 ms on the MI355X).  Here every ray's samples are listed up
+    front by the training marcher (same positions and step lengths as the inference marcher, no perturbation), the fused field
+    kernel evaluates them in ONE launch (the count is read on the device), and `sdn_composite_whole_rays` composites each ray with
+    the inference arithmetic: image and weights_sum are the loop's bit for bit, depth to fp32 rounding.  A seal mapper, if given,
+    sits between marcher and field exactly as in the loop.  Cost: the samples behind a ray's termination point are evaluated too.
+
+    `samples_per_ray` sizes the sample buffer (N * samples_per_ray slots); a batch that needs more loses its last rays -- `render(...,
+    check=True)` reads the count back and raises, `overflowed()` does the same on demand."""
+
+    def __init__(self, model, field, N, device, max_steps=1024, T_thresh=1e-2, dt_gamma=0.0, mapper=None, samples_per_ray=96):
+        import sdn_backend as B
+        B.require_device()
+        self.model, self.field, self.N, self.device, self.mapper = model, field, int(N), torch.device(device), mapper
+        self.max_steps, self.T_thresh, self.dt_gamma = int(max_steps), float(T_thresh), float(dt_gamma)
+        M = self.N * int(samples_per_ray)
+        self.M = M + (128 - M % 128)
+        f32, dev = torch.float32, self.device
+        self.flat = torch.empty(self.M * 8, dtype=f32, device=dev)
+        self.xyzs, self.dirs, self.deltas = self.flat[:3 * self.M].view(-1, 3), self.flat[3 * self.M:6 * self.M].view(-1, 3), self.flat[6 * self.M:].view(-1, 2)
+        self.rays = torch.empty(self.N, 3, dtype=torch.int32, device=dev)
+        self.counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.noises = torch.zeros(self.N, dtype=f32, device=dev)
+        self.nears, self.fars = torch.empty(self.N, dtype=f32, device=dev), torch.empty(self.N, dtype=f32, device=dev)
+        self.identity = torch.arange(self.M, dtype=torch.int32, device=dev)
+        self.scratch = torch.empty(int(B.lib.sdn_march_rays_train_scratch_bytes(self.N, self.max_steps)), dtype=torch.uint8, device=dev)
+        self.weights_sum, self.depth = torch.empty(self.N, dtype=f32, device=dev), torch.empty(self.N, dtype=f32, device=dev)
+        self.image = torch.empty(self.N, 3, dtype=f32, device=dev)
+        self.image_out, self.depth_out = torch.empty(self.N, 3, dtype=f32, device=dev), torch.empty(self.N, dtype=f32, device=dev)
+        self._aabb = model.aabb_infer.detach().to(dev, f32).contiguous()
+
+    @torch.no_grad()
+    def render(self, rays_o, rays_d, time, bg_color=1.0, check=False):
+        import sdn_backend as B
+        m, lib, st = self.model, B.lib, B.stream()
+        ro, rd = rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3)
+        if ro.shape[0] != self.N:
+            raise ValueError(f"RayBatchRenderer was built for {self.N} rays, got {ro.shape[0]}")
+        self.field.set_time(time)                       # time bias, canonical-frame flag, occupancy slice -- by VALUE, cached
+        bitfield = m.density_bitfield[self.field.t_idx]
+        B.check(lib.sdn_near_far_from_aabb(B.ptr(ro, torch.float32, "rays_o"), B.ptr(rd, torch.float32, "rays_d"), B.ptr(self._aabb), self.N,
+                                           float(m.min_near), B.ptr(self.nears), B.ptr(self.fars), st), "near_far_from_aabb")
+        self.flat.zero_()
+        self.counter.zero_()
+        B.check(lib.sdn_march_rays_train(B.ptr(ro), B.ptr(rd), B.ptr(bitfield, torch.uint8, "density_bitfield"), float(m.bound), self.dt_gamma,
+                                         self.max_steps, self.N, int(m.cascade), int(m.grid_size), self.M, B.ptr(self.nears), B.ptr(self.fars),
+                                         B.ptr(self.xyzs), B.ptr(self.dirs), B.ptr(self.deltas), B.ptr(self.rays), B.ptr(self.counter),
+                                         B.ptr(self.noises), B.ptr(self.scratch), st), "march_rays_train")
+        torch.clamp(self.counter[:1], max=self.M, out=self.count)
+        mask = self.mapper.map_to_origin_(self.xyzs, self.dirs) if self.mapper is not None else None
+        sigmas, rgbs = self.field(self.xyzs, self.dirs, live_idx=self.identity, live_count=self.count)
+        if mask is not None:
+            self.mapper.map_color_(rgbs, mask)
+        B.check(lib.sdn_composite_whole_rays(B.ptr(sigmas), B.ptr(rgbs), B.ptr(self.deltas), B.ptr(self.rays), B.ptr(self.nears), self.M, self.N,
+                                             self.T_thresh, B.ptr(self.weights_sum), B.ptr(self.depth), B.ptr(self.image), st), "composite_whole_rays")
+        bg = bg_color if isinstance(bg_color, torch.Tensor) else float(bg_color)
+        torch.addcmul(self.image, (1 - self.weights_sum).unsqueeze(-1), bg if isinstance(bg, torch.Tensor) else torch.full((1, 3), bg, device=self.device),
+                      out=self.image_out)
+        torch.div(torch.clamp(self.depth - self.nears, min=0), self.fars - self.nears, out=self.depth_out)
+        if check and self.overflowed():
+            raise RuntimeError(f"RayBatchRenderer: the batch needs {int(self.counter[0])} samples, the buffer holds {self.M} (raise samples_per_ray)")
+        return {"image": self.image_out, "depth": self.depth_out, "weights_sum": self.weights_sum, "n_samples": self.counter[:1]}
+
+    def overflowed(self):
+        """One host read-back: did the last batch need more sample slots than the buffer has?"""
+        return int(self.counter[0]) > self.M

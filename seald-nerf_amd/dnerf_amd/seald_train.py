@@ -24,10 +24,16 @@ def freeze_deformation(student):
 
 
 class EditTrainStep:
-    def __init__(self, teacher, student, mapper, optimizer, scaler, n_rays, device, time, native=True, **render_kw):
+    def __init__(self, teacher, student, mapper, optimizer, scaler, n_rays, device, time, native=True, one_pass=True, **render_kw):
+        """one_pass: the teacher's proxy render in one pass (`RayBatchRenderer`: march, one field launch, whole-ray compositing --
+        the loop's image bit for bit) instead of the iteration loop built for whole frames (a chain of ~30 launches per batch)."""
         self.teacher, self.student = teacher, student
         self.field = fused.FusedField(teacher, time, fp16=True)
-        self.loop = DeviceLoop(teacher, self.field, n_rays, device, T_thresh=1e-4, mapper=mapper)
+        if one_pass:
+            from .renderer import RayBatchRenderer
+            self.loop, self._checked = RayBatchRenderer(teacher, self.field, n_rays, device, T_thresh=1e-4, mapper=mapper), 0
+        else:
+            self.loop = DeviceLoop(teacher, self.field, n_rays, device, T_thresh=1e-4, mapper=mapper)
         if native:
             from .train_native import NativeTrainStep
             kw = {k: v for k, v in render_kw.items() if k in ("perturb", "bg_color", "dt_gamma", "max_steps", "T_thresh", "seed", "ema_decay")}
@@ -39,7 +45,10 @@ class EditTrainStep:
     def proxy_truth(self, rays_o, rays_d, time, bg_color=1.0):
         """Teacher colours [n_rays, 3] for these rays (the edited scene)."""
         # (the loop derives the time slice / time bias / canonical-frame flag from the VALUE of `time`, cached per value)
-        return self.loop.render(rays_o, rays_d, time, bg_color=bg_color, want_stats=False)["image"]
+        if isinstance(self.loop, DeviceLoop):
+            return self.loop.render(rays_o, rays_d, time, bg_color=bg_color, want_stats=False)["image"]
+        self._checked += 1
+        return self.loop.render(rays_o, rays_d, time, bg_color=bg_color, check=self._checked in (1, 2) or self._checked % 256 == 0)["image"]
 
     def __call__(self, rays_o, rays_d, time):
         target = self.proxy_truth(rays_o, rays_d, time)

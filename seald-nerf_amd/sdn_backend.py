@@ -28,6 +28,7 @@ PROTOTYPES = {
     "sdn_packbits": [_vp, _u32, _f32, _vp, _vp],
     "sdn_march_rays_train": [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sdn_composite_rays_train_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp, _vp],
+    "sdn_composite_whole_rays": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp, _vp],
     "sdn_composite_rays_train_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp],
     "sdn_march_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sdn_march_rays_ex": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp],

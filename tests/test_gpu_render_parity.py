@@ -481,3 +481,37 @@ def test_lego_scene_800x800_properties():
         assembled[idx_t] = o["image"]
     torch.cuda.synchronize()
     assert torch.equal(assembled, img)
+
+
+@pytest.mark.parametrize("with_mapper", [False, True])
+def test_one_pass_ray_batch_render_equals_the_loop(with_mapper):
+    """RayBatchRenderer (march_rays_train without perturbation -> ONE fused-field launch -> sdn_composite_whole_rays) against the
+    device loop on a 4096-ray batch, with and without a bbox seal mapper (T_thresh 1e-4, as the SealD teacher's proxy render):
+    image and weights_sum bit for bit, depth to fp32 rounding; the one-pass render evaluates at least the loop's samples."""
+    import numpy as np_
+    from dnerf_amd import fused, seal_mapper as SM
+    from dnerf_amd.bench_scene import build_scene
+    from dnerf_amd.renderer import DeviceLoop, RayBatchRenderer
+    sc = build_scene(H=128, W=128, device="cuda", seed=0)
+    mapper = None
+    if with_mapper:
+        half, centre = 0.12, (0.0, 0.47, 0.0)
+        raw = [[centre[0] + sx * half, centre[1] + sy * half, centre[2] + sz * half] for sz in (-1, 1) for sy in (-1, 1) for sx in (-1, 1)]
+        T = np_.eye(4); T[0, 3] = 0.35
+        mapper = SM.get_seal_mapper({"type": "bbox", "raw": raw, "transform": T.tolist(), "scale": [1.0, 1.0, 1.0], "boundType": "to", "hsv": [0.3, 0.0, 0.0]})
+        SM.fill_bitfield(sc.model.density_bitfield, mapper.map_data["force_fill_bound"].cpu().numpy(), sc.model.grid_size, sc.model.bound)
+    idx = torch.randperm(sc.rays_o.shape[0], generator=torch.Generator().manual_seed(5))[:4096].cuda()
+    ro, rd = sc.rays_o[idx].contiguous(), sc.rays_d[idx].contiguous()
+    for t in (0.5, 0.0, 0.83):
+        field = fused.FusedField(sc.model, t, fp16=True)
+        loop = DeviceLoop(sc.model, field, 4096, "cuda", T_thresh=1e-4, mapper=mapper)
+        want = loop.render(ro, rd, t, bg_color=1.0)
+        want = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in want.items()}
+        once = RayBatchRenderer(sc.model, fused.FusedField(sc.model, t, fp16=True), 4096, "cuda", T_thresh=1e-4, mapper=mapper)
+        got = once.render(ro, rd, t, bg_color=1.0, check=True)
+        torch.cuda.synchronize()
+        assert torch.equal(got["image"], want["image"]), float((got["image"] - want["image"]).abs().max())
+        d0, d1 = got["depth"], want["depth"]
+        assert torch.equal(torch.isnan(d0), torch.isnan(d1))
+        assert float((torch.nan_to_num(d0) - torch.nan_to_num(d1)).abs().max()) < 1e-5
+        assert int(got["n_samples"]) >= int(want["n_samples"])
