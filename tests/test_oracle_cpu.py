@@ -298,3 +298,31 @@ def test_scene_rays_and_bitfield_are_deterministic():
     ro, rd = scene.get_rays(scene.look_at_pose(), scene.intrinsics(8, 8), 8, 8)
     assert ro.shape == (64, 3) and np.allclose(np.linalg.norm(rd, axis=1), 1, atol=1e-6)
     assert np.allclose(np.linalg.norm(ro[0]), scene.CAMERA_RADIUS, atol=1e-5)
+
+
+def test_training_step_layout_and_argument_checks_on_the_host():
+    """`sdn_train_layout` is host arithmetic: every buffer 256-byte aligned, inside the block, the two sample sets one stride apart,
+    the block growing with the batch; a record that cannot be run is refused before anything is launched (no GPU here)."""
+    import ctypes
+    import sdn_backend as B
+    off = (ctypes.c_int32 * 17)()
+    rows, res = 0, [int(np.ceil(16 * np.exp2(np.log2(2048 / 16) / 15) ** i)) for i in range(16)]
+    for i, r in enumerate(res):
+        off[i] = rows
+        rows += int(np.ceil(min(2 ** 19, (r + 1) ** 3) / 8) * 8)
+    off[16] = rows
+    assert rows == 6119864                                          # the dnerf grid of dnerf/network.py:55-60 (SURVEY level table)
+    small, big = B.SdnTrainLayout(), B.SdnTrainLayout()
+    assert B.lib.sdn_train_layout(4096, 9216, 1024, off, ctypes.byref(small)) == 0
+    assert B.lib.sdn_train_layout(8192, 18432, 1024, off, ctypes.byref(big)) == 0
+    fields = [f for f, _ in B.SdnTrainLayout._fields_ if f not in ("total_bytes", "sample_set_stride", "found_inf", "dirs", "deltas")]
+    for f in fields:
+        v = getattr(small, f)
+        assert v % 256 == 0 and v < small.total_bytes, f
+    assert small.total_bytes < big.total_bytes and small.sample_set_stride % 256 == 0
+    assert small.xyzs + small.sample_set_stride < small.total_bytes
+    assert small.g_table - small.w_table >= rows * 2 * 2          # the fp16 table copy fits in front of the next persistent buffer
+    assert B.lib.sdn_train_layout(0, 9216, 1024, off, ctypes.byref(small)) == -1          # SDN_E_BADARG
+    rec = B.SdnTrainStep()
+    assert B.lib.sdn_train_step_f16(ctypes.byref(rec), None) == -1
+    assert B.lib.sdn_train_refresh(ctypes.byref(rec), None) == -1
