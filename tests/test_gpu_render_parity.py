@@ -515,3 +515,19 @@ def test_one_pass_ray_batch_render_equals_the_loop(with_mapper):
         assert torch.equal(torch.isnan(d0), torch.isnan(d1))
         assert float((torch.nan_to_num(d0) - torch.nan_to_num(d1)).abs().max()) < 1e-5
         assert int(got["n_samples"]) >= int(want["n_samples"])
+
+
+def test_one_pass_ray_batch_render_reports_a_short_sample_buffer():
+    from dnerf_amd import fused
+    from dnerf_amd.bench_scene import build_scene
+    from dnerf_amd.renderer import RayBatchRenderer
+    sc = build_scene(H=64, W=64, device="cuda", seed=0)
+    field = fused.FusedField(sc.model, sc.time, fp16=True)
+    tight = RayBatchRenderer(sc.model, field, sc.rays_o.shape[0], "cuda", samples_per_ray=1)
+    out = tight.render(sc.rays_o, sc.rays_d, sc.time)           # renders what fits, no fault ...
+    torch.cuda.synchronize()
+    assert torch.isfinite(out["image"]).all() and tight.overflowed()
+    with pytest.raises(RuntimeError):                            # ... and says so when asked
+        tight.render(sc.rays_o, sc.rays_d, sc.time, check=True)
+    with pytest.raises(ValueError):
+        tight.render(sc.rays_o[:100], sc.rays_d[:100], sc.time)
