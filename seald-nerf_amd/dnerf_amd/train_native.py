@@ -148,8 +148,22 @@ class NativeTrainStep:
             self._cull_cache[t_idx] = hit
         return hit.data_ptr()
 
-    def refresh(self):
-        """Re-derive the fp16 copies the kernels read from the fp32 parameters (after a checkpoint load, an eager step, ...)."""
+    def refresh(self, optimizer_state=False):
+        """Re-derive the fp16 copies the kernels read from the fp32 parameters (after a checkpoint load, an eager step, ...).
+        optimizer_state=True: also re-read the optimizer's state -- `optimizer.load_state_dict()` REPLACES the moment tensors and
+        carries the step counts -- and the scaler's scale tensors (`scaler.load_state_dict()` replaces them too)."""
+        if optimizer_state:
+            for i, p in enumerate(self.params):
+                st = self.opt.state[p]
+                if "exp_avg" not in st:
+                    raise RuntimeError("NativeTrainStep.refresh(optimizer_state=True): the optimizer holds no state for a trained parameter")
+                if st["exp_avg"].device != p.device:
+                    st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].to(p.device), st["exp_avg_sq"].to(p.device)
+                if i in (0, 1):
+                    self.adam_steps[i] = float(st["step"])
+            if self.scaler._scale is None:
+                self.scaler._lazy_init_scale_growth_tracker(self.device)
+            self._rec = None
         if self._rec is None:
             return self._build()
         _sdn.check(_sdn.lib.sdn_train_refresh(ctypes.byref(self._rec), _sdn.stream()), "train_refresh")
