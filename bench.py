@@ -34,7 +34,7 @@ PMC_SUMMARY = "r02_field_pmc_summary.json"               # rocprofv3 --pmc summa
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--steps", type=int, default=384)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=800, help="image side (800 = BASELINE config)")
     ap.add_argument("--fp32", action="store_true", help="fp32 field network instead of the -O (fp16) configuration")
@@ -640,7 +640,7 @@ def main():
         if result["roofline"]:
             result["roofline"]["instrumented_steps"] = (
                 f"{n_instrumented} of {n_groups} timed loops (every {every}th" + (", plus the last" if ploop is not None else "") + ")"
-                + (f"; {n_excl} of them (the last) rendered with nothing else in flight -- its launches give achieved / frac -- and "
+                + (f"; {n_excl} of them (the last" + (" and the quarter points" if n_excl > 1 else "") + ") rendered with nothing else in flight -- their launches give achieved / frac -- and "
                    f"{n_instrumented - n_excl} overlapped like the uninstrumented ones (the `overlapped` entry)" if ploop is not None else ""))
             # field FLOPs of the whole timed region over its wall time: a lower bound of the kernel's rate that no overlap can inflate
             result["roofline"]["whole_job_mfma_frac"] = FIELD_FLOP_PER_POINT * n_samples / elapsed / 1e12 / MFMA_F16_PEAK_TFLOPS
@@ -655,8 +655,9 @@ def exclusive_frames(k):
     """Frames of a k-frame stream that are rendered with nothing else in flight so that their launch durations are the kernel's
     own: the LAST one (the pipeline is draining there anyway: holding it back until its predecessors are done costs the stream a
     fraction of one loop's latency; an exclusive FIRST frame -- round 1 and the start of round 2 -- delays every other context by a
-    whole loop, 7 % of a 20-frame stream)."""
-    return {k - 1}
+    whole loop, 7 % of a 20-frame stream).  A long stream affords three more (quarter points: each holds the pipeline back for
+    about one loop latency, ~1 % of 384 frames together), which makes the figure an average over four different frames."""
+    return {k - 1} | ({k // 4, k // 2, 3 * k // 4} if k >= 128 else set())
 
 
 def roofline(timers, fp16, points_exclusive, points_overlapped=0):

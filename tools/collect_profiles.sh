@@ -15,7 +15,7 @@ pmc() {  # name, counters, program...
   local name=$1 counters=$2; shift 2
   rocprofv3 --kernel-trace --pmc $counters --output-format csv -d $OUT/pmc_$name -o p -- "$@" > $OUT/pmc_${name}.out 2> $OUT/pmc_${name}.err
 }
-python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench default done"      # the driver's command: 96 steps, 3 warm-up
+python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench default done"      # the driver's command: 384 steps, 3 warm-up
 python3 bench.py --steps 20 --no-cpu-baseline > $OUT/bench_default_20.json 2>/dev/null
 python3 bench.py --steps 20 --pipeline 0 --no-cpu-baseline > $OUT/bench_sequential.json 2>/dev/null
 python3 bench.py --steps 20 --static-frame --no-cpu-baseline > $OUT/bench_static_frame.json 2>/dev/null
@@ -38,7 +38,7 @@ pmc grid_bwd_fetch FETCH_SIZE python3 tools/grid_bwd_speed.py
 pmc grid_bwd_write WRITE_SIZE python3 tools/grid_bwd_speed.py
 echo "pmc done"
 python3 tools/grid_bwd_speed.py > $OUT/grid_bwd_speed.txt 2>/dev/null
-for cfg in "--emulate-rank-of 8 --group-frames 8 --steps 96" "--emulate-rank-of 8 --group-frames 1 --steps 96" "--emulate-rank-of 8 --group-frames 5 --steps 20" "--emulate-rank-of 4 --group-frames 4 --steps 96" "--emulate-rank-of 2 --group-frames 2 --steps 96" "--steps 96" "--steps 20"; do
+for cfg in "--emulate-rank-of 8 --group-frames 8 --steps 384" "--emulate-rank-of 8 --group-frames 8 --steps 96" "--emulate-rank-of 8 --group-frames 1 --steps 96" "--emulate-rank-of 8 --group-frames 5 --steps 20" "--emulate-rank-of 4 --group-frames 4 --steps 384" "--emulate-rank-of 2 --group-frames 2 --steps 384" "--steps 384" "--steps 96" "--steps 20"; do
   python3 bench.py $cfg --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], '| ms/frame', round(d['ms_per_step'],4), 'latency ms/loop', round(d['latency_ms_one_loop_at_a_time'],3), 'points/s', '%.4g'%d['value'], 'rays/loop', d['config']['rays_per_loop_on_this_gpu'])" "$cfg" >> $OUT/frame_groups_one_gpu.txt
 done
 python3 bench.py --mode train --steps 200 --warmup 10 > $OUT/bench_train.json 2>/dev/null
