@@ -452,14 +452,15 @@ def main():
     dloop = None
     if loop_kind == "device":
         from dnerf_amd.renderer import DeviceLoop
-        dloop = DeviceLoop(sc.model, field, n_loop, dev, frames=F)
+        dloop = DeviceLoop(sc.model, field, n_loop, dev, frames=F, keep_cull_grids=True)
     elif F > 1:
         raise SystemExit("frame groups need the device loop (fused field)")
 
     ploop = None
     if args.pipeline > 0 and dloop is not None:
         from dnerf_amd.renderer import PipelinedDeviceLoop
-        ploop = PipelinedDeviceLoop(sc.model, field, n_loop, dev, overlap_div=args.pipeline, contexts=args.contexts, frames=F)
+        # (keep_cull_grids: the occupancy grid does not change while a sequence is rendered: each slice's cull grid is derived once)
+        ploop = PipelinedDeviceLoop(sc.model, field, n_loop, dev, overlap_div=args.pipeline, contexts=args.contexts, frames=F, keep_cull_grids=True)
 
     def make_timing(frames):
         """Event pairs (created outside the timed region) for the field launches of `frames` instrumented frames."""

@@ -303,6 +303,10 @@ typedef struct SdnFrameTime {
     const uint8_t *bitfield[SDN_MAX_GROUP_FRAMES];   /* occupancy slice per frame */
     const float *field_bias0;                         /* device, [frames][128] */
     uint32_t zero_deform;                             /* bit f: frame f renders the canonical field (time == 0) */
+    uint32_t reserved_;
+    const void *cull_grid[SDN_MAX_GROUP_FRAMES];     /* optional: sdn_build_cull_grid(bitfield[f]) kept by the caller per occupancy
+                                                       * slice (a slice is rendered many times between density updates); when every
+                                                       * frame has one, the loop copies them instead of deriving them again */
 } SdnFrameTime;
 
 typedef struct SdnRenderCtx {
@@ -343,6 +347,9 @@ typedef struct SdnRenderCtx {
     uint32_t n_group_frames, rays_per_frame;
     const uint8_t *frame_bitfield[SDN_MAX_GROUP_FRAMES];
     uint8_t *slot_frame;
+    /* optional prebuilt cull grids (sdn_build_cull_grid) of `bitfield` (entry 0) / of frame_bitfield[f]: copied into cull_bits at the
+     * start of a frame instead of being derived again; any NULL entry among the frames in use = derive */
+    const void *frame_cull[SDN_MAX_GROUP_FRAMES];
 } SdnRenderCtx;
 
 /* Resets per-ray state (alive = 0..N-1, rays_t = nears, accumulators = 0), the loop record and the counters, and builds

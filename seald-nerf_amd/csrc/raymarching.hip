@@ -1547,6 +1547,21 @@ int build_cull(const uint8_t *bitfield, uint32_t *cull_bits, hipStream_t st) {
     return sdn_launch_status();
 }
 
+// cull grids the caller kept per occupancy slice -> the context's contiguous copy (one launch, 4 KiB per frame)
+struct CullCopy { const uint32_t *src[SDN_MAX_GROUP_FRAMES]; };
+__global__ void __launch_bounds__(256) k_copy_cull_grids(CullCopy srcs, uint32_t *__restrict__ dst, uint32_t words, uint32_t stride) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < words) dst[(size_t)blockIdx.y * stride + i] = srcs.src[blockIdx.y][i];
+}
+
+int copy_cull(const void *const *prebuilt, uint32_t n_frames, uint32_t *cull_bits, hipStream_t st) {
+    CullCopy c{};
+    for (uint32_t f = 0; f < n_frames && f < (uint32_t)SDN_MAX_GROUP_FRAMES; f++) c.src[f] = (const uint32_t *)prebuilt[f];
+    const uint32_t words = sdn_cull_grid_bytes() / 4u;
+    hipLaunchKernelGGL(k_copy_cull_grids, dim3(sdn_div_up(words, 256u), n_frames), dim3(256), 0, st, c, cull_bits, words, n_frames > 1 ? words : 0u);
+    return sdn_launch_status();
+}
+
 int build_cull_group(const FrameSel &fs, uint32_t *cull_bits, hipStream_t st) {
     hipLaunchKernelGGL(k_cull_meta_init, dim3(1), dim3(64), 0, st, cull_bits, fs.n_frames, fs.cull_stride);
     hipLaunchKernelGGL(k_build_cull_grid, dim3(kCullRes * kCullRes * kCullRes / 256, fs.n_frames), dim3(256), 0, st, (const uint8_t *)nullptr,

@@ -25,8 +25,13 @@ int render_begin(const SdnRenderCtx *c, void *mailbox, uint32_t frame_tag, hipSt
     int rc = loop_begin(c->N, c->max_steps, c->nears, c->alive_a, c->rays_t, c->weights_sum, c->depth, c->image, c->state, c->live_counts,
                         c->n_counters, mailbox, frame_tag, c->rays_tend, st);
     if (rc) return rc;
-    if (c->H == 128 && c->C == 1)
-        rc = c->n_group_frames > 1 ? build_cull_group(frame_sel(c), (uint32_t *)c->cull_bits, st) : build_cull(c->bitfield, (uint32_t *)c->cull_bits, st);
+    if (c->H == 128 && c->C == 1) {
+        const uint32_t nf = c->n_group_frames > 1 ? c->n_group_frames : 1u;
+        bool kept = true;
+        for (uint32_t f = 0; f < nf; f++) kept = kept && c->frame_cull[f] != nullptr;
+        if (kept) rc = copy_cull(c->frame_cull, nf, (uint32_t *)c->cull_bits, st);
+        else rc = c->n_group_frames > 1 ? build_cull_group(frame_sel(c), (uint32_t *)c->cull_bits, st) : build_cull(c->bitfield, (uint32_t *)c->cull_bits, st);
+    }
     return rc;
 }
 }  // namespace sdn_int
@@ -297,6 +302,7 @@ int sdn_render_frames_pipelined_f16(const SdnRenderCtx *const *ctxs, uint32_t n_
             if (!ft.field_bias0 || !ft.bitfield[0]) return SDN_E_BADARG;
             local[slot].bitfield = ft.bitfield[0];
             for (uint32_t f = 0; f < SDN_MAX_GROUP_FRAMES; f++) local[slot].frame_bitfield[f] = ft.bitfield[f];
+            for (uint32_t f = 0; f < SDN_MAX_GROUP_FRAMES; f++) local[slot].frame_cull[f] = ft.cull_grid[f];
             local[slot].field_bias0 = ft.field_bias0;
             local[slot].zero_deform = (int32_t)ft.zero_deform;
         }

@@ -43,6 +43,7 @@ int march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *gr
                      uint32_t H, uint32_t M, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
                      const float *noises, void *scratch, const void *prebuilt_cull, hipStream_t st);
 int build_cull_group(const FrameSel &fs, uint32_t *cull_bits, hipStream_t st);   // one cull grid per frame of the group
+int copy_cull(const void *const *prebuilt, uint32_t n_frames, uint32_t *cull_bits, hipStream_t st);   // prebuilt grids -> the context's copy
 int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count, const int32_t *state,
                       uint32_t M, const void *weights, const float *bias0, const void *table, const int32_t *offsets_host, float S,
                       uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, uint32_t expect_points,

@@ -465,7 +465,8 @@ class DeviceLoop:
     RING = 4
     MAX_TIMED = 24  # iterations whose fused-field launch can be timed in place (the headline frame has 11 + 1)
 
-    def __init__(self, model, field, N, device, max_steps=1024, T_thresh=1e-2, dt_gamma=0.0, mailbox=True, mapper=None, frames=1):
+    def __init__(self, model, field, N, device, max_steps=1024, T_thresh=1e-2, dt_gamma=0.0, mailbox=True, mapper=None, frames=1,
+                 keep_cull_grids=False):
         """frames > 1: a FRAME GROUP -- the N rays are `frames` equal, frame-major blocks (the shards of consecutive frames of a camera
         path / of successive time steps) rendered together by one loop, each at its own time (`bind(..., time=[t_0, ..., t_F-1])`):
         the chain of ~30 dependent launches of a loop is paid once per group instead of once per frame.  Per-ray results do not
@@ -475,6 +476,7 @@ class DeviceLoop:
         f32, i32 = torch.float32, torch.int32
         self.model, self.field, self.N = model, field, N
         self.frames = int(frames)
+        self.keep_cull_grids = bool(keep_cull_grids)
         if not 1 <= self.frames <= MAX_GROUP_FRAMES or N % self.frames:
             raise ValueError(f"a frame group holds 1..{MAX_GROUP_FRAMES} frames of equal ray count (N = {N}, frames = {frames})")
         M = N + 128 + 8 * 128
@@ -574,7 +576,38 @@ class DeviceLoop:
         for f, b_ in enumerate(bits):
             ft.bitfield[f] = b_.data_ptr()
         ft.field_bias0, ft.zero_deform = bias.data_ptr(), mask
-        return ft, (bias, bits)
+        culls = None
+        if self.keep_cull_grids and int(model.grid_size) == 128 and int(model.cascade) == 1:
+            culls = [self._cull_grid(s_) for s_ in slices]
+            for f, g_ in enumerate(culls):
+                ft.cull_grid[f] = g_.data_ptr()
+        return ft, (bias, bits, culls)
+
+    def _cull_grid(self, t_idx):
+        """The marcher's coarse skip grid of one occupancy slice (`sdn_build_cull_grid`), kept until the density grid is updated
+        (`model.iter_density` counts the updates) or `invalidate_cull_grids()` is called: a slice is rendered many times in between,
+        and deriving its cull grid again is two launches at the head of every frame's latency chain (eight grids per frame group)."""
+        import sdn_backend as B
+        cache = DeviceLoop._cull_cache.setdefault(id(self.model), {"epoch": None, "grids": {}})
+        if cache["epoch"] != (self.model.iter_density, self.model.density_bitfield.data_ptr()):
+            cache["epoch"], cache["grids"] = (self.model.iter_density, self.model.density_bitfield.data_ptr()), {}
+        hit = cache["grids"].get(t_idx)
+        if hit is None:
+            hit = torch.empty(int(B.lib.sdn_cull_grid_bytes()), dtype=torch.uint8, device=self.model.density_bitfield.device)
+            B.check(B.lib.sdn_build_cull_grid(self.model.density_bitfield[t_idx].data_ptr(), 128, hit.data_ptr(), B.stream()), "build_cull_grid")
+            cache["grids"][t_idx] = hit
+        return hit
+
+    _cull_cache = {}
+
+    @staticmethod
+    def invalidate_cull_grids(model=None):
+        """Forget kept cull grids (of `model`, or all): call after writing `density_bitfield` by any other means than
+        `update_extra_state` (e.g. `seal_mapper.fill_bitfield`, a checkpoint load)."""
+        if model is None:
+            DeviceLoop._cull_cache.clear()
+        else:
+            DeviceLoop._cull_cache.pop(id(model), None)
 
     def bind(self, rays_o, rays_d, time):
         """Points the context at this frame's rays and time constants (the native driver launches near_far_from_aabb itself)."""
@@ -591,6 +624,7 @@ class DeviceLoop:
         c.bitfield, c.field_bias0, c.zero_deform = ft.bitfield[0], ft.field_bias0, int(ft.zero_deform)
         for f in range(self.frames):
             c.frame_bitfield[f] = ft.bitfield[f]
+            c.frame_cull[f] = ft.cull_grid[f]
         self._frame_refs = (rays_o, rays_d, nears, fars, refs)  # keep the tensors alive while the frame is in flight
         cur = torch.cuda.current_stream()
         if self._handles is None:  # materialise raw hipEvent_t / hipStream_t handles once

@@ -63,7 +63,8 @@ MAX_GROUP_FRAMES = 16   # SDN_MAX_GROUP_FRAMES
 
 class SdnFrameTime(ctypes.Structure):
     """Mirror of `SdnFrameTime` in include/sdn_hip.h: the time-dependent constants of one frame (or of each frame of a group)."""
-    _fields_ = [("bitfield", _vp * MAX_GROUP_FRAMES), ("field_bias0", _vp), ("zero_deform", _u32)]
+    _fields_ = [("bitfield", _vp * MAX_GROUP_FRAMES), ("field_bias0", _vp), ("zero_deform", _u32), ("reserved_", _u32),
+                ("cull_grid", _vp * MAX_GROUP_FRAMES)]
 
 
 class SdnRenderCtx(ctypes.Structure):
@@ -76,7 +77,8 @@ class SdnRenderCtx(ctypes.Structure):
                 + [(n, _u32) for n in ("N", "M_cap", "n_counters", "max_steps", "C", "H")]
                 + [(n, _f32) for n in ("bound", "dt_gamma", "T_thresh", "density_scale")]
                 + [("zero_deform", ctypes.c_int32), ("aabb", _vp), ("min_near", _f32), ("reserved_", ctypes.c_int32), ("rays_tend", _vp), ("seal", _vp), ("seal_mask", _vp),
-                   ("n_group_frames", _u32), ("rays_per_frame", _u32), ("frame_bitfield", _vp * MAX_GROUP_FRAMES), ("slot_frame", _vp)])
+                   ("n_group_frames", _u32), ("rays_per_frame", _u32), ("frame_bitfield", _vp * MAX_GROUP_FRAMES), ("slot_frame", _vp),
+                   ("frame_cull", _vp * MAX_GROUP_FRAMES)])
 
 
 class SdnSealBox(ctypes.Structure):

@@ -146,3 +146,42 @@ def test_on_done_hands_finished_frames_on_in_order(model_bits):
     for f in range(6):
         assert torch.equal(copies[f], outs[f][0])
     assert not torch.equal(copies[0], copies[2])
+
+
+def test_kept_cull_grids_change_nothing_and_follow_the_bitfield(model_bits):
+    """`keep_cull_grids=True`: each occupancy slice's cull grid is derived once and copied into the context afterwards (single
+    frames, a stream, a frame group): frames bit-identical to the loops that derive it every time; after the occupancy grid was
+    written, `invalidate_cull_grids` makes the next frame use the new one."""
+    from dnerf_amd.fused import FusedField
+    from dnerf_amd.renderer import DeviceLoop, PipelinedDeviceLoop
+    model, _ = model_bits
+    H = W = 64
+    n = H * W
+    cams = [_rays(H, W, az) for az in (30.0, 100.0, 170.0, 240.0)]
+    times = [0.5, 0.0, 0.26, 0.5]
+    field = FusedField(model, 0.5)
+    plain = DeviceLoop(model, field, n, "cuda")
+    want = [plain.render(ro, rd, t)["image"].clone() for (ro, rd), t in zip(cams, times)]
+    kept = DeviceLoop(model, field, n, "cuda", keep_cull_grids=True)
+    for k in range(2):                                      # second round: every grid comes from the cache
+        for (ro, rd), t, w in zip(cams, times, want):
+            assert torch.equal(kept.render(ro, rd, t)["image"], w)
+    pl = PipelinedDeviceLoop(model, field, n, "cuda", contexts=3, keep_cull_grids=True)
+    outs = [(torch.empty(n, 3, device="cuda"), torch.empty(n, device="cuda")) for _ in cams]
+    pl.render_frames([c[0] for c in cams], [c[1] for c in cams], times, outputs=outs)
+    torch.cuda.synchronize()
+    assert all(torch.equal(o[0], w) for o, w in zip(outs, want))
+    grp = DeviceLoop(model, field, 4 * n, "cuda", frames=4, keep_cull_grids=True)
+    out = grp.render(torch.cat([c[0] for c in cams]).contiguous(), torch.cat([c[1] for c in cams]).contiguous(), times)
+    assert all(torch.equal(out["image"][f * n:(f + 1) * n], want[f]) for f in range(4))
+    # empty the occupancy grid: a kept grid is stale until invalidated
+    saved = model.density_bitfield.clone()
+    try:
+        model.density_bitfield.zero_()
+        DeviceLoop.invalidate_cull_grids(model)
+        blank = kept.render(cams[0][0], cams[0][1], times[0])
+        assert blank["n_samples"] == 0 and torch.equal(blank["image"], torch.ones_like(blank["image"]))
+    finally:
+        model.density_bitfield.copy_(saved)
+        DeviceLoop.invalidate_cull_grids(model)
+    assert torch.equal(kept.render(cams[0][0], cams[0][1], times[0])["image"], want[0])
