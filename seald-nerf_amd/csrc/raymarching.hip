@@ -742,6 +742,36 @@ __global__ void __launch_bounds__(kScanBlock) k_march_train_offsets(const uint32
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         base_out[0] = base;  // consumed by the write pass; counter itself is bumped by k_march_train_finish
         base_out[1] = s_prev + total;
+        base_out[2] = ray_base;
+    }
+}
+
+// A training batch (N of a few thousand rays) does not need the two-pass scan: ONE workgroup walks the rays in chunks of its size with
+// a running carry, writes the ray records and bumps the counters itself (the emit pass takes its bases from base_out) -- three
+// launches (block totals, offsets, finish) become one.
+__global__ void __launch_bounds__(kScanBlock) k_march_train_offsets_small(const uint32_t *__restrict__ num_steps, uint32_t N, int32_t *__restrict__ rays,
+                                                                          int32_t *__restrict__ counter, uint32_t *__restrict__ base_out) {
+    __shared__ uint32_t lds[16];
+    const uint32_t base = (uint32_t)counter[0], ray_base = (uint32_t)counter[1];
+    uint32_t carry = 0;
+    for (uint32_t c0 = 0; c0 < N; c0 += kScanBlock) {
+        const uint32_t i = c0 + threadIdx.x;
+        const uint32_t v = i < N ? num_steps[i] : 0u;
+        uint32_t total;
+        const uint32_t incl = block_inclusive_scan(v, lds, total);
+        if (i < N) {
+            const uint32_t ri = ray_base + i;
+            rays[ri * 3] = (int32_t)i;
+            rays[ri * 3 + 1] = (int32_t)(base + carry + incl - v);
+            rays[ri * 3 + 2] = (int32_t)v;
+        }
+        carry += total;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        base_out[0] = base; base_out[1] = carry; base_out[2] = ray_base;
+        counter[0] = (int32_t)(base + carry);
+        counter[1] = (int32_t)(ray_base + N);
     }
 }
 
@@ -760,12 +790,12 @@ template <bool FAST>
 __global__ void __launch_bounds__(256) k_march_train_emit(const float *__restrict__ rays_o, const float *__restrict__ rays_d, float bound,
                                                           float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                                                           const float *__restrict__ nears, const float *__restrict__ noises,
-                                                          const int32_t *__restrict__ rays, const int32_t *__restrict__ counter,
+                                                          const int32_t *__restrict__ rays, const uint32_t *__restrict__ bases,
                                                           const float *__restrict__ sample_t, float *__restrict__ xyzs,
                                                           float *__restrict__ dirs, float *__restrict__ deltas) {
     const uint32_t n = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (n >= N) return;
-    const uint32_t ray_base = (uint32_t)counter[1];  // not yet bumped: k_march_train_finish runs after this kernel
+    const uint32_t ray_base = bases[2];              // the ray counter's value before this call (the offsets pass recorded it)
     const uint32_t point_index = (uint32_t)rays[(size_t)(ray_base + n) * 3 + 1];
     const uint32_t num_steps = (uint32_t)rays[(size_t)(ray_base + n) * 3 + 2];
     if (num_steps == 0 || point_index + num_steps > M) return;
@@ -1630,7 +1660,7 @@ int sdn_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *b
     return sdn_launch_status();
 }
 
-static uint64_t train_scratch_words(uint32_t N) { return (uint64_t)N + sdn_div_up(N, kScanBlock) + 2u; }   // num_steps, block totals, bases
+static uint64_t train_scratch_words(uint32_t N) { return (uint64_t)N + sdn_div_up(N, kScanBlock) + 4u; }   // num_steps, block totals, bases
 
 uint64_t sdn_march_rays_train_scratch_bytes(uint32_t N, uint32_t max_steps) {
     // scan workspace | cull grid of the time slice | t of every sample [N, max_steps]
@@ -1681,15 +1711,20 @@ int sdn_int::march_rays_train(const float *rays_o, const float *rays_d, const ui
                                  max_steps, N, C, H, nears, fars, noises, num_steps, use_cull ? cull : nullptr, sample_t);
     else hipLaunchKernelGGL(k_march_train_count<false>, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
                             max_steps, N, C, H, nears, fars, noises, num_steps, (const uint32_t *)nullptr, sample_t);
-    hipLaunchKernelGGL(k_scan_block_totals, dim3(nb), dim3(kScanBlock), 0, st, num_steps, N, block_totals);
     // The reference writes ray records at rays[atomicAdd(counter+1, 1)] and points at atomicAdd(counter, n):
     // both bases are read on the device from the counter the caller hands in (zeroed by dnerf/renderer.py:291-292).
-    hipLaunchKernelGGL(k_march_train_offsets, dim3(nb), dim3(kScanBlock), 0, st, num_steps, N, block_totals, rays, counter, base_out);
+    const bool small = N <= 16u * kScanBlock;
+    if (small) {
+        hipLaunchKernelGGL(k_march_train_offsets_small, dim3(1), dim3(kScanBlock), 0, st, num_steps, N, rays, counter, base_out);
+    } else {
+        hipLaunchKernelGGL(k_scan_block_totals, dim3(nb), dim3(kScanBlock), 0, st, num_steps, N, block_totals);
+        hipLaunchKernelGGL(k_march_train_offsets, dim3(nb), dim3(kScanBlock), 0, st, num_steps, N, block_totals, rays, counter, base_out);
+    }
     if (fast) hipLaunchKernelGGL(k_march_train_emit<true>, dim3(sdn_div_up(N, 4u)), dim3(256), 0, st, rays_o, rays_d, bound, dt_gamma, max_steps, N, C, H, M,
-                                 nears, noises, rays, counter, sample_t, xyzs, dirs, deltas);
+                                 nears, noises, rays, base_out, sample_t, xyzs, dirs, deltas);
     else hipLaunchKernelGGL(k_march_train_emit<false>, dim3(sdn_div_up(N, 4u)), dim3(256), 0, st, rays_o, rays_d, bound, dt_gamma, max_steps, N, C, H, M,
-                            nears, noises, rays, counter, sample_t, xyzs, dirs, deltas);
-    hipLaunchKernelGGL(k_march_train_finish, dim3(1), dim3(64), 0, st, counter, base_out, N);
+                            nears, noises, rays, base_out, sample_t, xyzs, dirs, deltas);
+    if (!small) hipLaunchKernelGGL(k_march_train_finish, dim3(1), dim3(64), 0, st, counter, base_out, N);
     return sdn_launch_status();
 }
 
