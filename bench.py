@@ -42,9 +42,10 @@ def parse():
     ap.add_argument("--loop", default="auto", choices=["auto", "host", "device"], help="loop driver: per-iteration host sync, or device-driven")
     ap.add_argument("--time-every", type=int, default=4, help="record the per-launch HIP events of the tracked kernels on every K-th timed step "
                     "(each event record costs ~5 us of queue time between two dependent launches; K = 1 instruments every step)")
-    ap.add_argument("--pipeline", type=int, default=1, metavar="DIV",
+    ap.add_argument("--pipeline", type=int, default=2, metavar="DIV",
                     help="device loop: render the timed steps as a stream of frames through --contexts loop contexts; the next frame "
-                         "starts when a context is free and the newest frame in flight is down to rays / DIV alive (1 = at once; "
+                         "starts when a context is free and the newest frame in flight is down to rays / DIV alive (1 = at once; 2 = behind the newest "
+                         "frame's first march, measured 1-2 % better than at once; "
                          "0 = strictly one frame at a time)")
     ap.add_argument("--contexts", type=int, default=4, help="--pipeline: loop contexts (frames in flight); the HIP runtime is given one "
                                                             "hardware queue per context + the default stream (GPU_MAX_HW_QUEUES, if unset)")
