@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=2, metavar="DIV",
                     help="device loop: render the timed steps as a stream of frames through --contexts loop contexts; the next frame "
                          "starts when a context is free and the newest frame in flight is down to rays / DIV alive (1 = at once; 2 = behind the newest "
-                         "frame's first march, measured 1-2 % better than at once; "
+                         "frame's first march, measured 1-2 %% better than at once; "
                          "0 = strictly one frame at a time)")
     ap.add_argument("--contexts", type=int, default=4, help="--pipeline: loop contexts (frames in flight); the HIP runtime is given one "
                                                             "hardware queue per context + the default stream (GPU_MAX_HW_QUEUES, if unset)")
