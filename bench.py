@@ -458,6 +458,9 @@ def main():
         raise SystemExit("frame groups need the device loop (fused field)")
 
     ploop = None
+    if args.pipeline == 2 and n_groups <= 2 * args.contexts:
+        args.pipeline = 1    # a stream of a few loops (frame groups of a short sequence): holding the later loops back costs more than the
+                             # lockstep it avoids (4 loops of 5 frames: 0.127 against 0.115 ms per frame)
     if args.pipeline > 0 and dloop is not None:
         from dnerf_amd.renderer import PipelinedDeviceLoop
         # (keep_cull_grids: the occupancy grid does not change while a sequence is rendered: each slice's cull grid is derived once)
