@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--train-native", type=int, default=1, help="--mode train: the step as ONE native call (sdn_train_step_f16, "
                                                                  "dnerf_amd/train_native.py); 0 = the autograd step (graphed or eager)")
     ap.add_argument("--train-prefetch", type=int, default=1, help="--mode train, native step: march batch k+1 on a second stream beside step k")
+    ap.add_argument("--gather-dtype", default="f32", choices=["f32", "f16", "u8"],
+                    help="--gpus N: what the per-frame all-gather moves (fp32 as rendered; fp16; or the 8-bit pixels the reference writes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-side", type=int, default=224, help="side of the CPU-baseline sample image (224: ~15 s of CPU work)")
     return ap.parse_args()
@@ -424,7 +426,7 @@ def main():
         cam_o = [r[idx_t].contiguous() for r in cam_o]
         cam_d = [r[idx_t].contiguous() for r in cam_d]
         if world > 1:
-            gather = FrameGather(n_total, args.size, world, dev)
+            gather = FrameGather(n_total, args.size, world, dev, transport=args.gather_dtype)
     n_local = cam_o[0].shape[0]
     # Frame groups: F consecutive frames' shards rendered by ONE loop (per-ray time constants), so that the ~30 dependent launches
     # of a loop are paid once per F frames; default F = gpus (a rank's batch keeps the size of one full frame), 1 on one GPU.
@@ -625,7 +627,7 @@ def main():
                    "field": field_kind, "loop": loop_kind, "frames_per_loop": F,
                    "rays_per_loop_on_this_gpu": n_loop,
                    "frames_in_flight": ("%d loops of %d frame(s) (the next starts when the newest is down to rays/%d alive)" % (args.contexts, F, args.pipeline)) if ploop is not None else F,
-                   "parallelism": (f"ray-tiles x{world}, {F} frames per loop, one all_gather_into_tensor per frame" + (" (ONE-GPU REHEARSAL, numbers invalid)" if rehearse else "")) if world > 1
+                   "parallelism": (f"ray-tiles x{world}, {F} frames per loop, one all_gather_into_tensor per frame ({args.gather_dtype})" + (" (ONE-GPU REHEARSAL, numbers invalid)" if rehearse else "")) if world > 1
                                   else ("single GPU" + (f" rendering rank 0's shard of a {args.emulate_rank_of}-way ray split (NOT a whole-frame figure)" if args.emulate_rank_of > 1 else ""))},
     }
     if rank == 0:

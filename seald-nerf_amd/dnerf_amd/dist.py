@@ -31,22 +31,35 @@ def shard_rays(n_rays, W, rank, world, tile=16):
 
 
 class FrameGather:
-    """Pre-computed index maps + buffers for assembling the full frame on every rank."""
+    """Pre-computed index maps + buffers for assembling the full frame on every rank.
 
-    def __init__(self, n_rays, W, world, device, tile=16):
+    transport: what travels.  "f32" (default): the renderer's fp32 colours and depth, 16 B per ray -- at 8 ranks 9 MB arrive per frame
+    and rank, 60-90 us on a ring over 153 GB/s xGMI links, about what a rank needs to RENDER its share of a frame (0.09-0.12 ms), so
+    the gathers must overlap the rendering completely (they run on their own stream).  "f16": half the bytes, colours to 5e-4.
+    "u8": a quarter -- the 8-bit pixels the reference finally writes (`nerf/utils.py` test(): `(pred * 255).astype(np.uint8)` for
+    image and depth alike); the frame then is uint8 [n_rays, 4]."""
+
+    def __init__(self, n_rays, W, world, device, tile=16, transport="f32"):
         self.world = world
         shards = [shard_rays(n_rays, W, r, world, tile) for r in range(world)]
         self.per = shards[0][1]
         self.all_idx = torch.from_numpy(np.concatenate([s[0] for s in shards])).to(device)
-        self.gathered = torch.empty(world * self.per, 4, dtype=torch.float32, device=device)
-        self.frame = torch.empty(n_rays, 4, dtype=torch.float32, device=device)
+        self.transport = transport
+        self.dtype = {"f32": torch.float32, "f16": torch.float16, "u8": torch.uint8}[transport]
+        self.gathered = torch.empty(world * self.per, 4, dtype=self.dtype, device=device)
+        self.frame = torch.empty(n_rays, 4, dtype=self.dtype, device=device)
 
     def __call__(self, image_local, depth_local):
         """image_local [per,3], depth_local [per] of this rank -> full frame [n_rays, 4] (rgb, depth) on every rank."""
         import torch.distributed as dist
-        local = torch.cat([image_local, depth_local.unsqueeze(-1)], dim=1).contiguous()
+        local = torch.cat([image_local, depth_local.unsqueeze(-1)], dim=1)
+        if self.transport == "u8":      # rays that miss the box have depth 0 / 0 = NaN in the reference (dnerf/renderer.py:379): 0 on the wire
+            local = (torch.nan_to_num(local, nan=0.0).clamp(0, 1) * 255).to(torch.uint8)
+        elif self.transport == "f16":
+            local = local.to(torch.float16)
+        local = local.contiguous()
         if local.is_cuda and dist.get_backend() == "gloo":  # one-GPU rehearsal only: gloo moves host memory
-            host = torch.empty(self.gathered.shape, dtype=torch.float32)
+            host = torch.empty(self.gathered.shape, dtype=self.dtype)
             dist.all_gather_into_tensor(host, local.cpu())
             self.gathered.copy_(host)
         else:

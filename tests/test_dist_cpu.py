@@ -30,6 +30,18 @@ def _worker(rank, world, port, H, W, out_dir):
         frame = FrameGather(n, W, world, "cpu")(image, depth)
         ref = torch.arange(n).float()
         ok = torch.equal(frame, torch.stack([ref, ref * 2, ref * 3, ref * 0.5], 1))
+        # narrower transports: fp16, and the 8-bit pixels the reference writes
+        unit = torch.stack([ridx / n, ridx / (2 * n), ridx / (3 * n)], 1)
+        dep = ridx / n
+        dep[ridx.long() % 7 == 0] = float("nan")                # rays that miss the box (a function of the RAY: shards are padded with repeats)
+        want = torch.stack([ref / n, ref / (2 * n), ref / (3 * n), ref / n], 1)
+        f16 = FrameGather(n, W, world, "cpu", transport="f16")(unit, ridx / n)
+        ok = ok and f16.dtype == torch.float16 and torch.equal(f16, want.half())
+        u8 = FrameGather(n, W, world, "cpu", transport="u8")(unit, dep)
+        want8 = (want.clamp(0, 1) * 255).to(torch.uint8)
+        miss = torch.arange(n) % 7 == 0
+        want8[miss, 3] = 0
+        ok = ok and u8.dtype == torch.uint8 and torch.equal(u8, want8)
         # timing protocol of bench.py: max over ranks
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
