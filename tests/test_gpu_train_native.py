@@ -403,5 +403,5 @@ def test_checkpoint_round_trip_through_the_optimizer_and_scaler_state():
         # (bound, not tolerance: early Adam steps move an element by ~lr in the direction of sign(grad); one whose gradient is at the
         # noise level of the table atomics' summation order may walk the other way for the three resumed steps)
         assert float(d.max()) <= 2.5 * 3 * (1e-2 if k == "encoder.embeddings" else 1e-3), (k, float(d.max()))
-        assert float((d > 1e-5).float().mean()) < 2e-2, (k, float((d > 1e-5).float().mean()))
+        assert float(d.mean()) <= 0.3 * 3 * (1e-2 if k == "encoder.embeddings" else 1e-3), (k, float(d.mean()))     # ... and few do
     assert float(step2.adam_steps[0]) == 6 and int(scaler2._growth_tracker) == 6
