@@ -71,9 +71,10 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("time", [None, 0.0])
 def test_forward_and_gradients_match_the_autograd_step(time):
-    """Forward: sample count and the per-ray (offset, count) table exact, image 2e-3 (fp16 network), loss 1e-3.  Backward: every
-    weight gradient within 2 % of the autograd gradient in the L2 norm (fp16 gradients: ~1e-3 per element + the summation order of
-    ~9000 samples), the table gradient likewise; at time == 0 the deformation MLP gets no gradient (dnerf/network.py:140)."""
+    """Forward: sample count and the per-ray (offset, count) table exact, image 5e-4 (measured 4e-5), loss 1e-4 (measured equal).
+    Backward: every weight gradient within 0.5 % of the autograd gradient in the L2 norm (measured 1e-5 .. 9e-4: fp16 gradients and
+    the summation order of ~9000 samples), the table gradient likewise; at time == 0 the deformation MLP gets no gradient
+    (dnerf/network.py:140)."""
     from dnerf_amd.train_native import NativeTrainStep
     sc, model, opt, scaler, target = _setup()
     tval = sc.time if time is None else torch.tensor([[time]], dtype=torch.float32, device="cuda")
@@ -85,14 +86,14 @@ def test_forward_and_gradients_match_the_autograd_step(time):
     got_loss = step(sc.rays_o, sc.rays_d, target, tval, grads_only=True)
     torch.cuda.synchronize()
     assert torch.equal(model.step_counter[0], ref_counter)
-    np.testing.assert_allclose(float(got_loss), float(loss.detach()), rtol=1e-3)
-    assert float((step.image - out["image"][0]).abs().max()) < 2e-3
+    np.testing.assert_allclose(float(got_loss), float(loss.detach()), rtol=1e-4)
+    assert float((step.image - out["image"][0]).abs().max()) < 5e-4
     grads = _native_grads(step, model)
     for k, want in ref.items():
         if want is None:
             assert time == 0.0 and k.startswith("deform_net")
             continue
-        assert _rel(grads[k], want.float()) < 2e-2, (k, _rel(grads[k], want.float()))
+        assert _rel(grads[k], want.float()) < 5e-3, (k, _rel(grads[k], want.float()))
     # nothing was updated
     assert float(step.adam_steps.sum()) == 0 and scaler.get_scale() == 65536.0
 
