@@ -460,9 +460,10 @@ def main():
         raise SystemExit("frame groups need the device loop (fused field)")
 
     ploop = None
-    if args.pipeline == 2 and n_groups <= 2 * args.contexts:
+    if args.pipeline == 2 and n_groups <= 2 * args.contexts and world == 1:
         args.pipeline = 1    # a stream of a few loops (frame groups of a short sequence): holding the later loops back costs more than the
-                             # lockstep it avoids (4 loops of 5 frames: 0.127 against 0.115 ms per frame)
+                             # lockstep it avoids (4 loops of 5 frames: 0.127 against 0.115 ms per frame).  Not with real ranks: loops that
+                             # end at different moments let all gathers but the last run under the rendering of the others.
     if args.pipeline > 0 and dloop is not None:
         from dnerf_amd.renderer import PipelinedDeviceLoop
         # (keep_cull_grids: the occupancy grid does not change while a sequence is rendered: each slice's cull grid is derived once)
@@ -485,7 +486,7 @@ def main():
         return out
 
     def gather_outputs(img, dep):
-        """One RCCL all-gather per FRAME (+ local un-permute), for single frames and for the frames of a group alike."""
+        """One RCCL all-gather per LOOP (+ local un-permute): a frame, or the frames of a group together."""
         if F == 1:
             gather(img, dep)
         else:
@@ -627,7 +628,7 @@ def main():
                    "field": field_kind, "loop": loop_kind, "frames_per_loop": F,
                    "rays_per_loop_on_this_gpu": n_loop,
                    "frames_in_flight": ("%d loops of %d frame(s) (the next starts when the newest is down to rays/%d alive)" % (args.contexts, F, args.pipeline)) if ploop is not None else F,
-                   "parallelism": (f"ray-tiles x{world}, {F} frames per loop, one all_gather_into_tensor per frame ({args.gather_dtype})" + (" (ONE-GPU REHEARSAL, numbers invalid)" if rehearse else "")) if world > 1
+                   "parallelism": (f"ray-tiles x{world}, {F} frames per loop, one all_gather_into_tensor per loop ({args.gather_dtype})" + (" (ONE-GPU REHEARSAL, numbers invalid)" if rehearse else "")) if world > 1
                                   else ("single GPU" + (f" rendering rank 0's shard of a {args.emulate_rank_of}-way ray split (NOT a whole-frame figure)" if args.emulate_rank_of > 1 else ""))},
     }
     if rank == 0:

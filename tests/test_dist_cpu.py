@@ -93,13 +93,13 @@ def _group_worker(rank, world, port, H, W, frames, out_dir):
         image = torch.cat([torch.stack([ridx + 1000 * f, ridx * 2, ridx * 3 + f], 1) for f in range(frames)])
         depth = torch.cat([ridx * 0.5 + f for f in range(frames)])
         fg = FrameGather(n, W, world, "cpu")
-        full = fg.gather_group(image, depth, frames, keep=True)        # one all_gather_into_tensor per frame
+        full = fg.gather_group(image, depth, frames, keep=True)        # ONE all_gather_into_tensor for the group
         ref = torch.arange(n).float()
         ok = len(full) == frames
         for f in range(frames):
             ok = ok and torch.equal(full[f], torch.stack([ref + 1000 * f, ref * 2, ref * 3 + f, ref * 0.5 + f], 1))
-        last = fg.gather_group(image, depth, frames)                   # streaming form: the buffer holds the last frame
-        ok = ok and torch.equal(last, full[-1])
+        group = fg.gather_group(image, depth, frames)                  # streaming form: the group's (reused) frame buffer
+        ok = ok and tuple(group.shape) == (frames, n, 4) and all(torch.equal(group[f], full[f]) for f in range(frames))
         np.save(os.path.join(out_dir, f"grp_{rank}.npy"), np.array([ok]))
     finally:
         dist.destroy_process_group()
@@ -107,7 +107,7 @@ def _group_worker(rank, world, port, H, W, frames, out_dir):
 
 @pytest.mark.parametrize("world,H,W,frames", [(2, 64, 64, 4), (3, 40, 56, 3)])
 def test_frame_group_gather_gloo(tmp_path, world, H, W, frames):
-    """bench.py --gpus N renders N frames' shards per loop (frame group) and assembles each frame with its own all-gather."""
+    """bench.py --gpus N renders N frames' shards per loop (frame group) and assembles the group's frames with one all-gather."""
     mp.spawn(_group_worker, args=(world, _free_port(), H, W, frames, str(tmp_path)), nprocs=world, join=True)
     assert all(bool(np.load(tmp_path / f"grp_{r}.npy")[0]) for r in range(world))
 
