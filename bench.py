@@ -368,7 +368,10 @@ def main():
     # (only the modes that keep `contexts` frames in flight: queues beyond the streams in use cost as much as too few -- the
     # two-stream edit-training epoch ran at 3.8 instead of 1.3 ms per step with 5 queues)
     if args.mode in ("render", "seald"):
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, args.contexts + 1)))
+        # (ranks of a multi-GPU job also run the per-loop all-gathers on a stream of their own: one queue more, so that a collective
+        # never waits behind a loop's chain of dependent launches)
+        multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, args.contexts + (2 if multi else 1))))
     if args.mode == "train":
         return train_mode(args)
     if args.mode == "density":
