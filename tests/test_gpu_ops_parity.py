@@ -634,3 +634,33 @@ def test_march_rays_train_wave_per_ray_kernel_exact(cam, max_steps, H, full):
     for o, r, name in zip(out, ref, ("xyzs", "dirs", "deltas", "rays")):
         assert o.shape == r.shape, name
         assert np.array_equal(o.cpu().numpy().view(np.uint32), r.view(np.uint32)), name
+
+
+@pytest.mark.parametrize("H,dt_gamma", [(64, 0.0), (64, 1.0 / 128), (128, 1.0 / 256)])
+def test_generic_marcher_bound2_cascade2_other_grid_sizes(cam, H, dt_gamma):
+    """`MarcherT<false>` (bound 2, two cascades: mip_from_pos / mip_from_dt, the double-typed cell index, no cull grid / LDS image) on
+    a random two-cascade occupancy grid of H^3 cells per cascade -- inference march (ragged alive list, 8 steps) and training march
+    (counts, ray records, samples) bit for bit against the oracle; H = 64 exercises a grid size the scenes do not use."""
+    import raymarching
+    rng = np.random.default_rng(3 + H)
+    bf = (rng.random(2 * H ** 3 // 8) < 0.35).astype(np.uint8) * rng.integers(1, 256, 2 * H ** 3 // 8).astype(np.uint8)
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    ro, rd = cam["ro"] * 1.6, cam["rd"]                                 # camera pulled back: rays cross both cascades
+    nears, fars = O.near_far_from_aabb(ro, rd, aabb, 0.2)
+    N = ro.shape[0]
+    alive = np.arange(N, dtype=np.int32)[::-1].copy()[: N - 5]
+    ref = O.march_rays(alive.shape[0], 8, alive, nears.copy(), ro, rd, 2.0, bf, 2, H, nears, fars, align=128, dt_gamma=dt_gamma)
+    out = raymarching.march_rays(alive.shape[0], 8, _dev(alive), _dev(nears.copy()), _dev(ro), _dev(rd), 2.0, _dev(bf), 2, H, _dev(nears), _dev(fars),
+                                 128, False, dt_gamma, 1024)
+    for o, r, name in zip(out, ref, ("xyzs", "dirs", "deltas")):
+        assert o.shape == r.shape and np.array_equal(o.cpu().numpy().view(np.uint32), r.view(np.uint32)), name
+    assert (ref[2][:, 0] > 0).sum() > 1000
+    sel = rng.integers(0, N, 1024)
+    counter = torch.zeros(2, dtype=torch.int32, device="cuda")
+    got = raymarching.march_rays_train(_dev(ro[sel]), _dev(rd[sel]), 2.0, _dev(bf), 2, H, _dev(nears[sel]), _dev(fars[sel]), counter, -1, False, 128,
+                                       False, dt_gamma, 1024)
+    counter_r = np.zeros(2, np.int32)
+    want = O.march_rays_train(ro[sel], rd[sel], 2.0, bf, 2, H, nears[sel], fars[sel], counter_r, -1, False, 128, False, dt_gamma, 1024)
+    assert np.array_equal(counter.cpu().numpy(), counter_r) and counter_r[0] > 1000
+    for o, r, name in zip(got, want, ("xyzs", "dirs", "deltas", "rays")):
+        assert o.shape == r.shape and np.array_equal(o.cpu().numpy().view(np.uint32), r.view(np.uint32)), name
