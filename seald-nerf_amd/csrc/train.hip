@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(256) k_train_deform_grad(const _Float16 *__res
 }
 
 // ---- optimizer ------------------------------------------------------------------------------------------------------------------
-struct CheckArgs { const _Float16 *g[5]; uint32_t n8[5]; uint32_t count; Hyper *hyper; };
+struct CheckArgs { const _Float16 *g[5]; uint32_t n8[5]; uint32_t count; Hyper *hyper; uint32_t col_seg; };
 
 // GradScaler's non-finite check over every gradient of the step (amp's _amp_foreach_non_finite_check_and_unscale_)
 __global__ void __launch_bounds__(256) k_train_check(CheckArgs A) {
@@ -529,7 +529,11 @@ __global__ void __launch_bounds__(256) k_train_check(CheckArgs A) {
         const uint4 *p = reinterpret_cast<const uint4 *>(A.g[s]);
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < A.n8[s]; i += gridDim.x * blockDim.x) {
             const uint4 v = p[i];
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            // input column 16 of the colour MLP's first layer is the log-density column: its weight is structurally zero and its
+            // "gradient" (dcol_hidden^T . log-density) has no counterpart in the reference and never reaches Adam (the `split` of
+            // build_segments skips it) -- an fp16 overflow there must not skip the step.  Row r, column 16 = half 0 of uint4 4 r + 2.
+            if (s == A.col_seg && i < kColW * kColIn / 8 && (i & 3u) == 2u) w[0] &= 0xFFFF0000u;
             #pragma unroll
             for (int k = 0; k < 4; k++) bad |= ((w[k] & 0x7C00u) == 0x7C00u) | ((w[k] & 0x7C000000u) == 0x7C000000u);
         }
@@ -709,7 +713,11 @@ bool step_ok(const SdnTrainStep *s) {
     for (int i = 0; i < SDN_TRAIN_N_PARAMS; i++) if (!s->params[i].param) return false;
     if (s->mode != 1) {
         if (!s->adam_steps || !s->loss_scale || !s->growth_tracker) return false;
-        for (int i = 0; i < SDN_TRAIN_N_PARAMS; i++) if (!s->params[i].exp_avg || !s->params[i].exp_avg_sq) return false;
+        // (a frozen deformation MLP -- SealD-NeRF's edit training -- has no optimizer state: its Adam segments are never touched)
+        for (int i = 0; i < SDN_TRAIN_N_PARAMS; i++) {
+            const bool frozen = s->deform_frozen && i >= 1 && i <= (int)kDefL + 1;
+            if (!frozen && (!s->params[i].exp_avg || !s->params[i].exp_avg_sq)) return false;
+        }
     } else if (!s->loss_scale) {
         return false;
     }
@@ -831,7 +839,7 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     ck.g[0] = H(L.g_table); ck.n8[0] = table_n / 8;
     ck.g[1] = H(L.g_sigma0); ck.n8[1] = kSigW * kSigIn / 8;
     ck.g[2] = H(L.g_sigma1); ck.n8[2] = kSigOut * kSigW / 8;
-    ck.g[3] = H(L.g_color); ck.n8[3] = kColFlat / 8;
+    ck.g[3] = H(L.g_color); ck.n8[3] = kColFlat / 8; ck.col_seg = 3;
     ck.count = 4;
     if (!freeze_deform) { ck.g[4] = H(L.g_deform); ck.n8[4] = kDefFlat / 8; ck.count = 5; }
     hipLaunchKernelGGL(k_train_check, dim3(1024), dim3(256), 0, st, ck);

@@ -71,16 +71,26 @@ class NativeTrainStep:
         self.adam_steps = torch.zeros(2, dtype=f32, device=device)
         self.time = 0.5
         self._offsets = (ctypes.c_int32 * 17)(*[int(v) for v in enc.offsets.cpu().tolist()])
-        # Adam state: the optimizer's own tensors (created here if it has not stepped yet)
-        steps = []
-        for p in self.params:
+        # Adam state: the optimizer's own tensors (created here if it has not stepped yet) -- for the parameters the optimizer
+        # trains.  A parameter outside its param_groups (the frozen deformation MLP of edit training) gets NO state entry: an entry
+        # for a foreign parameter makes `optimizer.state_dict()` raise KeyError, and the native step never reads a frozen segment's
+        # moments (csrc/train.hip: step_ok, k_train_adam).
+        in_groups = {id(q) for g in optimizer.param_groups for q in g["params"]}
+        self._trained = [id(p) in in_groups for p in self.params]
+        missing = [n for n, p, t in zip(_PARAM_NAMES, self.params, self._trained) if not t and not (not train_deform and n.startswith("deform_net."))]
+        if missing:
+            raise ValueError(f"NativeTrainStep: the optimizer does not hold {missing} (only a frozen deformation MLP may be left out)")
+        steps = {}
+        for i, p in enumerate(self.params):
+            if not self._trained[i]:
+                continue
             st = optimizer.state[p]
             if "exp_avg" not in st:
                 st["step"] = torch.zeros((), dtype=f32, device=p.device) if optimizer.defaults.get("capturable") else torch.tensor(0.0, dtype=f32)
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            steps.append(float(st["step"]))
-        self.adam_steps[0], self.adam_steps[1] = steps[0], steps[1]
+            steps[i] = float(st["step"])
+        self.adam_steps[0], self.adam_steps[1] = steps[0], steps.get(1, 0.0)
         if scaler.is_enabled() and scaler._scale is None:
             scaler._lazy_init_scale_growth_tracker(self.device)
         if not scaler.is_enabled():
@@ -92,6 +102,7 @@ class NativeTrainStep:
         self._set, self._pending, self._side, self._before_step = 0, None, None, None
         self.grad_sync, self.train_deform = grad_sync, bool(train_deform)
         self.noises = None          # optional [n_rays] f32 device tensor: the per-ray offsets of the next steps (instead of the generator)
+        self._time_cache = (None, None, None)       # (tensor, _version, value) of the last `time` tensor read back
         self._lr_of = {}
         for g in optimizer.param_groups:
             for p in g["params"]:
@@ -121,9 +132,13 @@ class NativeTrainStep:
             r.grid_offsets[i] = self._offsets[i]
         r.grid_S, r.grid_H = float(np.log2(m.encoder.per_level_scale)), int(m.encoder.base_resolution)
         for i, p in enumerate(self.params):
-            st = self.opt.state[p]
             q = r.params[i]
-            q.param, q.exp_avg, q.exp_avg_sq, q.n = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+            q.param, q.n = p.data_ptr(), p.numel()
+            if self._trained[i]:
+                st = self.opt.state[p]
+                q.exp_avg, q.exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            else:
+                q.exp_avg, q.exp_avg_sq = None, None      # frozen segment: never read (deform_frozen)
             q.ema = self.ema_shadow[i].data_ptr() if self.ema_shadow is not None else None
         r.adam_steps = self.adam_steps.data_ptr()
         r.loss_scale, r.growth_tracker = self.scaler._scale.data_ptr(), self.scaler._growth_tracker.data_ptr()
@@ -139,8 +154,11 @@ class NativeTrainStep:
         m = self.model
         if int(m.grid_size) != 128 or int(m.cascade) != 1:
             return None
-        if self._cull_epoch != m.iter_density:
-            self._cull_cache, self._cull_epoch = {}, m.iter_density
+        # (the epoch also names the bitfield's storage and in-place version: `load_state_dict`, `fill_bitfield` and
+        # `reset_extra_state` rewrite the occupancy without a new `iter_density` value)
+        epoch = (m.iter_density, m.density_bitfield.data_ptr(), m.density_bitfield._version)
+        if self._cull_epoch != epoch:
+            self._cull_cache, self._cull_epoch = {}, epoch
         hit = self._cull_cache.get(t_idx)
         if hit is None:
             hit = torch.empty(int(_sdn.lib.sdn_cull_grid_bytes()), dtype=torch.uint8, device=self.device)
@@ -148,12 +166,20 @@ class NativeTrainStep:
             self._cull_cache[t_idx] = hit
         return hit.data_ptr()
 
+    def invalidate_cull_grids(self):
+        """Forget the cached skip grids (the occupancy bitfield was rewritten by something this object cannot see)."""
+        self._cull_cache, self._cull_epoch = {}, None
+
     def refresh(self, optimizer_state=False):
-        """Re-derive the fp16 copies the kernels read from the fp32 parameters (after a checkpoint load, an eager step, ...).
+        """Re-derive the fp16 copies the kernels read from the fp32 parameters (after a checkpoint load, an eager step, ...); the
+        cached skip grids are dropped too (a checkpoint load rewrites the occupancy bitfield in place).
         optimizer_state=True: also re-read the optimizer's state -- `optimizer.load_state_dict()` REPLACES the moment tensors and
         carries the step counts -- and the scaler's scale tensors (`scaler.load_state_dict()` replaces them too)."""
+        self.invalidate_cull_grids()
         if optimizer_state:
             for i, p in enumerate(self.params):
+                if not self._trained[i]:
+                    continue
                 st = self.opt.state[p]
                 if "exp_avg" not in st:
                     raise RuntimeError("NativeTrainStep.refresh(optimizer_state=True): the optimizer holds no state for a trained parameter")
@@ -184,9 +210,18 @@ class NativeTrainStep:
         return [self.view("g_table", torch.float16, (rows * 2,)), small]
 
     # ---- one step -------------------------------------------------------------------------------------------------------------------
-    @staticmethod
-    def _time_value(time):
-        return float(np.float32(float(time.reshape(-1)[0]) if isinstance(time, torch.Tensor) else float(time)))
+    def _time_value(self, time):
+        """The time stamp as a host float.  A host number costs nothing; a DEVICE tensor (what the reference's loader hands over,
+        dnerf/provider.py) costs a blocking read-back, so its value is cached per tensor OBJECT and in-place version (the cache keeps
+        the tensor alive: an address alone can be recycled by another tensor with another value): a loader that reuses its time
+        tensor, or passes a float, keeps the step free of host synchronisation."""
+        if not isinstance(time, torch.Tensor):
+            return float(np.float32(float(time)))
+        if time.device.type != "cuda":
+            return float(np.float32(float(time.reshape(-1)[0])))
+        if self._time_cache[0] is not time or self._time_cache[1] != time._version:
+            self._time_cache = (time, time._version, float(np.float32(float(time.reshape(-1)[0]))))
+        return self._time_cache[2]
 
     def load(self, rays_o, rays_d, target, time, bg_color=None):
         if self._pending is None:                         # (a prefetched batch already has its rays in place and its samples marched)
@@ -305,4 +340,5 @@ class NativeTrainStep:
         `optimizer.state_dict()` / an eager `optimizer.step()`."""
         main, deform = [float(v) for v in self.adam_steps.tolist()]
         for i, p in enumerate(self.params):
-            self.opt.state[p]["step"].fill_(deform if 1 <= i <= 8 else main)
+            if self._trained[i]:
+                self.opt.state[p]["step"].fill_(deform if 1 <= i <= 8 else main)

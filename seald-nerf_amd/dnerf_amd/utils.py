@@ -67,6 +67,21 @@ def get_rays(poses, intrinsics, H, W, N=-1, error_map=None, patch_size=1):
     return results
 
 
+def _numpy_data_globals():
+    """(callable, pickled name) pairs of numpy's data-only reconstructors, under the module paths numpy 1.x and 2.x write."""
+    import numpy as np
+    try:
+        from numpy._core import multiarray as ma
+    except ImportError:                                  # numpy 1.x
+        from numpy.core import multiarray as ma
+    out = []
+    for mod in ("numpy.core.multiarray", "numpy._core.multiarray"):
+        out += [(ma.scalar, mod + ".scalar"), (ma._reconstruct, mod + "._reconstruct")]
+    out += [np.ndarray, np.dtype]
+    out += list({type(np.dtype(t)) for t in ("float64", "float32", "float16", "int64", "int32", "int16", "int8", "uint8", "bool")})
+    return out
+
+
 def load_reference_checkpoint(model, path, map_location="cpu", optimizer=None, lr_scheduler=None, scaler=None, ema=None, model_only=True):
     """Loads a checkpoint written by the reference's trainer (`Trainer.save_checkpoint`, nerf/utils.py:1033-1093) into a
     `dnerf_amd.network.NeRFNetwork`, the way `Trainer.load_checkpoint` (:1095-1154) does:
@@ -78,10 +93,23 @@ def load_reference_checkpoint(model, path, map_location="cpu", optimizer=None, l
     Parameter and buffer names are the reference's (`encoder.embeddings`, `deform_net.N.weight`, `density_bitfield`, ...), so the
     model entry is a plain name match with strict=False.  With model_only=False the optimizer / lr_scheduler / scaler / ema given
     are restored from their entries when present (a failure to restore one of them is reported, not raised, as in the reference).
-    The file is read with `weights_only=True` (nothing in it is executed).
+    The file is read with `weights_only=True` (nothing in it is executed).  The reference's `stats['results']` /
+    `stats['best_result']` hold numpy.float64 scalars (`PSNRMeter.measure()`, nerf/utils.py:1017-1018,1073-1075), which the
+    weights-only unpickler refuses by default: the data-only numpy reconstructors (scalar / dtype / ndarray rebuild, under both the
+    numpy 1.x and 2.x module paths) are allow-listed for this one read -- they build values from bytes and call nothing.  Any
+    other global in the file is still refused, and the error then names it.
     Returns (missing_keys, unexpected_keys); the trainer bookkeeping is left in `load_reference_checkpoint.last`
     ({'epoch', 'global_step', 'stats', 'restored': [...], 'failed': [...]})."""
-    blob = torch.load(path, map_location=map_location, weights_only=True)
+    try:
+        with torch.serialization.safe_globals(_numpy_data_globals()):
+            blob = torch.load(path, map_location=map_location, weights_only=True)
+    except Exception as exc:
+        try:
+            extra = sorted(torch.serialization.get_unsafe_globals_in_checkpoint(path))
+        except Exception:
+            extra = []
+        raise RuntimeError(f"load_reference_checkpoint: {path} cannot be read by the weights-only loader"
+                           + (f" (globals it would have to execute: {extra})" if extra else "") + f": {exc}") from exc
     info = {"epoch": None, "global_step": None, "stats": None, "restored": [], "failed": []}
     load_reference_checkpoint.last = info
     if not (isinstance(blob, dict) and "model" in blob):

@@ -519,7 +519,7 @@ def test_load_full_reference_layout_checkpoint(tmp_path):
         scaler_a.scale(loss).backward()
         scaler_a.step(opt_a); scaler_a.update(); sched_a.step()
     ema_state = {"decay": 0.95, "num_updates": 2, "shadow_params": [p.detach().clone() for p in a.parameters()], "collected_params": None}
-    state = {"epoch": 5, "global_step": 1234, "stats": {"loss": [0.5, 0.25], "valid_loss": [], "results": [0.1], "checkpoints": [], "best_result": 0.1},
+    state = {"epoch": 5, "global_step": 1234, "stats": {"loss": [0.5, 0.25], "valid_loss": [], "results": [np.float64(0.1)], "checkpoints": [], "best_result": np.float64(0.1)},   # numpy scalars, as PSNRMeter.measure() returns them
              "mean_count": 4321, "mean_density": 0.125, "optimizer": opt_a.state_dict(), "lr_scheduler": sched_a.state_dict(),
              "scaler": scaler_a.state_dict(), "ema": ema_state, "model": a.state_dict()}
     full = str(tmp_path / "ngp_ep0005.pth")
