@@ -71,7 +71,12 @@ def parse():
     ap.add_argument("--gather-dtype", default="f32", choices=["f32", "f16", "u8"],
                     help="--gpus N: what the per-frame all-gather moves (fp32 as rendered; fp16; or the 8-bit pixels the reference writes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-side", type=int, default=224, help="side of the CPU-baseline sample image (224: ~15 s of CPU work)")
+    ap.add_argument("--cpu-baseline-side", type=int, default=224, help="side of the CPU-baseline sample of the 800x800 camera (224: ~12 s of CPU work; "
+                                                                       "800 = the whole frame SURVEY 8(d) names, ~160 s)")
+    ap.add_argument("--min-timed-s", type=float, default=0.25,
+                    help="the K-step stream is repeated inside the timed region until it lasts at least this long (ms_per_step = elapsed / "
+                         "frames rendered; `repeats` in the output; 0 = exactly one pass)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the marcher / grid_encode side measurements (roofline_secondary, grid_gather_rate)")
     return ap.parse_args()
 
 
@@ -488,16 +493,46 @@ def main():
         torch.cuda.synchronize()
         return out
 
+    class GatherStats:
+        """Event pairs around every per-loop gather (recorded on the stream the gather runs on: the helper thread's), so that the first
+        real multi-GPU run says where the time went: per rank, the device-side span of the renders, the summed duration of the gathers,
+        and how much of it was NOT hidden under rendering (gather time after the last render finished)."""
+
+        def __init__(self):
+            self.pairs = []
+
+        def reset(self):
+            self.pairs = []
+
+        def wrap(self, fn):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            self.pairs.append((a, b))
+
+        def summary(self, done_events, start_ev):
+            if not self.pairs or not done_events:
+                return {}
+            gather_ms = sum(a.elapsed_time(b) for a, b in self.pairs)
+            render_ms = max(start_ev.elapsed_time(e) for e in done_events)          # start of the stream -> the last loop's last kernel
+            gathers_end = start_ev.elapsed_time(self.pairs[-1][1])
+            exposed = max(0.0, gathers_end - render_ms)
+            return {"loops": len(done_events), "render_ms": render_ms, "gathers": len(self.pairs), "gather_ms_total": gather_ms,
+                    "gather_ms_mean": gather_ms / len(self.pairs), "gather_ms_exposed_after_last_render": exposed,
+                    "gather_hidden_frac": 1.0 - min(1.0, exposed / max(gather_ms, 1e-9))}
+
+    gather_stats, rank_stats = GatherStats(), {}
+
     def gather_outputs(img, dep):
         """One RCCL all-gather per LOOP (+ local un-permute): a frame, or the frames of a group together."""
-        if F == 1:
-            gather(img, dep)
-        else:
-            gather.gather_group(img, dep, F)
+        gather_stats.wrap((lambda: gather(img, dep)) if F == 1 else (lambda: gather.gather_group(img, dep, F)))
 
-    def stream_of_frames(k, every=0):
-        """The first k loops (frames, or frame groups) of the sequence through the pipelined driver; every > 0: the field launches of
-        every `every`-th loop are timed in place."""
+    def stream_of_frames(k, every=0, reps=1):
+        """The first k loops (frames, or frame groups) of the sequence, `reps` times over, through the pipelined driver as ONE stream;
+        every > 0: the field launches of every `every`-th loop are timed in place."""
+        loops_o, loops_d, loops_t = grp_o[:k] * reps, grp_d[:k] * reps, grp_t[:k] * reps
+        k = k * reps
         # instrumented loops: the last is rendered with nothing else in flight -- the pipeline is draining there anyway -- and its
         # launch durations are the kernel's own (the roofline figure); every `every`-th loop before it is instrumented while it
         # overlaps like all the others (a launch while it shares the device)
@@ -510,18 +545,24 @@ def main():
             per_frame[f] = next(it)
             exclusive[f] = f in excl_set
         outputs = None
-        if world > 1:  # every loop keeps its own shard output until it has been gathered
-            outputs = [(torch.empty(n_loop, 3, dtype=torch.float32, device=dev), torch.empty(n_loop, dtype=torch.float32, device=dev))
-                       for _ in range(k)]
+        if world > 1:  # every loop keeps its own shard output until it has been gathered (a ring of buffers: 4 loops are in flight)
+            ring = [(torch.empty(n_loop, 3, dtype=torch.float32, device=dev), torch.empty(n_loop, dtype=torch.float32, device=dev))
+                    for _ in range(min(k, 4 * args.contexts))]
+            outputs = [ring[i % len(ring)] for i in range(k)]
         barrier()
+        start_ev = torch.cuda.Event(enable_timing=True)
+        start_ev.record()
         t0 = time.perf_counter()
         # multi-GPU: a helper thread issues the per-frame all-gathers of a loop the moment that loop's last kernel is enqueued, on its
         # own stream, while the later loops still render (the driver call itself only returns when every loop has finished)
-        outs, iters = ploop.render_frames(grp_o[:k], grp_d[:k], grp_t[:k], outputs=outputs,
+        outs, iters = ploop.render_frames(loops_o, loops_d, loops_t, outputs=outputs,
                                           timing=[p[0] if p else None for p in per_frame] if every else None,
                                           exclusive=exclusive if every else None,
                                           on_done=(lambda f, img, dep: gather_outputs(img, dep)) if world > 1 else None)
         t1 = time.perf_counter()
+        if world > 1:      # device-side spans of this rank, before the closing barrier: renders (first launch -> last loop's done event)
+            torch.cuda.synchronize()
+            rank_stats.update(gather_stats.summary(ploop.last_done_events, start_ev))
         barrier()
         elapsed = time.perf_counter() - t0
         if os.environ.get("SDN_DRIVER_STATS"):
@@ -530,7 +571,7 @@ def main():
             if p:
                 key = "field_forward_f16" if exclusive[f] else "field_forward_f16_overlapped"
                 timers.records.setdefault(key, []).extend(p[1][: min(DeviceLoop.MAX_TIMED, iters[f])])
-        return elapsed, outs
+        return elapsed, outs, marked, excl_set
 
     def time_tensor(t):
         return torch.tensor([[t]], dtype=torch.float32, device=dev)
@@ -566,9 +607,8 @@ def main():
         torch.cuda.synchronize()
 
     every = max(1, args.time_every)
-    if world > 1 or (ploop is not None and n_groups < 8):
-        every = 0    # multi-GPU runs and very short streams are not instrumented: an exclusive (alone-on-the-device) loop would be a
-                     # large part of the stream, and the roofline figure is a one-GPU quantity
+    if world > 1:
+        every = 0    # multi-GPU runs are not instrumented: the roofline figure is a one-GPU quantity
     n_instrumented = len(range(0, n_groups, every)) if every else 0
     # A generation-2 pass of CPython's cyclic collector costs tens of milliseconds with torch + numpy loaded and fires on allocation
     # counts, i.e. inside the timed region for some argument combinations and not for others (seen: 20 frames in 14 ms of driver
@@ -576,18 +616,39 @@ def main():
     import gc
     gc.collect()
     gc.disable()
+    reps, marked, excl_set = 1, [], set()
     if ploop is not None:
-        stream_of_frames(min(n_groups, max(args.contexts, args.warmup)))           # warm every context
-        elapsed, _ = stream_of_frames(n_groups, every)
+        warm_s, _, _, _ = stream_of_frames(min(n_groups, max(args.contexts, args.warmup)))           # warm every context
+        # The driver's command times K = 20 steps: 13 ms.  The K-step stream is therefore repeated inside the timed region until it
+        # lasts >= --min-timed-s (estimated from the warm-up stream); ms_per_step = elapsed / loops rendered.
+        est = warm_s / min(n_groups, max(args.contexts, args.warmup)) * n_groups
+        reps = max(1, int(np.ceil(args.min_timed_s / max(est, 1e-6)))) if args.min_timed_s > 0 else 1
+        if world > 1:      # every rank must render the same number of loops
+            rt = torch.tensor([reps], dtype=torch.int64, device="cpu" if rehearse else dev)
+            dist.all_reduce(rt, op=dist.ReduceOp.MAX)
+            reps = int(rt.item())
+        gather_stats.reset()
+        every_eff = every if every else 0
+        if every_eff and n_groups * reps < 8:
+            every_eff = 0
+        elapsed, _, marked, excl_set = stream_of_frames(n_groups, every_eff, reps)
+        every = every_eff
     else:
+        one = None
+        if dloop is not None and args.min_timed_s > 0:
+            barrier(); t0 = time.perf_counter(); step(0); barrier()
+            one = time.perf_counter() - t0
+            reps = max(1, int(np.ceil(args.min_timed_s / max(one * n_groups, 1e-6))))
+        n_instrumented = len(range(0, n_groups * reps, every)) if every else 0
         if dloop is not None:
             dloop.prepare_timing(n_instrumented)  # event pairs for the in-place timing of the fused-field launches, created up front
         barrier()
         t0 = time.perf_counter()
-        for i in range(n_groups):
-            step(i, timed=bool(every) and (i % every == 0))
+        for i in range(n_groups * reps):
+            step(i % n_groups, timed=bool(every) and (i % every == 0))
         barrier()
         elapsed = time.perf_counter() - t0
+        marked = list(range(0, n_groups * reps, every)) if every else []
     # latency of ONE loop with nothing else in flight (what --pipeline 0 reports as ms_per_step), same sequence, after the timed region
     latency_ms = None
     if dloop is not None:
@@ -600,7 +661,12 @@ def main():
             lat.append((time.perf_counter() - t0) * 1e3)
         latency_ms = sorted(lat)[len(lat) // 2]
     gc.enable()
+    all_rank_stats = None
     if world > 1:
+        # per-rank device-side spans (render_ms: first launch -> last loop done; gather_ms_*: events on the gather stream; how much of
+        # the gather time was hidden under rendering): what the first real N-GPU run should be read by
+        all_rank_stats = [None] * world
+        dist.all_gather_object(all_rank_stats, dict(rank_stats, rank=rank, elapsed_ms=elapsed * 1e3))
         cdev = "cpu" if rehearse else dev
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -610,10 +676,12 @@ def main():
         n_samples = int(ns.item())
     else:
         n_samples = n_samples_local
-    ms_per_step = elapsed / K * 1e3
+    frames_rendered = K * reps
+    n_samples *= reps
+    ms_per_step = elapsed / frames_rendered * 1e3
     points_per_s = n_samples / elapsed
     n_rays_frame = n_total if args.emulate_rank_of <= 1 else n_local
-    rays_per_s = n_rays_frame * K / elapsed
+    rays_per_s = n_rays_frame * frames_rendered / elapsed
 
     seq = ("one camera at t = 0.5, repeated" if args.static_frame else
            f"test sequence of {n_cams} frames (camera orbit, one time stamp per frame, t = 0 .. 1: every frame selects its own occupancy "
@@ -621,13 +689,14 @@ def main():
     result = {
         "metric": METRIC, "value": points_per_s, "unit": "sampled-points/s", "rays_per_s": rays_per_s,
         "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "repeats": reps, "frames_rendered": frames_rendered, "timed_region_s": elapsed,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f16" if fp16 else "f32", "data": "synthetic",
         "latency_ms_one_loop_at_a_time": latency_ms,
         "config": {"workload": f"dnerf {args.scene}-like {args.size}x{args.size} full-frame inference render, "
                                f"{'-O (fp16 field network, fp16 grid table)' if fp16 else 'fp32'}, {seq}, "
                                f"T_thresh 1e-2, max_steps 1024, dt_gamma 0",
-                   "rays": n_total, "sampled_points_per_frame": n_samples / K, "loop_iterations": n_iters,
+                   "rays": n_total, "sampled_points_per_frame": n_samples / frames_rendered, "loop_iterations": n_iters,
                    "field": field_kind, "loop": loop_kind, "frames_per_loop": F,
                    "rays_per_loop_on_this_gpu": n_loop,
                    "frames_in_flight": ("%d loops of %d frame(s) (the next starts when the newest is down to rays/%d alive)" % (args.contexts, F, args.pipeline)) if ploop is not None else F,
@@ -635,31 +704,115 @@ def main():
                                   else ("single GPU" + (f" rendering rank 0's shard of a {args.emulate_rank_of}-way ray split (NOT a whole-frame figure)" if args.emulate_rank_of > 1 else ""))},
     }
     if rank == 0:
+        def loop_samples(g):     # sampled points of loop g of the (repeated) stream
+            g = g % n_groups
+            return distinct[tuple(frame_cam[g * F:(g + 1) * F])][0]
         if not every:
-            marked, n_excl, excl_samples, over_samples = [], 0, 0, 0
+            n_excl, excl_samples, over_samples = 0, 0, 0
         elif ploop is not None:
-            marked = sorted(set(range(0, n_groups, every)) | exclusive_frames(n_groups))
-            n_instrumented, n_excl = len(marked), len(exclusive_frames(n_groups))
-            excl_samples = sum(distinct[tuple(frame_cam[g * F:(g + 1) * F])][0] for g in exclusive_frames(n_groups))
-            over_samples = sum(distinct[tuple(frame_cam[g * F:(g + 1) * F])][0] for g in marked if g not in exclusive_frames(n_groups))
+            n_instrumented, n_excl = len(marked), len(excl_set)
+            excl_samples = sum(loop_samples(g) for g in excl_set)
+            over_samples = sum(loop_samples(g) for g in marked if g not in excl_set)
         else:
-            marked = list(range(0, n_groups, every))
-            n_excl = n_instrumented
-            excl_samples = sum(distinct[tuple(frame_cam[g * F:(g + 1) * F])][0] for g in marked)
+            n_excl = n_instrumented = len(marked)
+            excl_samples = sum(loop_samples(g) for g in marked)
             over_samples = 0
         result["roofline"], result["kernel_times"] = roofline(timers, fp16, excl_samples, over_samples) if every else (None, {})
         if result["roofline"]:
             result["roofline"]["instrumented_steps"] = (
-                f"{n_instrumented} of {n_groups} timed loops (every {every}th" + (", plus the last" if ploop is not None else "") + ")"
+                f"{n_instrumented} of {n_groups * reps} timed loops (every {every}th" + (", plus the last" if ploop is not None else "") + ")"
                 + (f"; {n_excl} of them (the last" + (" and the quarter points" if n_excl > 1 else "") + ") rendered with nothing else in flight -- their launches give achieved / frac -- and "
                    f"{n_instrumented - n_excl} overlapped like the uninstrumented ones (the `overlapped` entry)" if ploop is not None else ""))
             # field FLOPs of the whole timed region over its wall time: a lower bound of the kernel's rate that no overlap can inflate
             result["roofline"]["whole_job_mfma_frac"] = FIELD_FLOP_PER_POINT * n_samples / elapsed / 1e12 / MFMA_F16_PEAK_TFLOPS
+        if world == 1 and dloop is not None and not args.no_secondary and args.emulate_rank_of <= 1:
+            result["roofline_secondary"] = marcher_roofline(dloop, grp_o, grp_d, grp_t, n_groups, distinct, frame_cam, F)
+            result["grid_gather_rate"] = grid_gather_rate(sc, dev)
+        if world > 1:
+            result["ranks"] = all_rank_stats
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sc, args.cpu_baseline_side)
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+MARCH_BYTES_PER_SAMPLE = 33.0       # 32 B written per emitted sample (xyz, dir, 2 deltas) + ~1 B of occupancy bits per probe
+COMPOSITE_BYTES_PER_SAMPLE = 24.0   # sigma, rgb, 2 deltas read per composited sample
+
+
+def marcher_roofline(dloop, grp_o, grp_d, grp_t, n_groups, distinct, frame_cam, F):
+    """`roofline_secondary`: the inference marchers (k_march_rays* before steady mode, k_composite_march* in it; raymarching.cu:701-815,
+    819-914) timed in place -- the frame driver's per-iteration event pairs are moved from the field launch to the marcher launch
+    (sdn_render_time_kernel) for four frames rendered one at a time after the timed region.  Algorithmic bytes: 33 B per emitted
+    sample + 24 B per composited sample (the fused kernel composites iteration k and marches k + 1); the kernels are latency-bound
+    (one dependent chain per ray), so the fraction of the HBM roof is small by nature -- the figure to watch is ms per frame."""
+    import sdn_backend
+    frames = min(4, n_groups)
+    t = sdn_backend.KernelTimers()
+    sdn_backend.check(sdn_backend.lib.sdn_render_time_kernel(1), "render_time_kernel")
+    samples = 0
+    try:
+        dloop.prepare_timing(frames)
+        sdn_backend.timers = t
+        for g in range(frames):
+            dloop.render(grp_o[g], grp_d[g], grp_t[g], want_stats=False)
+            samples += distinct[tuple(frame_cam[g * F:(g + 1) * F])][0]
+        torch.cuda.synchronize()
+    finally:
+        sdn_backend.timers = None
+        sdn_backend.check(sdn_backend.lib.sdn_render_time_kernel(0), "render_time_kernel")
+    summ = t.summary().get("field_forward_f16")      # (the event pairs keep their name; they bracketed the marcher launches here)
+    if not summ:
+        return None
+    per_frame_ms = summ["total_ms"] / frames
+    bytes_per_frame = (MARCH_BYTES_PER_SAMPLE + COMPOSITE_BYTES_PER_SAMPLE) * samples / frames
+    achieved = bytes_per_frame / (per_frame_ms * 1e-3) / 1e9
+    return {"kernel": "inference marchers (k_march_rays_g / k_composite_march_g; lane-per-ray forms with SDN_GROUP_MARCH=0)", "bound": "hbm",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "bytes_per_sample": MARCH_BYTES_PER_SAMPLE + COMPOSITE_BYTES_PER_SAMPLE, "launches_per_frame": summ["launches"] / frames,
+            "avg_launch_ms": summ["avg_ms"], "ms_per_frame": per_frame_ms, "frames": frames,
+            "note": "one frame at a time (nothing else in flight), HIP events around the marcher launch of every iteration; the steady-mode "
+                    "entry march (one more launch per frame) is not bracketed; latency-bound kernels: read ms_per_frame, not frac"}
+
+
+def grid_gather_rate(sc, dev, n_points=196352, launches=20):
+    """Stand-alone `grid_encode` forward (k_grid_fwd, gridencoder.cu:87-245) on the fp16 table, clean run (no profiler): n_points
+    uniformly random points inside the figure's bounding box per launch, HIP events around every launch.  `achieved` is the ALGORITHMIC
+    gather rate (588 B per point: 512 B of table gathers + 12 in + 64 out -- SURVEY 8(d)) over the average launch time; the HBM-side
+    traffic under rocprofv3 --pmc is 0.29-0.50 of it (profiles/r02_grid_pmc_summary.json: the table is served by L2 / Infinity Cache)."""
+    import sdn_backend
+    g = torch.Generator(device="cpu").manual_seed(5)
+    lo, hi = torch.tensor([-0.35, -0.6, -0.2]), torch.tensor([0.35, 0.6, 0.2])
+    x = (lo + (hi - lo) * torch.rand(n_points, 3, generator=g)).to(dev)
+    enc = sc.model.encoder
+    t = sdn_backend.KernelTimers()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        enc(x, bound=sc.model.bound)
+        torch.cuda.synchronize()
+        sdn_backend.timers = t
+        for _ in range(launches):
+            enc(x, bound=sc.model.bound)
+        sdn_backend.timers = None
+    torch.cuda.synchronize()
+    summ = t.summary()
+    name = next((k for k in summ if k.startswith("grid_encode_fwd")), None)
+    if name is None:
+        return None
+    ms = summ[name]["avg_ms"]
+    achieved = GRID_BYTES_PER_POINT["f16"] * n_points / (ms * 1e-3) / 1e9
+    out = {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "bytes_per_point_algorithmic": GRID_BYTES_PER_POINT["f16"], "points_per_launch": n_points, "avg_launch_ms": ms, "launches": launches,
+           "note": "algorithmic gather rate of the stand-alone op, clean run; counter bytes are static (separate rocprofv3 --pmc passes)"}
+    pmc = os.path.join(ROOT, "profiles", "r02_grid_pmc_summary.json")
+    if os.path.exists(pmc):
+        try:
+            k = json.load(open(pmc))["kernels"]["k_grid_fwd"]["hbm"]
+            out["traffic_static"] = {"hbm_bytes_per_point_raw": k.get("hbm_bytes_per_point_raw"), "hbm_bytes_per_point_fetch_x2": k.get("hbm_bytes_per_point_fetch_x2"),
+                                     "source": "profiles/r02_grid_pmc_summary.json"}
+        except Exception:
+            pass
+    return out
 
 
 def exclusive_frames(k):
@@ -716,21 +869,27 @@ def roofline(timers, fp16, points_exclusive, points_overlapped=0):
 
 
 def cpu_baseline(sc, side):
-    """The reference's pure-PyTorch renderer (`NeRFRenderer.run`, 128 uniform samples per ray, no occupancy grid) on the
-    host cores, on a bounded sample of the same workload: a side x side image of the same camera / scene / weights."""
+    """The reference's pure-PyTorch renderer (`NeRFRenderer.run`, dnerf/renderer.py:129-258: 128 uniform samples per ray, no occupancy
+    grid, max_ray_batch 4096) on the host cores, as SURVEY 8(d) lays it out: 1 warm-up + 3 timed frames at 64 x 64 (BASELINE config 1)
+    and the 800 x 800 camera -- of which a bounded side x side sample is timed by default (the whole frame is 640 000 rays x 128 samples,
+    ~160 s on 64 cores; `--cpu-baseline-side 800` runs it whole), keeping the default bench within a few minutes."""
     from dnerf_amd import scene
     from oracle import render as orender
     cores = os.cpu_count() or 1
     cores = min(cores, 64)
     os.environ["OMP_NUM_THREADS"] = str(cores)
     torch.set_num_threads(cores)
-    ro, rd = scene.get_rays(sc.pose, scene.intrinsics(side, side), side, side)
     state = orender.state_of(sc.model)
-    orender.render_run_cpu(state, ro[:1024], rd[:1024], 0.5, threads=cores)  # warm-up (page-in, thread pools)
-    t0 = time.perf_counter()
-    orender.render_run_cpu(state, ro, rd, 0.5, threads=cores)
-    dt = time.perf_counter() - t0
-    n = ro.shape[0]
+
+    def frame(s):
+        ro, rd = scene.get_rays(sc.pose, scene.intrinsics(s, s), s, s)
+        t0 = time.perf_counter()
+        orender.render_run_cpu(state, ro, rd, 0.5, threads=cores)
+        return ro.shape[0], time.perf_counter() - t0
+    frame(64)                                                  # warm-up (page-in, thread pools)
+    small = [frame(64) for _ in range(3)]
+    n64, t64 = small[0][0], sorted(t for _, t in small)[1]     # median of the three timed 64 x 64 frames
+    n, dt = frame(side)
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -738,9 +897,11 @@ def cpu_baseline(sc, side):
     except OSError:
         pass
     return {"value": n * 128 / dt, "unit": "sampled-points/s", "rays_per_s": n / dt, "cores": cores, "cpu_model": model, "kind": "port",
-            "sample": f"{side}x{side} rays of the same camera and weights, 128 uniform samples/ray (the reference's non-cuda_ray "
-                      f"sampler, upsample_steps=0, max_ray_batch=4096), fp32, {dt:.1f} s; it samples empty space too, so rays/s is the "
-                      f"like-for-like figure"}
+            "sample": f"{side}x{side} rays of the 800x800 frame's camera and weights ({'the whole frame' if side >= 800 else 'bounded sample; the whole frame of 640 000 rays is projected at %.0f s' % (640000 / (n / dt))}), "
+                      f"128 uniform samples/ray (the reference's non-cuda_ray sampler, upsample_steps=0, max_ray_batch=4096), fp32, {dt:.1f} s; "
+                      f"it samples empty space too, so rays/s is the like-for-like figure",
+            "config1_64x64": {"rays_per_s": n64 / t64, "value": n64 * 128 / t64, "unit": "sampled-points/s", "frames": "1 warm-up + 3 timed (median)",
+                              "ms_per_frame": t64 * 1e3}}
 
 
 if __name__ == "__main__":

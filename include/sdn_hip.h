@@ -363,6 +363,10 @@ int sdn_render_step_f16(const SdnRenderCtx *ctx, uint32_t bound_alive, void *str
  * a caller can time the dominant kernel in place (bench.py's roofline). */
 int sdn_render_step_f16_ev(const SdnRenderCtx *ctx, uint32_t bound_alive, void *ev_field_begin, void *ev_field_end,
                            void *stream);
+/* Which launches the `ev_field` timing events of the frame drivers bracket: 0 (default) the fused-field launch of an iteration,
+ * 1 the marcher launch of the same iteration (k_march_rays* before steady mode, k_composite_march* in it) -- bench.py's
+ * `roofline_secondary`.  Process-wide; set it while no frame is in flight. */
+int sdn_render_time_kernel(int which);
 /* Whole frame in one call (begin, iterations until no ray is alive, finish).  This is the one entry point that waits on the
  * device: after enqueuing iteration k it blocks on the (side-stream, pinned-memory) read-back of iteration k-1's survivor
  * count, which bounds the grids of iteration k+1 and ends the loop.  ev_main[4] / ev_copy[4]: hipEvent_t created by the
@@ -384,7 +388,9 @@ int sdn_render_frame_f16(const SdnRenderCtx *ctx, float bg_color, float *image_o
  * recorded on frame i's stream behind its last kernel, and only THEN iterations_out[i] becomes non-zero (release store) -- a second
  * host thread can poll iterations_out and hand finished frames on (e.g. to the per-frame all-gather) while later frames still
  * render.  Returns SDN_E_TIMEOUT when no iteration of any
- * frame in flight completes within 20 s (all streams are synchronised before any error return). */
+ * frame in flight completes within 20 s.  Every OTHER error return synchronises all streams first; the time-out return does NOT
+ * (a kernel that never reports back is hung: waiting for it would hang the caller too) -- after SDN_E_TIMEOUT the device still owns
+ * every buffer of the contexts and of the frames in flight: do not reuse or free them, end the process. */
 int sdn_render_frames_pipelined_f16(const SdnRenderCtx *const *ctxs, uint32_t n_ctx, uint32_t n_frames, const float *const *rays_o,
                                     const float *const *rays_d, float *const *image_outs, float *const *depth_outs, float bg_color,
                                     uint32_t overlap_div, void *const *streams, void *const *side_streams, void **ev_main,

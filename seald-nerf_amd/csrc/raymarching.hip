@@ -13,6 +13,8 @@
 // and by wave divergence, not by HBM.  Rays keep image order in rays_alive
 // (stable compaction), so a wave's 64 rays are neighbouring pixels and take
 // similar trip counts.
+#include <stdlib.h>
+
 #include "sdn_common.h"
 #include "sdn_internal.h"
 
@@ -77,6 +79,10 @@ constexpr uint32_t kCullRes = 32;  // cull grid resolution (see "Exact early-out
 constexpr uint32_t kCullWords = kCullRes * kCullRes * kCullRes / 32;  // 1024 words of marks, followed by 8 words of meta:
 // meta = {x0, y0, z0, x1, y1, z1 (inclusive bounding box of the marked cells), -, -}
 constexpr uint32_t kFineCacheCells = 4096;  // LDS budget for the fine-bit cache: 32 KiB
+// meta[6] = 1: the cull-grid buffer also carries the PACKED fine-bit image of the marked bounding box (one 64-bit word per 4x4x4 block,
+// x fastest) behind the meta record -- built once per occupancy slice, so a marching workgroup fills its LDS cache with a contiguous
+// copy instead of a Morton gather with three integer divisions per word.
+constexpr uint32_t kCullImageWord = kCullWords + 8;   // uint32 offset of the image (16-byte aligned)
 __device__ __forceinline__ uint32_t m2(uint32_t v) { return (v & 1u) | ((v & 2u) << 2); }  // 2-bit Morton spread
 __device__ __forceinline__ bool cull_marked(const uint32_t *cull_bits, int cx, int cy, int cz) {
     const uint32_t c = ((uint32_t)cz * kCullRes + (uint32_t)cy) * kCullRes + (uint32_t)cx;
@@ -121,38 +127,53 @@ struct MarcherT {
 
     __device__ __forceinline__ float step_size(float t) const { return dt_is_const ? dt_const : clampf_(t * dt_gamma, dt_min, dt_max); }
 
-    // One loop-body evaluation at parameter t.  Occupied: returns true with the sample in
-    // (x,y,z,dt), t untouched.  Empty: returns false with t advanced past the voxel.
-    __device__ __forceinline__ bool probe(float &t, float &x, float &y, float &z, float &dt, const uint32_t *cull_bits = nullptr) const {
+    // ---- the pieces of one FAST loop-body evaluation (shared by the sequential chain below and the cooperative marcher) ----
+    // position and voxel of the parameter t (raymarching.cu:752-768 with the exact float forms of the FAST configuration)
+    __device__ __forceinline__ void locate(float t, float &x, float &y, float &z, int &nx, int &ny, int &nz) const {
         x = clampf_(ox + t * dx, -bound, bound);
         y = clampf_(oy + t * dy, -bound, bound);
         z = clampf_(oz + t * dz, -bound, bound);
-        dt = step_size(t);
-        if constexpr (FAST) {
-            const int nx = (int)clampf_((x + 1) * halfH, 0.0f, Hm1);
-            const int ny = (int)clampf_((y + 1) * halfH, 0.0f, Hm1);
-            const int nz = (int)clampf_((z + 1) * halfH, 0.0f, Hm1);
-            bool occ = false;
-            if (fine) {
-                // The LDS image holds the fine bits of every 4x4x4 block inside the bounding box of the marked cull cells, and
-                // every occupied voxel lies in a marked cell: one LDS read answers the probe inside the box (a block of an unmarked
-                // cell reads as zero), three register compares answer it outside.  bit = Morton code of the low two bits per axis.
-                const int bx = (nx >> 2) - fx0, by = (ny >> 2) - fy0, bz = (nz >> 2) - fz0;
-                if ((uint32_t)bx < (uint32_t)fnx && (uint32_t)by < (uint32_t)fny && (uint32_t)bz < (uint32_t)fnz) {
-                    const uint32_t b = m2((uint32_t)nx & 3u) | (m2((uint32_t)ny & 3u) << 1) | (m2((uint32_t)nz & 3u) << 2);
-                    // (24-bit multiplies: full-rate v_mad_u32_u24 instead of quarter-rate v_mul_lo_u32; all factors < 32)
-                    occ = (fine[__umul24(__umul24((uint32_t)bz, (uint32_t)fny) + (uint32_t)by, (uint32_t)fnx) + (uint32_t)bx] >> b) & 1ull;
-                }
-            } else if (!cull_bits || cull_marked(cull_bits, nx >> 2, ny >> 2, nz >> 2)) {
-                // an unmarked cull cell holds no occupied voxel: the fine bit (a dependent L2 load) is only fetched near the object
-                const uint32_t index = morton3D_8bit((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
-                occ = grid[index >> 3] & (1u << (index & 7u));
+        nx = (int)clampf_((x + 1) * halfH, 0.0f, Hm1);
+        ny = (int)clampf_((y + 1) * halfH, 0.0f, Hm1);
+        nz = (int)clampf_((z + 1) * halfH, 0.0f, Hm1);
+    }
+    // occupancy bit of a voxel (raymarching.cu:770-772)
+    __device__ __forceinline__ bool occupied(int nx, int ny, int nz, const uint32_t *cull_bits) const {
+        bool occ = false;
+        if (fine) {
+            // The LDS image holds the fine bits of every 4x4x4 block inside the bounding box of the marked cull cells, and
+            // every occupied voxel lies in a marked cell: one LDS read answers the probe inside the box (a block of an unmarked
+            // cell reads as zero), three register compares answer it outside.  bit = Morton code of the low two bits per axis.
+            const int bx = (nx >> 2) - fx0, by = (ny >> 2) - fy0, bz = (nz >> 2) - fz0;
+            if ((uint32_t)bx < (uint32_t)fnx && (uint32_t)by < (uint32_t)fny && (uint32_t)bz < (uint32_t)fnz) {
+                const uint32_t b = m2((uint32_t)nx & 3u) | (m2((uint32_t)ny & 3u) << 1) | (m2((uint32_t)nz & 3u) << 2);
+                // (24-bit multiplies: full-rate v_mad_u32_u24 instead of quarter-rate v_mul_lo_u32; all factors < 32)
+                occ = (fine[__umul24(__umul24((uint32_t)bz, (uint32_t)fny) + (uint32_t)by, (uint32_t)fnx) + (uint32_t)bx] >> b) & 1ull;
             }
-            if (occ) return true;
-            const float tx = ((((float)nx + ex) * twoRH - 1) - x) * rdx;
-            const float ty = ((((float)ny + ey) * twoRH - 1) - y) * rdy;
-            const float tz = ((((float)nz + ez) * twoRH - 1) - z) * rdz;
-            const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        } else if (!cull_bits || cull_marked(cull_bits, nx >> 2, ny >> 2, nz >> 2)) {
+            // an unmarked cull cell holds no occupied voxel: the fine bit (a dependent L2 load) is only fetched near the object
+            const uint32_t index = morton3D_8bit((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+            occ = grid[index >> 3] & (1u << (index & 7u));
+        }
+        return occ;
+    }
+    // parameter at which the ray leaves the voxel, evaluated at t (raymarching.cu:786-791)
+    __device__ __forceinline__ float exit_t(float t, float x, float y, float z, int nx, int ny, int nz) const {
+        const float tx = ((((float)nx + ex) * twoRH - 1) - x) * rdx;
+        const float ty = ((((float)ny + ey) * twoRH - 1) - y) * rdy;
+        const float tz = ((((float)nz + ez) * twoRH - 1) - z) * rdz;
+        return t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    }
+
+    // One loop-body evaluation at parameter t.  Occupied: returns true with the sample in
+    // (x,y,z,dt), t untouched.  Empty: returns false with t advanced past the voxel.
+    __device__ __forceinline__ bool probe(float &t, float &x, float &y, float &z, float &dt, const uint32_t *cull_bits = nullptr) const {
+        if constexpr (FAST) {
+            int nx, ny, nz;
+            locate(t, x, y, z, nx, ny, nz);
+            dt = step_size(t);
+            if (occupied(nx, ny, nz, cull_bits)) return true;
+            const float tt = exit_t(t, x, y, z, nx, ny, nz);
             if (dt_is_const) {
                 // `do t += dt while (t < tt)` with the same additions in the same order, without a divergent loop: one 128^3 voxel is
                 // crossed in at most 8 steps of dt_min = 2 sqrt(3) / 1024; anything longer falls through to the loop
@@ -168,6 +189,10 @@ struct MarcherT {
             }
             return false;
         } else {
+            x = clampf_(ox + t * dx, -bound, bound);
+            y = clampf_(oy + t * dy, -bound, bound);
+            z = clampf_(oz + t * dz, -bound, bound);
+            dt = step_size(t);
             const int l0 = mip_from_pos(x, y, z, Cf), l1 = mip_from_dt(dt, Hf, Cf);
             const int level = l0 > l1 ? l0 : l1;
             const float mip_bound = fminf(scalbnf(1.0f, level), bound);
@@ -246,11 +271,33 @@ __global__ void k_cull_meta_init(uint32_t *__restrict__ cull_bits, uint32_t n_fr
     }
 }
 
+__global__ void __launch_bounds__(256) k_build_fine_image(const uint8_t *__restrict__ bitfield, uint32_t *__restrict__ cull_bits, sdn_int::FrameSel fs) {
+    if (fs.n_frames > 1) {   // frame group: blockIdx.y = frame
+        bitfield = frame_grid_uniform_y(fs);
+        cull_bits += (size_t)blockIdx.y * fs.cull_stride;
+    }
+    int *meta = reinterpret_cast<int *>(cull_bits + kCullWords);
+    const int fx0 = meta[0], fy0 = meta[1], fz0 = meta[2];
+    const int fnx = meta[3] - fx0 + 1, fny = meta[4] - fy0 + 1, fnz = meta[5] - fz0 + 1;
+    const bool fits = fnx > 0 && fny > 0 && fnz > 0 && (uint32_t)(fnx * fny * fnz) <= kFineCacheCells;
+    const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+    if (i == 0) meta[6] = fits ? 1 : 0;
+    if (!fits || i >= (uint32_t)(fnx * fny * fnz)) return;
+    const unsigned long long *__restrict__ blocks = reinterpret_cast<const unsigned long long *>(bitfield);
+    unsigned long long *img = reinterpret_cast<unsigned long long *>(cull_bits + kCullImageWord);
+    const int cx = fx0 + (int)i % fnx, cy = fy0 + ((int)i / fnx) % fny, cz = fz0 + (int)i / (fnx * fny);
+    img[i] = blocks[morton3D_8bit((uint32_t)cx, (uint32_t)cy, (uint32_t)cz)];
+}
+
 // Scans the remaining segment [t, far] once per cull-cell width.  Returns false if no marked cell is met (the ray
 // cannot produce a sample).  Otherwise t_end receives a parameter beyond which no marked cell is met any more: the
 // marcher may stop there -- the reference would only step through empty voxels from there to `far`.
+// t_safe (optional): a parameter up to which the ray certainly stays >= 2 fine voxels away from every occupied voxel -- the scan
+// position one cell width before the first marked one (-FLT_MAX when unknown): where the cooperative marcher may start looking.
 __device__ __forceinline__ bool ray_may_hit(const uint32_t *cull_bits, float ox, float oy, float oz, float dx, float dy, float dz,
-                                            float t, float far, float &t_end, int bx0, int by0, int bz0, int bnx, int bny, int bnz) {
+                                            float t, float far, float &t_end, int bx0, int by0, int bz0, int bnx, int bny, int bnz,
+                                            float *t_safe = nullptr) {
+    if (t_safe) *t_safe = -__FLT_MAX__;
     const float len = sqrtf(dx * dx + dy * dy + dz * dz);
     const float ds = (2.0f / kCullRes) / fmaxf(len, 1e-12f);  // parameter step = one cull cell along the ray
     t_end = far;
@@ -286,10 +333,14 @@ __device__ __forceinline__ bool ray_may_hit(const uint32_t *cull_bits, float ox,
         const int cx = (int)fminf((x + 1) * (0.5f * kCullRes), (float)(kCullRes - 1));
         const int cy = (int)fminf((y + 1) * (0.5f * kCullRes), (float)(kCullRes - 1));
         const int cz = (int)fminf((z + 1) * (0.5f * kCullRes), (float)(kCullRes - 1));
-        if (cull_marked(cull_bits, cx, cy, cz)) { hit = true; t_end = ss + ds; }
+        if (cull_marked(cull_bits, cx, cy, cz)) {
+            if (!hit && t_safe) *t_safe = ss - ds;
+            hit = true; t_end = ss + ds;
+        }
         if (s >= s1) return hit;
     }
     t_end = far;
+    if (t_safe) *t_safe = -__FLT_MAX__;
     return true;
 }
 
@@ -312,7 +363,12 @@ __device__ __forceinline__ void occ_cache_load(const uint32_t *__restrict__ cull
             oc.fnx = meta[3] - oc.fx0 + 1; oc.fny = meta[4] - oc.fy0 + 1;
             const int fnz = meta[5] - oc.fz0 + 1;
             oc.fnz = fnz;
-            if (oc.fnx > 0 && oc.fny > 0 && fnz > 0 && (uint32_t)(oc.fnx * oc.fny * fnz) <= kFineCacheCells) {
+            if (oc.fnx > 0 && oc.fny > 0 && fnz > 0 && (uint32_t)(oc.fnx * oc.fny * fnz) <= kFineCacheCells && meta[6] == 1) {
+                const int pairs = (oc.fnx * oc.fny * fnz + 1) / 2;        // contiguous copy, 16 bytes per lane
+                const uint4 *__restrict__ img = reinterpret_cast<const uint4 *>(cull + kCullImageWord);
+                for (int i = (int)threadIdx.x; i < pairs; i += 256) reinterpret_cast<uint4 *>(s_fine)[i] = img[i];
+                oc.fine = s_fine;
+            } else if (oc.fnx > 0 && oc.fny > 0 && fnz > 0 && (uint32_t)(oc.fnx * oc.fny * fnz) <= kFineCacheCells) {
                 const unsigned long long *__restrict__ blocks = reinterpret_cast<const unsigned long long *>(grid);
                 const int cells = oc.fnx * oc.fny * fnz;
                 for (int i = (int)threadIdx.x; i < cells; i += 256) {
@@ -325,6 +381,38 @@ __device__ __forceinline__ void occ_cache_load(const uint32_t *__restrict__ cull
             oc.s_cull = reinterpret_cast<const uint32_t *>(s_cull4);
         }
     }
+}
+
+// The same in two steps for the cooperative marcher: the 4 KiB of marks (needed by the cull scan of phase A) first, the <= 32 KiB of
+// fine bits only by workgroups that have a ray to march.  Both contain a barrier.
+__device__ __forceinline__ void occ_cache_load_marks(const uint32_t *__restrict__ cull, uint4 *s_cull4, OccCache &oc) {
+    if (cull) {  // kernel-uniform
+        s_cull4[threadIdx.x] = reinterpret_cast<const uint4 *>(cull)[threadIdx.x];
+        const int *meta = reinterpret_cast<const int *>(cull + kCullWords);
+        oc.fx0 = meta[0]; oc.fy0 = meta[1]; oc.fz0 = meta[2];
+        oc.fnx = meta[3] - oc.fx0 + 1; oc.fny = meta[4] - oc.fy0 + 1; oc.fnz = meta[5] - oc.fz0 + 1;
+        oc.s_cull = reinterpret_cast<const uint32_t *>(s_cull4);
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void occ_cache_load_fine(const uint32_t *__restrict__ cull, const uint8_t *__restrict__ grid, unsigned long long *s_fine,
+                                                    OccCache &oc) {
+    if (cull && oc.fnx > 0 && oc.fny > 0 && oc.fnz > 0 && (uint32_t)(oc.fnx * oc.fny * oc.fnz) <= kFineCacheCells &&
+        reinterpret_cast<const int *>(cull + kCullWords)[6] == 1) {
+        const int pairs = (oc.fnx * oc.fny * oc.fnz + 1) / 2;
+        const uint4 *__restrict__ img = reinterpret_cast<const uint4 *>(cull + kCullImageWord);
+        for (int i = (int)threadIdx.x; i < pairs; i += 256) reinterpret_cast<uint4 *>(s_fine)[i] = img[i];
+        oc.fine = s_fine;
+    } else if (cull && oc.fnx > 0 && oc.fny > 0 && oc.fnz > 0 && (uint32_t)(oc.fnx * oc.fny * oc.fnz) <= kFineCacheCells) {
+        const unsigned long long *__restrict__ blocks = reinterpret_cast<const unsigned long long *>(grid);
+        const int cells = oc.fnx * oc.fny * oc.fnz;
+        for (int i = (int)threadIdx.x; i < cells; i += 256) {
+            const int cx = oc.fx0 + i % oc.fnx, cy = oc.fy0 + (i / oc.fnx) % oc.fny, cz = oc.fz0 + i / (oc.fnx * oc.fny);
+            s_fine[i] = blocks[morton3D_8bit((uint32_t)cx, (uint32_t)cy, (uint32_t)cz)];
+        }
+        oc.fine = s_fine;
+    }
+    __syncthreads();
 }
 
 
@@ -978,6 +1066,346 @@ __device__ __forceinline__ uint32_t march_ray(MarcherT<FAST> &m, const OccCache 
     return step;
 }
 
+// march_ray with a probe budget (FAST configuration with LDS caches; the caller has resolved the cull bound t_end): at most
+// max_probes loop-body evaluations.  Returns the samples written; `more` = the budget ran out before the ray was finished -- t then is
+// the lattice point the chain stands at, last_t the parameter behind its last sample, and the unused slots are NOT zero-filled (the
+// cooperative marcher continues the ray).  A finished ray is exactly march_ray's result.
+__device__ __forceinline__ uint32_t march_ray_some(MarcherT<true> &m, const OccCache &oc, float &t, float far, float t_end, uint32_t n_step,
+                                                   float *px, float *pd, float *pl, uint8_t *psf, uint32_t frame, uint32_t max_probes, float &last_t,
+                                                   bool &more) {
+    m.fine = oc.fine; m.fx0 = oc.fx0; m.fy0 = oc.fy0; m.fz0 = oc.fz0; m.fnx = oc.fnx; m.fny = oc.fny; m.fnz = oc.fnz;
+    uint32_t step = 0, probes = 0;
+    float x, y, z, dt;
+    last_t = t;
+    more = false;
+    while (t < far && t < t_end && step < n_step) {
+        if (probes == max_probes) { more = true; break; }
+        probes++;
+        if (m.probe(t, x, y, z, dt, oc.s_cull)) {
+            px[0] = x; px[1] = y; px[2] = z;
+            pd[0] = m.dx; pd[1] = m.dy; pd[2] = m.dz;
+            t += dt;
+            pl[0] = dt;
+            pl[1] = t - last_t;
+            last_t = t;
+            px += 3; pd += 3; pl += 2;
+            if (psf) psf[step] = (uint8_t)frame;
+            step++;
+        }
+    }
+    if (!more) {
+        for (uint32_t k = step; k < n_step; k++) {
+            px[0] = 0; px[1] = 0; px[2] = 0;
+            pd[0] = 0; pd[1] = 0; pd[2] = 0;
+            pl[0] = 0; pl[1] = 0;
+            px += 3; pd += 3; pl += 2;
+        }
+    }
+    return step;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Cooperative marcher: kGL lanes per ray (FAST configuration, constant step, LDS occupancy caches).
+//
+// One lane per ray walks a dependent chain of ~1000 cycles per voxel probe, and a launch lasts as long as its longest chain
+// (profiles/r03_marcher_pmc_summary.json: waves live 20 K cycles on average in a launch of 60 K, 61 % of their cycles waiting, 46 %
+// of the VALU lanes active).  Here a ray is marched by a GROUP of kGL = 16 consecutive lanes: with a constant step every parameter
+// the marcher visits is a point of one lattice L_0 = t, L_{k+1} = fl(L_k + dt) (see k_march_train_count_wave), so the group takes
+// a window of 16 consecutive lattice points -- one per lane, by the closed form L_k = base + k c while the window stays inside one
+// binade, by the recurrence otherwise --, evaluates position, voxel, occupancy bit and the voxel's exit parameter in parallel with
+// the sequential marcher's own expressions (MarcherT<true>::locate / occupied / exit_t), derives every empty lane's successor
+// (first later lattice point >= its exit parameter) and walks the chain  next(k) = occupied ? k + 1 : successor(k)  over the
+// window with group-local shuffles.  Visited set, samples, step lengths and counts are the sequential chain's bit for bit; only
+// the schedule changes: 16 lattice points (3-4 voxels) per round instead of one voxel per probe, 16x the waves to hide latency
+// behind, no lane idling while its neighbour crosses empty space.
+//
+// Fresh rays (first march of a frame) do not walk the chain from the cube's entry point to the figure (~100 empty voxels): the
+// group jumps along the lattice (closed form, binade by binade) to a window shortly before the parameter t_safe up to which the
+// cull scan saw only unmarked cells (every point there is >= 2 fine voxels from any occupied voxel: nothing can be sampled), and
+// RE-SYNCHRONISES with the chain exactly: from a visited point v of an empty run (= the lattice points of one voxel) the chain
+// goes to the first lattice point >= exit(v), i.e. the start a of the next run -- unless a lattice point lies within rounding of
+// the voxel boundary.  If EVERY lattice point i of a complete run R satisfies exit(L_i) <= L_a, the chain -- which enters R or
+// lands on a directly from the run before, an overshoot being at most one lattice point -- is at a whichever points it visited
+// before.  The group verifies that for the first complete run of its window (all of the run's lanes, not just the visited
+// one) and starts the walk at a; if the check fails (a lattice point within ~1e-7 of a voxel face: ~3e-5 per run) it tries the
+// next run, and gives up to the walk from the ray's own start after that.  Nothing is approximated.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kGL = 16;
+
+#ifdef SDN_STAMPS
+// Diagnostic build only (make diag; the product library has no stamp): shader-clock sums per phase of the cooperative kernels,
+// accumulated by thread 0 of every workgroup.  [0..7] k_composite_march_g, [8..15] k_march_rays_g:
+//   +0 workgroups with work  +1 phase A (entry -> task list complete)  +2 fine-bit cache  +3 phase B (all passes)  +4 live-list append
+//   +5 tasks  +6 windows (rounds of group_march)  +7 slow-form windows
+__device__ unsigned long long g_stamps[32];
+#define SDN_STAMP_NOW() __builtin_amdgcn_s_memtime()
+#define SDN_STAMP_ADD(i, v) atomicAdd(&g_stamps[i], (unsigned long long)(v))
+#else
+#define SDN_STAMP_NOW() 0ull
+#define SDN_STAMP_ADD(i, v) ((void)(v))
+#endif
+
+// L_g of the lattice starting at `base` for the kGL lanes of a group, and L_kGL (the next window's base).  cstep > 0: closed form.
+__device__ __forceinline__ float group_lattice(float base, float dt, uint32_t g, float &next_base, float &cstep) {
+    {
+        const float first = base + dt;
+        const float c = first - base;                               // exact: both multiples of the binade's ulp U
+        const float err = dt - c;                                   // rounding error of base + dt (exact for base >= dt)
+        const float last = base + (float)kGL * c;
+        const uint32_t eb = __float_as_uint(base) >> 23, el = __float_as_uint(last) >> 23;     // sign bit clear: t > 0
+        const bool normal = base >= dt && dt > 0.0f && eb > 30u && eb < 255u;
+        const float half_ulp = __uint_as_float((eb - 24u) << 23), c_cap = __uint_as_float((eb - 5u) << 23);   // U / 2, 2^18 U
+        if (normal && eb == el && fabsf(err) != half_ulp && c < c_cap) {
+            next_base = last;
+            cstep = c;                                              // L_k = base + k c holds for k = 0 .. kGL
+            return base + (float)g * c;
+        }
+    }
+    cstep = 0.0f;
+    float v = base, mine = base;
+    for (uint32_t i = 0; i < kGL; i++) {
+        if (i == g) mine = v;
+        v += dt;
+    }
+    next_base = v;
+    return mine;
+}
+
+// The largest lattice point <= target of the lattice t, fl(t + dt), ... (t itself if none): closed form inside a binade, one
+// recurrence step across a binade boundary.  Gives up (returns the point reached) where the closed form does not hold.
+__device__ __forceinline__ float lattice_floor(float t, float dt, float target) {
+    for (int hop = 0; hop < 4; hop++) {
+        const float first = t + dt;
+        if (!(first <= target)) break;
+        const float c = first - t;
+        const float err = dt - c;
+        const uint32_t eb = __float_as_uint(t) >> 23;
+        const bool normal = t >= dt && dt > 0.0f && eb > 30u && eb < 254u;
+        const float half_ulp = __uint_as_float((eb - 24u) << 23), c_cap = __uint_as_float((eb - 5u) << 23);
+        if (!(normal && fabsf(err) != half_ulp && c < c_cap)) break;
+        const float top = __uint_as_float(((eb + 1u) << 23) - 1u);       // the largest float of t's binade
+        const float lim = fminf(target, top);
+        float k = floorf((lim - t) / c);
+        while (t + (k + 1.0f) * c <= lim) k += 1.0f;                       // (products and sums exact: multiples of U below 2^24 U)
+        while (k > 0.0f && t + k * c > lim) k -= 1.0f;
+        t = t + k * c;
+        if (lim == target) break;
+        if (!(t + dt <= target)) break;
+        t = t + dt;                                                       // the one step that crosses into the next binade
+    }
+    return t;
+}
+
+// lane g - 1's value within the group (a group is one DPP row of 16 lanes): row_shr:1; lane 0 of the group gets 0
+__device__ __forceinline__ uint32_t group_prev_lane(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+}
+
+// Re-synchronisation with the sequential chain inside a window of kGL EMPTY lattice points starting at `cand` (all of them before
+// the ray's end): looks for a complete run (the lattice points of one voxel) all of whose points i satisfy exit(L_i) <= L_a, a the
+// start of the next run; the chain is then certainly at a, whatever it visited before (see the header comment).  Returns false if
+// the window is not a closed-form window or no run qualifies.
+__device__ __forceinline__ bool group_resync(const MarcherT<true> &m, const uint32_t *s_cull, float cand, uint32_t g, uint32_t gbase, float &found_t) {
+    float nb, cstep;
+    const float t = group_lattice(cand, m.dt_const, g, nb, cstep);
+    if (!(cstep > 0.0f)) return false;                                                     // group-uniform
+    float x, y, z;
+    int nx, ny, nz;
+    m.locate(t, x, y, z, nx, ny, nz);
+    const bool occ = m.occupied(nx, ny, nz, s_cull);
+    if ((uint32_t)(__ballot(occ) >> gbase) & 0xFFFFu) return false;                        // the caller saw none; be safe
+    const float tt = m.exit_t(t, x, y, z, nx, ny, nz);
+    const uint32_t vox = (uint32_t)nx | ((uint32_t)ny << 8) | ((uint32_t)nz << 16);
+    const uint32_t vprev = group_prev_lane(vox);
+    const uint32_t chg = (uint32_t)(__ballot(g > 0u && vox != vprev) >> gbase) & 0xFFFFu;  // bit k: lane k starts a run
+    const uint32_t above = chg & ~((2u << g) - 1u);                                        // run starts after my lane
+    const bool has_next = above != 0u;
+    const uint32_t a = has_next ? (uint32_t)__builtin_ctz(above) : kGL;
+    const bool bad = !has_next || !(tt <= cand + (float)a * cstep);
+    const uint32_t badm = (uint32_t)(__ballot(bad) >> gbase) & 0xFFFFu;
+    uint32_t rest = chg;                    // complete runs: [c_j, c_{j+1}) for consecutive set bits; the first whose lanes all pass
+    while (rest) {
+        const uint32_t cj = (uint32_t)__builtin_ctz(rest);
+        rest &= rest - 1u;
+        if (!rest) break;
+        const uint32_t cn = (uint32_t)__builtin_ctz(rest);
+        const uint32_t runm = ((1u << cn) - 1u) & ~((1u << cj) - 1u);
+        if (!(badm & runm)) { found_t = cand + (float)cn * cstep; return true; }
+    }
+    return false;
+}
+
+// Marches one ray by the kGL lanes [gbase, gbase + kGL) of the wave; every lane of the group calls it with the same arguments
+// (g = its index in the group).  Same contract as march_ray: writes up to n_step samples, zero-fills the unused slots, returns
+// the number written.  t_safe: see ray_may_hit (-FLT_MAX: no jump).  The ray may have been started by march_ray_some: t0 is then
+// the point its chain stopped at (a visited lattice point), step0 / last_t0 its sample count and the parameter behind its last sample.
+//
+// The state between rounds is ONE number: `exact_base`, a lattice point the sequential chain certainly visits.  Rounds:
+// * SCAN: only the occupancy bits of a window are evaluated; while none is set the chain cannot sample, so the window is passed
+//   without knowing which of its points the chain visits.  When a scan meets an occupied lattice point the group re-synchronises in
+//   the (empty) window before it (group_resync) and goes on exactly from there; if that fails, exactly from the last known point.
+// * EXACT, fast form (a closed-form window that starts at a visited point): the chain visits the start of every run and every
+//   occupied point PROVIDED no empty point i of a complete run has exit(L_i) > L_a, a the start of the next run -- checked for all
+//   of the run's lanes at once (one DPP move for the neighbour's voxel, bit operations for a, one compare).  Then the samples are
+//   simply the occupied lattice points (up to the budget), and the next window starts at the first point after the window if its
+//   last point is occupied, else at the start of its last (empty) run, which the chain visits.  No successor indices, no walk.
+// * EXACT, slow form (a check failed: a lattice point within rounding of a voxel face, ~3e-5 per run; or a window across a binade
+//   boundary): successor indices and the walk over the window, then the chain's next point by the marcher's own `t += dt` loop.
+__device__ __forceinline__ uint32_t group_march(const MarcherT<true> &m, const uint32_t *s_cull, float t0, float far, float t_end, uint32_t n_step,
+                                                float *px, float *pd, float *pl, uint8_t *psf, uint32_t frame, uint32_t g, uint32_t gbase,
+                                                float t_safe, uint32_t step0, float last_t0, uint32_t *win_ctr = nullptr) {
+    const float dt = m.dt_const;
+    const uint32_t sh = gbase;
+    uint32_t step = step0;                                   // samples the lane-per-ray phase already wrote (0: a fresh start)
+    float last_t = last_t0;                                  // parameter behind the previous sample (the iteration's start: t0)
+    float exact_base = t0;                                   // a lattice point the chain visits
+    float scan_base = t0, prev_base = 0.0f, force_until = -__FLT_MAX__;
+    bool scanning = true, prev_valid = false;
+    const bool go = t0 < far && t0 < t_end;
+    if (go && t_safe > t0 + 48.0f * dt)                      // fresh ray: jump along the lattice towards the first marked cull cell
+        scan_base = lattice_floor(t0, dt, fminf(t_safe, fminf(far, t_end)) - 18.0f * dt);
+    while (go) {
+        const float wbase = scanning ? scan_base : exact_base;
+        float nb, cstep;
+        const float t = group_lattice(wbase, dt, g, nb, cstep);
+        const bool act = t < far && t < t_end;                  // the loop condition of the sequential marcher at this lattice point
+        float x, y, z;
+        int nx, ny, nz;
+        m.locate(t, x, y, z, nx, ny, nz);
+        const bool occ = act && m.occupied(nx, ny, nz, s_cull);
+        const uint32_t am = (uint32_t)(__ballot(act) >> sh) & 0xFFFFu, om = (uint32_t)(__ballot(occ) >> sh) & 0xFFFFu;
+#ifdef SDN_STAMPS
+        if (g == 0u && win_ctr) atomicAdd(win_ctr, 1u);
+#endif
+        if (scanning) {
+            if (om == 0u) {
+                if (am != 0xFFFFu) break;                        // the ray ends inside this window without another sample
+                prev_base = wbase; prev_valid = cstep > 0.0f;
+                scan_base = nb;
+                continue;
+            }
+            scanning = false;
+            if (wbase != exact_base) {                           // an occupied lattice point ahead and the chain's points are not known here
+                float found;
+                if (prev_valid && group_resync(m, s_cull, prev_base, g, gbase, found)) exact_base = found;
+                else force_until = wbase;                        // walk exactly from the last known point up to this window
+                continue;
+            }
+        }
+        const float tt = m.exit_t(t, x, y, z, nx, ny, nz);
+        const bool empty = act && !occ;
+        const uint32_t budget = n_step - step;
+        uint32_t emit = 0;
+        bool done = false;
+        float next_base = nb;
+        // ---- fast form ---------------------------------------------------------------------------------------------------------
+        bool fast = cstep > 0.0f;
+        uint32_t chg = 0;
+        if (fast) {
+            const uint32_t vox = (uint32_t)nx | ((uint32_t)ny << 8) | ((uint32_t)nz << 16);
+            const uint32_t vprev = group_prev_lane(vox);
+            chg = (uint32_t)(__ballot(g > 0u && vox != vprev) >> sh) & 0xFFFFu;           // bit k: lane k starts a run
+            const uint32_t above = chg & ~((2u << g) - 1u);
+            const uint32_t a = above ? (uint32_t)__builtin_ctz(above) : kGL;
+            const bool bad = empty && above && !(tt <= wbase + (float)a * cstep);
+            if ((uint32_t)(__ballot(bad) >> sh) & 0xFFFFu) fast = false;
+            // a window that ends inside an empty run continues at that run's start: it must not be the window's own start
+            if (fast && am == 0xFFFFu && !((om >> (kGL - 1u)) & 1u) && chg == 0u) fast = false;
+        }
+        if (fast) {
+            emit = om;
+            const uint32_t cnt = (uint32_t)__builtin_popcount(om);
+            if (cnt >= budget) {
+                for (uint32_t k = cnt; k > budget; k--) emit &= ~(1u << (31u - (uint32_t)__builtin_clz(emit)));   // the first `budget` of them
+                done = true;
+            } else if (am != 0xFFFFu) {
+                done = true;                                     // the chain runs into the ray's end inside this window
+            } else if (!((om >> (kGL - 1u)) & 1u)) {
+                next_base = wbase + (float)(31u - (uint32_t)__builtin_clz(chg)) * cstep;   // start of the trailing empty run
+            }
+        } else {
+            // ---- slow form: successor indices + walk (k_march_train_count_wave's scheme on kGL lanes) --------------------------------
+#ifdef SDN_STAMPS
+            if (g == 0u && win_ctr) atomicAdd(win_ctr + 1, 1u);
+#endif
+            uint32_t nxt = g + 1u;
+            if (cstep > 0.0f) {
+                if (empty) {
+                    const float q = (tt - wbase) / cstep;
+                    int j = q < (float)kGL ? (int)ceilf(q) : (int)kGL;
+                    if (j < (int)g + 1) j = (int)g + 1;
+                    while (j > (int)g + 1 && wbase + (float)(j - 1) * cstep >= tt) j--;
+                    while (j < (int)kGL && wbase + (float)j * cstep < tt) j++;
+                    nxt = (uint32_t)j;
+                }
+            } else {
+                for (uint32_t k = 0; k < kGL; k++) {
+                    const float lv = __shfl(t, (int)(gbase + (nxt & (kGL - 1u))), 64);
+                    if (empty && nxt < kGL && lv < tt) nxt++;
+                }
+            }
+            uint32_t cur = 0, left = budget;
+            float pending = -__FLT_MAX__;                        // exit parameter of an empty voxel whose successor lies beyond the window
+            while (!done && cur < kGL) {
+                if (!((am >> cur) & 1u)) { done = true; break; }                  // t >= far or t >= t_end: the ray is finished
+                const uint32_t o = om >> cur;
+                if (o & 1u) {
+                    // a run of occupied lattice points: every one is visited and sampled
+                    uint32_t run = (uint32_t)__builtin_ctz(~o);
+                    if (run >= left) { run = left; done = true; }
+                    emit |= ((1u << run) - 1u) << cur;
+                    left -= run;
+                    cur += run;
+                } else {
+                    const uint32_t to = (uint32_t)__shfl((int)nxt, (int)(gbase + cur), 64);
+                    if (to >= kGL) pending = __shfl(tt, (int)(gbase + cur), 64);
+                    cur = to;
+                }
+            }
+            if (!done && pending != -__FLT_MAX__) {
+                while (next_base < pending) next_base += dt;     // `do t += dt while (t < tt)`, continued beyond the window
+            }
+        }
+        if (emit) {
+            const bool mine = (emit >> g) & 1u;
+            const uint32_t below = emit & ((1u << g) - 1u);
+            const float t_after = t + dt;                                      // `t += dt` of the sequential marcher
+            const uint32_t prev = below ? 31u - (uint32_t)__builtin_clz(below) : 0u, top = 31u - (uint32_t)__builtin_clz(emit);
+            float prev_after, top_after;
+            if (cstep > 0.0f) {                                                // the other lanes' values by the closed form: no shuffle
+                prev_after = (wbase + (float)prev * cstep) + dt;
+                top_after = (wbase + (float)top * cstep) + dt;
+            } else {
+                prev_after = __shfl(t_after, (int)(gbase + prev), 64);
+                top_after = __shfl(t_after, (int)(gbase + top), 64);
+            }
+            if (mine) {
+                const uint32_t slot = step + (uint32_t)__builtin_popcount(below);
+                px[slot * 3] = x; px[slot * 3 + 1] = y; px[slot * 3 + 2] = z;
+                pd[slot * 3] = m.dx; pd[slot * 3 + 1] = m.dy; pd[slot * 3 + 2] = m.dz;
+                pl[slot * 2] = dt;
+                pl[slot * 2 + 1] = t_after - (below ? prev_after : last_t);
+                if (psf) psf[slot] = (uint8_t)frame;
+            }
+            last_t = top_after;
+            step += (uint32_t)__builtin_popcount(emit);
+        }
+        if (done) break;
+        exact_base = next_base;
+        if (om == 0u && !(wbase < force_until)) {       // nothing to sample here: pass the following windows by their occupancy bits
+            scanning = true;
+            scan_base = next_base;
+            prev_valid = false;
+        }
+    }
+    for (uint32_t k = step + g; k < n_step; k += kGL) {
+        px[k * 3] = 0; px[k * 3 + 1] = 0; px[k * 3 + 2] = 0;
+        pd[k * 3] = 0; pd[k * 3 + 1] = 0; pd[k * 3 + 2] = 0;
+        pl[k * 2] = 0; pl[k * 2 + 1] = 0;
+    }
+    return step;
+}
+
 // ---- frame groups (FrameSel::n_frames > 1) -------------------------------------------------------------------------------------
 // The alive list is ordered by ray id (stable compaction; the steady mode's frozen list keeps that order) and rays are
 // frame-major, so a 256-entry workgroup sees one frame, or two at a frame boundary.  A marching workgroup therefore loops over the
@@ -1016,6 +1444,34 @@ __device__ __forceinline__ void live_append(uint32_t step, uint32_t n, uint32_t 
     for (uint32_t k = 0; k < step; k++) live_idx[dst + k] = n * n_step + k;
 }
 
+// Appends the slots n * n_step .. + steps of every list entry of the workgroup to the live list with ONE atomic per workgroup (a
+// returning atomic on the one counter of an iteration costs ~11 ns of serialised time each: thousands of waves appending were a
+// large part of a launch).  Entry i = thread i (slot base n0 + i).  Contains barriers: every thread of the workgroup calls it.
+__device__ __forceinline__ void wg_live_append(const uint32_t *s_steps, uint32_t n0, uint32_t n_step, uint32_t *__restrict__ live_idx,
+                                               uint32_t *__restrict__ live_count, uint32_t *s_scan) {
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    const uint32_t mine = s_steps[threadIdx.x];
+    uint32_t incl = mine;
+    #pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(incl, off, 64);
+        if (lane >= (uint32_t)off) incl += u;
+    }
+    if (lane == 63u) s_scan[wid] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+        s_scan[4] = total ? atomicAdd(live_count, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t dst = s_scan[4] + incl - mine;
+    for (uint32_t w = 0; w < wid; w++) dst += s_scan[w];
+    if (mine) {
+        const uint32_t first = (n0 + threadIdx.x) * n_step;
+        for (uint32_t k = 0; k < mine; k++) live_idx[dst + k] = first + k;
+    }
+}
+
 // Resumes the compositing of one ray over its n_step slots (raymarching.cu:845-904).  Returns true if the ray survives.
 // The per-ray state and -- in the n_step == 8 case the loop spends most of its iterations in -- all 8 slots of the ray
 // (8 sigmas, 24 colours, 16 deltas: twelve 16-byte loads) are fetched before the serial recurrence starts, so the ray pays one
@@ -1023,7 +1479,7 @@ __device__ __forceinline__ void live_append(uint32_t step, uint32_t n, uint32_t 
 // behind); the arithmetic and its order, including the two early exits, are the reference's.
 __device__ __forceinline__ bool composite_ray(int index, uint32_t n_step, float T_thresh, const float *s, const float *c, const float *dl,
                                               float *__restrict__ rays_t, float *__restrict__ weights_sum, float *__restrict__ depth,
-                                              float *__restrict__ image) {
+                                              float *__restrict__ image, float *t_out = nullptr) {
     float t = rays_t[index];
     float weight_sum = weights_sum[index], d = depth[index];
     float r = image[(size_t)index * 3], g = image[(size_t)index * 3 + 1], b = image[(size_t)index * 3 + 2];
@@ -1067,6 +1523,7 @@ __device__ __forceinline__ bool composite_ray(int index, uint32_t n_step, float 
     }
     const bool survives = !(step < n_step);
     if (survives) rays_t[index] = t;
+    if (t_out) *t_out = t;
     weights_sum[index] = weight_sum; depth[index] = d;
     image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
     return survives;
@@ -1468,6 +1925,273 @@ __global__ void __launch_bounds__(256) k_composite_march(float T_thresh, int32_t
     publish_snapshot(state, snap, call);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The loop kernels on the cooperative marcher (FAST configuration with a constant step): phase A runs one lane per ray -- alive
+// test, cull scan or cached bound, compositing in the fused kernel -- and lists the rays that march in LDS; phase B marches the
+// listed rays 16 at a time, kGL lanes each (group_march).  Outputs are those of k_march_rays<true> / k_composite_march<true> bit
+// for bit (same slots, same zero fill, same counters); only the order of the live-sample list differs (it is unordered anyway).
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kGW = 256;     // list entries (rays) per 256-thread workgroup: phase A one lane per entry, phase B 16 rays per pass
+struct GroupTask { uint32_t n, tid, step0; float t, t_end, t_safe, far, last_t, o[3], d[3]; };   // 56 bytes: phase B reads no global memory to start a ray
+constexpr uint32_t kProbeBudget = 12;   // loop-body evaluations a lane spends on its own ray (8 samples + a few empty voxels) before the ray goes to a group
+
+// Phase B: the listed rays, 16 at a time, kGL lanes each.
+__device__ __forceinline__ void run_group_tasks(const GroupTask *s_task, uint32_t *s_steps, uint32_t *s_scan, uint32_t ntask, const OccCache &oc,
+                                                float bound, uint32_t max_steps, uint32_t H, const uint8_t *grid_f, uint32_t n_step,
+                                                float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas, uint8_t *slot_frame,
+                                                uint32_t frame, uint32_t stamp_base) {
+    const uint32_t lane = threadIdx.x & 63u, g = lane & (kGL - 1u), gbase = lane & ~(kGL - 1u);
+    const unsigned long long st0 = SDN_STAMP_NOW();
+    for (uint32_t first = 0; first < ntask; first += 256u / kGL) {        // workgroup-uniform trip count
+        const uint32_t gi = first + (threadIdx.x / kGL);
+        if (gi < ntask) {                                                   // group-uniform
+            const GroupTask tk = s_task[gi];
+            MarcherT<true> m;
+            m.init(tk.o, tk.d, bound, 0.0f, max_steps, 1u, H, grid_f);
+            m.fine = oc.fine; m.fx0 = oc.fx0; m.fy0 = oc.fy0; m.fz0 = oc.fz0; m.fnx = oc.fnx; m.fny = oc.fny; m.fnz = oc.fnz;
+            const uint32_t n = tk.n;
+            const uint32_t step = group_march(m, oc.s_cull, tk.t, tk.far, tk.t_end, n_step, xyzs + (size_t)n * n_step * 3,
+                                              dirs + (size_t)n * n_step * 3, deltas + (size_t)n * n_step * 2,
+                                              slot_frame ? slot_frame + (size_t)n * n_step : nullptr, frame, g, gbase, tk.t_safe, tk.step0, tk.last_t,
+#ifdef SDN_STAMPS
+                                              s_scan + 6
+#else
+                                              nullptr
+#endif
+                                              );
+            if (g == 0u) s_steps[tk.tid] = step;
+        }
+    }
+    if (threadIdx.x == 0) {
+        SDN_STAMP_ADD(stamp_base + 3, SDN_STAMP_NOW() - st0);
+        SDN_STAMP_ADD(stamp_base + 5, ntask);
+        SDN_STAMP_ADD(stamp_base + 0, 1);
+    }
+}
+
+// Phase A of a marching ray (one lane): cull scan or its cached result; then the lane marches its own ray for at most kProbeBudget
+// loop bodies (march_ray_some) -- a ray inside the figure is finished by then -- and a ray that is not finished (a long run of empty
+// voxels ahead: a fresh ray on its way from the cube's face to the figure goes there at once) becomes a task for a group of phase B.
+// Returns the samples written so far.
+__device__ __forceinline__ uint32_t group_enlist(GroupTask *s_task, uint32_t *s_ntask, const OccCache &oc, MarcherT<true> &m, uint32_t n, int index,
+                                                 float t, float far, float *tend, uint32_t n_step, float *__restrict__ xyzs,
+                                                 float *__restrict__ dirs, float *__restrict__ deltas, uint8_t *slot_frame, uint32_t frame) {
+    bool go = t < far;
+    float t_end = far, t_safe = -__FLT_MAX__;
+    if (oc.s_cull && go) {
+        const float cached = tend ? *tend : kTendUnset;
+        if (cached != kTendUnset) {
+            t_end = cached;                 // kTendDead (< every t) ends the ray here
+            go = t < t_end;
+        } else {
+            go = ray_may_hit(oc.s_cull, m.ox, m.oy, m.oz, m.dx, m.dy, m.dz, t, far, t_end, oc.fx0, oc.fy0, oc.fz0, oc.fnx, oc.fny, oc.fnz, &t_safe);
+            if (tend) *tend = go ? t_end : kTendDead;
+        }
+    }
+    float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3, *pl = deltas + (size_t)n * n_step * 2;
+    uint8_t *psf = slot_frame ? slot_frame + (size_t)n * n_step : nullptr;
+    uint32_t step = 0;
+    float last_t = t;
+    bool more = false;
+    const float t_start = t;
+    if (go) {
+        const bool jump = t_safe > t + 48.0f * m.dt_const;           // a fresh ray far from the first marked cell: straight to a group
+        step = march_ray_some(m, oc, t, far, t_end, n_step, px, pd, pl, psf, frame, jump ? 0u : kProbeBudget, last_t, more);
+    } else {
+        for (uint32_t k = 0; k < n_step; k++) {
+            px[0] = 0; px[1] = 0; px[2] = 0;
+            pd[0] = 0; pd[1] = 0; pd[2] = 0;
+            pl[0] = 0; pl[1] = 0;
+            px += 3; pd += 3; pl += 2;
+        }
+    }
+    if (more) {
+        const uint32_t at = atomicAdd(s_ntask, 1u);
+        s_task[at] = GroupTask{n, threadIdx.x, step, t, t_end, step == 0u && t == t_start ? t_safe : -__FLT_MAX__, far, last_t,
+                               {m.ox, m.oy, m.oz}, {m.dx, m.dy, m.dz}};
+    }
+    return step;
+}
+
+__global__ void __launch_bounds__(256) k_march_rays_g(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
+                                                      const float *__restrict__ rays_t, const float *__restrict__ rays_o,
+                                                      const float *__restrict__ rays_d, float bound, uint32_t max_steps, uint32_t H,
+                                                      const uint8_t *__restrict__ grid, const float *__restrict__ fars, float *__restrict__ xyzs,
+                                                      float *__restrict__ dirs, float *__restrict__ deltas, const float *__restrict__ noises,
+                                                      uint32_t M_pad, const uint32_t *__restrict__ cull, uint32_t *__restrict__ live_idx,
+                                                      uint32_t *__restrict__ live_count, const int32_t *__restrict__ state,
+                                                      const int32_t *__restrict__ rays_alive_b, FrameSel fs) {
+    if (state) {  // device-driven loop: sizes, ping-pong side and the iteration's live counter come from the loop state
+        n_alive = (uint32_t)state[0];
+        n_step = (uint32_t)state[1];
+        if (n_alive == 0) return;
+        if (state[4]) rays_alive = rays_alive_b;
+        live_count += state[3];
+        const uint32_t m0 = n_alive * n_step;
+        M_pad = m0 + (128u - m0 % 128u);
+    }
+    __shared__ uint4 s_cull4[256];
+    __shared__ unsigned long long s_fine[kFineCacheCells];
+    __shared__ uint32_t s_min4[4];
+    __shared__ GroupTask s_task[kGW];
+    __shared__ uint32_t s_ntask, s_steps[kGW], s_scan[8];
+    if (blockIdx.x * kGW >= n_alive + (M_pad - n_alive * n_step)) return;   // workgroup-uniform (grids are sized by an upper bound)
+    const uint32_t n = blockIdx.x * kGW + threadIdx.x;
+    const int index = n < n_alive ? rays_alive[n] : -1;
+    const bool grouped = fs.n_frames > 1;  // kernel-uniform
+    const uint32_t frame = (grouped && index >= 0) ? (uint32_t)index / fs.rays_per_frame : (grouped ? kNoFrame : 0u);
+    s_steps[threadIdx.x] = 0;
+    uint32_t fcur = grouped ? block_min_256(frame, s_min4) : 0u;
+    while (fcur != kNoFrame) {   // one round per frame present in this workgroup (exactly one without a frame group)
+        const uint8_t *grid_f = grouped ? frame_grid_uniform(fs, fcur) : grid;
+        const uint32_t *cull_f = (grouped && cull) ? cull + (size_t)fcur * fs.cull_stride : cull;
+        if (threadIdx.x == 0) { s_ntask = 0; s_scan[6] = 0; s_scan[7] = 0; }
+        const unsigned long long sa0 = SDN_STAMP_NOW();
+        OccCache oc;
+        occ_cache_load<true>(cull_f, grid_f, s_cull4, s_fine, oc);
+        if (!cull_f) __syncthreads();
+        const unsigned long long sa1 = SDN_STAMP_NOW();
+        if (index >= 0 && frame == fcur) {
+            MarcherT<true> m;
+            m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, 0.0f, max_steps, 1u, H, grid_f);
+            float t = rays_t[index];
+            t += m.step_size(t) * (noises ? noises[n] : 0.0f);
+            float *tend = state ? state_tend(state) : nullptr;
+            if (tend) tend += index;
+            s_steps[threadIdx.x] = group_enlist(s_task, &s_ntask, oc, m, n, index, t, fars[index], tend, n_step, xyzs, dirs, deltas,
+                                                grouped ? fs.slot_frame : nullptr, fcur);
+        }
+        __syncthreads();
+        const uint32_t ntask = s_ntask;
+        if (threadIdx.x == 0) { SDN_STAMP_ADD(8 + 2, sa1 - sa0); SDN_STAMP_ADD(8 + 1, SDN_STAMP_NOW() - sa1); }
+        if (ntask)                                                           // workgroup-uniform
+            run_group_tasks(s_task, s_steps, s_scan, ntask, oc, bound, max_steps, H, grid_f, n_step, xyzs, dirs, deltas,
+                            grouped ? fs.slot_frame : nullptr, fcur, 8u);
+        if (!grouped) break;
+        fcur = block_min_256((frame != kNoFrame && frame > fcur) ? frame : kNoFrame, s_min4);   // (the barriers inside also fence the LDS caches and the task list)
+    }
+    __syncthreads();
+    const unsigned long long sl0 = SDN_STAMP_NOW();
+    if (live_idx) wg_live_append(s_steps, blockIdx.x * kGW, n_step, live_idx, live_count, s_scan);   // kernel-uniform condition
+    if (threadIdx.x == 0) {
+        SDN_STAMP_ADD(8 + 4, SDN_STAMP_NOW() - sl0);
+#ifdef SDN_STAMPS
+        SDN_STAMP_ADD(8 + 6, s_scan[6]); SDN_STAMP_ADD(8 + 7, s_scan[7]);
+#endif
+    }
+    if (n >= n_alive) {
+        const uint32_t slot = n_alive * n_step + (n - n_alive);  // spare lanes of the last blocks clear the alignment tail
+        if (slot < M_pad) {
+            xyzs[(size_t)slot * 3] = 0; xyzs[(size_t)slot * 3 + 1] = 0; xyzs[(size_t)slot * 3 + 2] = 0;
+            dirs[(size_t)slot * 3] = 0; dirs[(size_t)slot * 3 + 1] = 0; dirs[(size_t)slot * 3 + 2] = 0;
+            deltas[(size_t)slot * 2] = 0; deltas[(size_t)slot * 2 + 1] = 0;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_composite_march_g(float T_thresh, int32_t *__restrict__ alive_a, int32_t *__restrict__ alive_b,
+                                                           float *__restrict__ rays_t, const float *__restrict__ rays_o,
+                                                           const float *__restrict__ rays_d, float bound, uint32_t max_steps, uint32_t H,
+                                                           const uint8_t *__restrict__ grid, const float *__restrict__ fars,
+                                                           const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                                           float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
+                                                           float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image,
+                                                           const uint32_t *__restrict__ cull, uint32_t *__restrict__ live_idx,
+                                                           uint32_t *__restrict__ live_counts, int32_t *__restrict__ state,
+                                                           int32_t *__restrict__ ticket, int32_t *__restrict__ trace, int32_t *__restrict__ snap,
+                                                           FrameSel fs) {
+    __shared__ uint4 s_cull4[256];
+    __shared__ unsigned long long s_fine[kFineCacheCells];
+    __shared__ uint32_t s_cnt[4], s_min4[4];
+    __shared__ GroupTask s_task[kGW];
+    __shared__ uint32_t s_ntask, s_steps[kGW], s_scan[8];
+    __shared__ int s_last;
+    const uint32_t n_alive = (uint32_t)state[0], n_step = (uint32_t)state[1], list_len = (uint32_t)state[8];
+    const int32_t it = state[3];
+    int32_t *__restrict__ alive = state[4] ? alive_b : alive_a;
+    const bool march_next = (uint32_t)state[2] + n_step < (uint32_t)state[6];  // `while step < max_steps` admits another iteration
+    const uint32_t n = blockIdx.x * kGW + threadIdx.x;
+    bool survives = false;
+    if (n_alive > 0 && blockIdx.x * kGW < list_len) {  // workgroup-uniform
+        const unsigned long long sa0 = SDN_STAMP_NOW();
+        const int index = n < list_len ? alive[n] : -1;
+        float t_now = 0.0f;
+        s_steps[threadIdx.x] = 0;
+        // composite iteration `it` of this ray; survivors march iteration it + 1 below
+        if (index >= 0) {
+            survives = composite_ray(index, n_step, T_thresh, sigmas + (size_t)n * n_step, rgbs + (size_t)n * n_step * 3,
+                                     deltas + (size_t)n * n_step * 2, rays_t, weights_sum, depth, image, &t_now);
+            if (!survives) alive[n] = -1;
+        }
+        const bool marches = survives && march_next;
+        const bool grouped = fs.n_frames > 1;  // kernel-uniform
+        const uint32_t frame = (grouped && marches) ? (uint32_t)index / fs.rays_per_frame : (grouped ? kNoFrame : 0u);
+        uint32_t fcur = grouped ? block_min_256(frame, s_min4) : 0u;
+        while (fcur != kNoFrame) {   // one round per frame present among this workgroup's marching rays (see block_min_256)
+            const uint8_t *grid_f = grouped ? frame_grid_uniform(fs, fcur) : grid;
+            const uint32_t *cull_f = (grouped && cull) ? cull + (size_t)fcur * fs.cull_stride : cull;
+            if (threadIdx.x == 0) { s_ntask = 0; s_scan[6] = 0; s_scan[7] = 0; }
+            const unsigned long long sa1 = SDN_STAMP_NOW();
+            OccCache oc;
+            occ_cache_load<true>(cull_f, grid_f, s_cull4, s_fine, oc);
+            if (!cull_f) __syncthreads();
+            const unsigned long long sa2 = SDN_STAMP_NOW();
+            if (marches && frame == fcur) {
+                MarcherT<true> m;
+                m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, 0.0f, max_steps, 1u, H, grid_f);
+                float *tend = state_tend(state);
+                if (tend) tend += index;
+                s_steps[threadIdx.x] = group_enlist(s_task, &s_ntask, oc, m, n, index, t_now, fars[index], tend, n_step, xyzs, dirs, deltas,
+                                                    grouped ? fs.slot_frame : nullptr, fcur);
+            }
+            __syncthreads();
+            const uint32_t ntask = s_ntask;
+            if (threadIdx.x == 0) { SDN_STAMP_ADD(2, sa2 - sa1); SDN_STAMP_ADD(1, (sa1 - sa0) + (SDN_STAMP_NOW() - sa2)); }
+            if (ntask)
+                run_group_tasks(s_task, s_steps, s_scan, ntask, oc, bound, max_steps, H, grid_f, n_step, xyzs, dirs, deltas,
+                                grouped ? fs.slot_frame : nullptr, fcur, 0u);
+            if (!grouped) break;
+            fcur = block_min_256((frame != kNoFrame && frame > fcur) ? frame : kNoFrame, s_min4);
+        }
+        __syncthreads();
+        const unsigned long long sl0 = SDN_STAMP_NOW();
+        wg_live_append(s_steps, blockIdx.x * kGW, n_step, live_idx, live_counts + it + 1, s_scan);
+        if (threadIdx.x == 0) {
+            SDN_STAMP_ADD(4, SDN_STAMP_NOW() - sl0);
+#ifdef SDN_STAMPS
+            SDN_STAMP_ADD(6, s_scan[6]); SDN_STAMP_ADD(7, s_scan[7]);
+#endif
+        }
+    }
+    // survivors of this workgroup -> global accumulator; the last workgroup of the launch advances the loop record
+    const unsigned long long mask = __ballot(survives);
+    if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t c = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (c) atomicAdd(state + 9, (int32_t)c);
+        __threadfence();
+        s_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x != 0) return;
+    __threadfence();
+    *ticket = 0;
+    const int32_t call = state[7];
+    state[7] = call + 1;
+    if (state[0] > 0) {
+        trace[2 * it] = state[0];
+        trace[2 * it + 1] = state[1];
+        state[2] += state[1];
+        state[3] = it + 1;
+        int32_t n_new = atomicAdd(state + 9, 0);
+        state[9] = 0;
+        if (state[2] >= state[6]) n_new = 0;
+        state[0] = n_new;  // n_step stays 8: N / n_new >= 8 holds from here on
+    }
+    publish_snapshot(state, snap, call);
+}
+
 // image = image + (1 - weights_sum) * bg ; depth = clamp(depth - nears, 0) / (fars - nears)   (dnerf/renderer.py:378-379)
 __global__ void __launch_bounds__(256) k_loop_finish(uint32_t N, const float *__restrict__ nears, const float *__restrict__ fars,
                                                      const float *__restrict__ weights_sum, const float *__restrict__ depth,
@@ -1482,6 +2206,20 @@ __global__ void __launch_bounds__(256) k_loop_finish(uint32_t N, const float *__
     depth_out[n] = fmaxf(depth[n] - nears[n], 0.0f) / (fars[n] - nears[n]);
 }
 
+}  // namespace
+
+namespace {
+// The cooperative (16 lanes per ray) marcher for the FAST configuration with a constant step is an OPT-IN (SDN_GROUP_MARCH=1 in the
+// environment): it produces the lane-per-ray kernels' samples bit for bit and is neither faster nor slower on the headline frame
+// (profiles/r03_cooperative_marcher.txt, DESIGN.md "The cooperative marcher").  Default: the lane-per-ray kernels.
+bool use_group_march(float bound, float dt_gamma, uint32_t C, uint32_t H) {
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("SDN_GROUP_MARCH");
+        on = (e && e[0] == '1') ? 1 : 0;
+    }
+    return on && dt_gamma == 0.0f && fast_config(bound, C, H);
+}
 }  // namespace
 
 namespace sdn_int {
@@ -1500,7 +2238,11 @@ int loop_march(uint32_t bound_alive, const int32_t *alive_a, const int32_t *aliv
                const float *fars, float *xyzs, float *dirs, float *deltas, const uint32_t *cull, uint32_t *live_idx,
                uint32_t *live_counts, const int32_t *state, const FrameSel &fs, hipStream_t st) {
     const dim3 g(sdn_div_up(bound_alive + 128u, 256u)), b(256);
-    if (fast_config(bound, C, H)) {
+    if (use_group_march(bound, dt_gamma, C, H)) {
+        if (cull && H != 128) cull = nullptr;
+        hipLaunchKernelGGL(k_march_rays_g, dim3(sdn_div_up(bound_alive + 128u, kGW)), b, 0, st, 0u, 0u, alive_a, rays_t, rays_o, rays_d, bound, max_steps, H, grid, fars, xyzs, dirs, deltas,
+                           (const float *)nullptr, 0u, cull, live_idx, live_counts, state, alive_b, fs);
+    } else if (fast_config(bound, C, H)) {
         if (cull && H != 128) cull = nullptr;
         hipLaunchKernelGGL(k_march_rays<true>, g, b, 0, st, 0u, 0u, alive_a, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars,
                            xyzs, dirs, deltas, (const float *)nullptr, 0u, cull, live_idx, live_counts, state, alive_b, fs);
@@ -1551,7 +2293,11 @@ int loop_composite_march(uint32_t bound_list, float T_thresh, int32_t *alive_a, 
                          float *weights_sum, float *depth, float *image, const uint32_t *cull, uint32_t *live_idx, uint32_t *live_counts,
                          int32_t *state, int32_t *ticket, int32_t *trace, int32_t *snap, const FrameSel &fs, hipStream_t st) {
     const dim3 g(sdn_div_up(bound_list, 256u)), b(256);
-    if (fast_config(bound, C, H)) {
+    if (use_group_march(bound, dt_gamma, C, H)) {
+        if (cull && H != 128) cull = nullptr;
+        hipLaunchKernelGGL(k_composite_march_g, dim3(sdn_div_up(bound_list, kGW)), b, 0, st, T_thresh, alive_a, alive_b, rays_t, rays_o, rays_d, bound, max_steps, H, grid, fars,
+                           sigmas, rgbs, xyzs, dirs, deltas, weights_sum, depth, image, cull, live_idx, live_counts, state, ticket, trace, snap, fs);
+    } else if (fast_config(bound, C, H)) {
         if (cull && H != 128) cull = nullptr;
         hipLaunchKernelGGL(k_composite_march<true>, g, b, 0, st, T_thresh, alive_a, alive_b, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
                            grid, fars, sigmas, rgbs, xyzs, dirs, deltas, weights_sum, depth, image, cull, live_idx, live_counts, state, ticket,
@@ -1571,9 +2317,11 @@ int loop_finish(uint32_t N, const float *nears, const float *fars, const float *
     return sdn_launch_status();
 }
 
-int build_cull(const uint8_t *bitfield, uint32_t *cull_bits, hipStream_t st) {
+// with_image: the buffer has sdn_cull_grid_bytes() behind it (marks + meta + packed fine bits); false: marks + meta only
+int build_cull(const uint8_t *bitfield, uint32_t *cull_bits, hipStream_t st, bool with_image) {
     hipLaunchKernelGGL(k_cull_meta_init, dim3(1), dim3(64), 0, st, cull_bits, 1u, 0u);
     hipLaunchKernelGGL(k_build_cull_grid, dim3(kCullRes * kCullRes * kCullRes / 256), dim3(256), 0, st, bitfield, cull_bits, FrameSel());
+    if (with_image) hipLaunchKernelGGL(k_build_fine_image, dim3(kFineCacheCells / 256), dim3(256), 0, st, bitfield, cull_bits, FrameSel());
     return sdn_launch_status();
 }
 
@@ -1596,6 +2344,7 @@ int build_cull_group(const FrameSel &fs, uint32_t *cull_bits, hipStream_t st) {
     hipLaunchKernelGGL(k_cull_meta_init, dim3(1), dim3(64), 0, st, cull_bits, fs.n_frames, fs.cull_stride);
     hipLaunchKernelGGL(k_build_cull_grid, dim3(kCullRes * kCullRes * kCullRes / 256, fs.n_frames), dim3(256), 0, st, (const uint8_t *)nullptr,
                        cull_bits, fs);
+    hipLaunchKernelGGL(k_build_fine_image, dim3(kFineCacheCells / 256, fs.n_frames), dim3(256), 0, st, (const uint8_t *)nullptr, cull_bits, fs);
     return sdn_launch_status();
 }
 
@@ -1701,7 +2450,7 @@ int sdn_int::march_rays_train(const float *rays_o, const float *rays_d, const ui
     if (use_cull && prebuilt_cull) {
         cull = (const uint32_t *)prebuilt_cull;
     } else if (use_cull) {
-        int rc = sdn_int::build_cull(grid, (uint32_t *)((unsigned char *)scratch + head), st);
+        int rc = sdn_int::build_cull(grid, (uint32_t *)((unsigned char *)scratch + head), st, false);   // (the scratch has no room for the image)
         if (rc) return rc;
     }
     if (fast && dt_gamma == 0.0f && H <= 256u)   // constant step: one WAVE per ray (k_march_train_count_wave), same samples bit for bit
@@ -1771,7 +2520,11 @@ static int launch_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *r
     if (M_pad < base) M_pad = base;
     const uint32_t threads = n_alive + (M_pad - base);  // one lane per alive ray + one per tail slot
     const dim3 g(sdn_div_up(threads, 256u)), b(256);
-    if (fast_config(bound, C, H)) {
+    if (use_group_march(bound, dt_gamma, C, H)) {
+        if (cull && H != 128) cull = nullptr;  // the cull grid is built for the 128^3 grid only
+        hipLaunchKernelGGL(k_march_rays_g, dim3(sdn_div_up(threads, kGW)), b, 0, st, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, max_steps, H, grid, fars, xyzs,
+                           dirs, deltas, noises, M_pad, cull, live_idx, live_count, (const int32_t *)nullptr, (const int32_t *)nullptr, FrameSel());
+    } else if (fast_config(bound, C, H)) {
         if (cull && H != 128) cull = nullptr;  // the cull grid is built for the 128^3 grid only
         hipLaunchKernelGGL(k_march_rays<true>, g, b, 0, st, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
                            grid, fars, xyzs, dirs, deltas, noises, M_pad, cull, live_idx, live_count, (const int32_t *)nullptr,
@@ -1801,7 +2554,17 @@ int sdn_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_t *rays_ali
                              deltas, noises, M_pad, (const uint32_t *)cull_grid, live_idx, live_count, (hipStream_t)stream);
 }
 
-uint32_t sdn_cull_grid_bytes(void) { return kCullWords * 4 + 32; }  // marks + bounding-box record
+#ifdef SDN_STAMPS
+// diagnostic build only: copies out and clears the stamp sums (see g_stamps)
+int sdn_debug_stamps(unsigned long long *out32) {
+    if (!out32) return SDN_E_BADARG;
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32) != hipSuccess) return sdn_launch_status();
+    const unsigned long long zeros[32] = {};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zeros, sizeof(zeros));
+}
+#endif
+
+uint32_t sdn_cull_grid_bytes(void) { return kCullImageWord * 4 + kFineCacheCells * 8; }  // marks + bounding-box record + packed fine bits
 
 int sdn_build_cull_grid(const uint8_t *bitfield, uint32_t H, uint8_t *cull_grid, void *stream) {
     if (!bitfield || !cull_grid) return SDN_E_BADARG;
@@ -1810,6 +2573,7 @@ int sdn_build_cull_grid(const uint8_t *bitfield, uint32_t H, uint8_t *cull_grid,
     hipLaunchKernelGGL(k_cull_meta_init, dim3(1), dim3(64), 0, (hipStream_t)stream, (uint32_t *)cull_grid, 1u, 0u);
     hipLaunchKernelGGL(k_build_cull_grid, dim3(kCullRes * kCullRes * kCullRes / 256), dim3(256), 0, (hipStream_t)stream, bitfield,
                        (uint32_t *)cull_grid, FrameSel());
+    hipLaunchKernelGGL(k_build_fine_image, dim3(kFineCacheCells / 256), dim3(256), 0, (hipStream_t)stream, bitfield, (uint32_t *)cull_grid, FrameSel());
     return sdn_launch_status();
 }
 

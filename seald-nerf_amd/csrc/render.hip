@@ -36,7 +36,17 @@ int render_begin(const SdnRenderCtx *c, void *mailbox, uint32_t frame_tag, hipSt
 }
 }  // namespace sdn_int
 
+namespace {
+std::atomic<int> g_timed_kernel{0};   // sdn_render_time_kernel: 0 = the field launch, 1 = the marcher launch of an iteration
+}
+
 extern "C" {
+
+int sdn_render_time_kernel(int which) {
+    if (which < 0 || which > 1) return SDN_E_BADARG;
+    g_timed_kernel.store(which);
+    return 0;
+}
 
 int sdn_render_finish(const SdnRenderCtx *c, float bg_color, float *image_out, float *depth_out, void *stream);
 int sdn_render_step_f16_ev(const SdnRenderCtx *c, uint32_t bound_alive, void *ev_field_begin, void *ev_field_end, void *stream);
@@ -85,9 +95,13 @@ int sdn_render_step_f16_ev(const SdnRenderCtx *c, uint32_t bound_alive, void *ev
     if (bound_alive > c->N) bound_alive = c->N;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t *cull = (c->H == 128 && c->C == 1) ? (const uint32_t *)c->cull_bits : nullptr;
+    const bool time_march = g_timed_kernel.load() == 1;
+    if (time_march && ev_field_begin) (void)hipEventRecord((hipEvent_t)ev_field_begin, st);
     int rc = sdn_int::loop_march(bound_alive, c->alive_a, c->alive_b, c->rays_t, c->rays_o, c->rays_d, c->bound, c->dt_gamma, c->max_steps,
                                  c->C, c->H, c->bitfield, c->fars, c->xyzs, c->dirs, c->deltas, cull, c->live_idx,
                                  (uint32_t *)c->live_counts, c->state, sdn_int::frame_sel(c), st);
+    if (time_march && ev_field_end) (void)hipEventRecord((hipEvent_t)ev_field_end, st);
+    if (time_march) ev_field_begin = ev_field_end = nullptr;
     if (rc) return rc;
     // n_alive * n_step <= N always (n_step <= N / n_alive), and <= 8 * bound_alive
     uint64_t m_bound = (uint64_t)bound_alive * 8u;
@@ -168,6 +182,9 @@ struct FrameRun {
             if (m_bound > c->N) m_bound = c->N;
             rc = seal_map(c, (uint32_t)m_bound, st);
             if (rc) return rc;
+            const bool time_march = g_timed_kernel.load() == 1;
+            void *m0 = time_march ? e0 : nullptr, *m1 = time_march ? e1 : nullptr;
+            if (time_march) e0 = e1 = nullptr;
             if (e0) (void)hipEventRecord((hipEvent_t)e0, st);
             rc = sdn_int::field_forward_f16(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, (uint32_t)m_bound,
                                             c->field_weights, c->field_bias0, c->grid_table, c->grid_offsets, c->grid_S, c->grid_H, c->bound,
@@ -175,11 +192,13 @@ struct FrameRun {
                                             c->n_group_frames > 1 ? c->slot_frame : nullptr, st);
             if (e1) (void)hipEventRecord((hipEvent_t)e1, st);
             if (!rc) rc = seal_color(c, (uint32_t)m_bound, st);
+            if (!rc && m0) (void)hipEventRecord((hipEvent_t)m0, st);
             if (!rc)
                 rc = sdn_int::loop_composite_march(bound, c->T_thresh, c->alive_a, c->alive_b, c->rays_t, c->rays_o, c->rays_d, c->bound,
                                                    c->dt_gamma, c->max_steps, c->C, c->H, c->bitfield, c->fars, c->sigmas, c->rgbs, c->xyzs,
                                                    c->dirs, c->deltas, c->weights_sum, c->depth, c->image, cull(), c->live_idx,
                                                    (uint32_t *)c->live_counts, c->state, c->n_out, c->trace, snap_dev, sdn_int::frame_sel(c), st);
+            if (!rc && m1) (void)hipEventRecord((hipEvent_t)m1, st);
         }
         if (rc) return rc;
         if (mail_dev) return 0;

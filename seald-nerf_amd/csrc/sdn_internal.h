@@ -38,7 +38,7 @@ int loop_composite_march(uint32_t bound_list, float T_thresh, int32_t *alive_a, 
 int loop_finish(uint32_t N, const float *nears, const float *fars, const float *weights_sum, const float *depth, const float *image, float bg,
                 float *image_out, float *depth_out, hipStream_t st);
 int render_begin(const SdnRenderCtx *c, void *mailbox, uint32_t frame_tag, hipStream_t st);
-int build_cull(const uint8_t *bitfield, uint32_t *cull_bits, hipStream_t st);
+int build_cull(const uint8_t *bitfield, uint32_t *cull_bits, hipStream_t st, bool with_image = true);
 int march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C,
                      uint32_t H, uint32_t M, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
                      const float *noises, void *scratch, const void *prebuilt_cull, hipStream_t st);

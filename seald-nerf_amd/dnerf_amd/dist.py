@@ -30,6 +30,53 @@ def shard_rays(n_rays, W, rank, world, tile=16):
     return mine.astype(np.int64), per
 
 
+class InOrderHandOn:
+    """Hands finished loops (frames, or frame groups) on to `on_done(f, image, depth)` in FRAME ORDER from a helper thread while later
+    loops still render -- the hook of the per-loop all-gather of a ray-sharded job.  Several loops are in flight and finish out of
+    order; every rank must issue its collectives in the same order, so loop f is handed on only after loops 0 .. f-1, whenever it
+    finished.  `finished(f)`: has loop f's last kernel been enqueued (the frame driver publishes its iteration count)?  `before(f)`:
+    optional, called right before `on_done` (orders the helper's stream behind the loop's `done` event).  `context`: optional context
+    manager factory entered by the thread (its CUDA stream).  `join()` re-raises what `on_done` raised; `cancel()` stops the thread.
+    `order` records the loops in the order they were handed on; `stamps` the host times (perf_counter) around each `on_done`."""
+
+    def __init__(self, n, finished, on_done, outputs, before=None, context=None, poll=2e-5):
+        import threading
+        self.n, self.finished, self.on_done, self.outputs, self.before, self.context, self.poll = n, finished, on_done, outputs, before, context, poll
+        self.order, self.stamps, self.failed, self._cancel = [], [], [], False
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def start(self):
+        self.thread.start()
+        return self
+
+    def cancel(self):
+        self._cancel = True
+
+    def _run(self):
+        import contextlib
+        import time as _t
+        try:
+            with (self.context() if self.context is not None else contextlib.nullcontext()):
+                for f in range(self.n):
+                    while not self.finished(f) and not self._cancel:
+                        _t.sleep(self.poll)
+                    if self._cancel:
+                        return
+                    if self.before is not None:
+                        self.before(f)
+                    t0 = _t.perf_counter()
+                    self.on_done(f, self.outputs[f][0], self.outputs[f][1])
+                    self.order.append(f)
+                    self.stamps.append((t0, _t.perf_counter()))
+        except BaseException as exc:     # surfaced by join()
+            self.failed.append(exc)
+
+    def join(self):
+        self.thread.join()
+        if self.failed:
+            raise self.failed[0]
+
+
 class FrameGather:
     """Pre-computed index maps + buffers for assembling the full frame on every rank.
 

@@ -758,42 +758,33 @@ class PipelinedDeviceLoop:
         _dbg = os.environ.get("SDN_DRIVER_STATS")
         a_done, worker = None, None
         if on_done is not None:
-            import threading
-            done = [torch.cuda.Event() for _ in range(n)]
+            from .dist import InOrderHandOn
+            # (timing-enabled: bench.py reads the device-side span of the renders and of the gathers from them)
+            done = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
             for e in done:
                 e.record(cur)                    # materialises the hipEvent_t handles; the driver re-records them
             a_done = (vp * n)(*[e.cuda_event for e in done])
-            failed = []
             dev_index = self.streams[0].device_index
+            self._done_stream = getattr(self, "_done_stream", None) or torch.cuda.Stream()
+            side = self._done_stream
 
-            def hand_on():                       # frame f is finished once the driver has published its iteration count
+            def in_side_stream():                # the helper thread's CUDA context: this device, its own stream
                 torch.cuda.set_device(dev_index)
-                side = self._done_stream = getattr(self, "_done_stream", None) or torch.cuda.Stream()
-                try:
-                    with torch.cuda.stream(side):
-                        for f in range(n):
-                            while iters[f] == 0 and not failed:
-                                _t.sleep(2e-5)
-                            if failed:
-                                return
-                            side.wait_event(done[f])
-                            on_done(f, outputs[f][0], outputs[f][1])
-                except BaseException as exc:     # surfaced by the caller below
-                    failed.append(exc)
-            worker = threading.Thread(target=hand_on, daemon=True)
-            worker.start()
+                return torch.cuda.stream(side)
+            # loop f is finished once the driver has published its iteration count; its `done` event orders the helper's stream behind it
+            worker = InOrderHandOn(n, lambda f: iters[f] != 0, on_done, outputs, before=lambda f: side.wait_event(done[f]),
+                                   context=in_side_stream).start()
+            self.last_done_events, self.last_hand_on = done, worker
         _t0 = _t.perf_counter()
         try:
             self._drive(lib, n, a_ro, a_rd, a_img, a_dep, bg_color, fx, a_ev, n_ev, exclusive, a_ft, a_done, iters)
         except BaseException:
             if worker is not None:
-                failed.append(True)
-                worker.join()
+                worker.cancel()
+                worker.thread.join()
             raise
         if worker is not None:
             worker.join()
-            if failed:
-                raise failed[0]
             cur.wait_stream(self._done_stream)
         self._ft_refs = ft_refs    # the per-frame constants stay alive until the next stream of frames
         _t1 = _t.perf_counter()

@@ -45,6 +45,7 @@ PROTOTYPES = {
     "sdn_render_step_f16": [_vp, _u32, _vp],
     "sdn_render_step_f16_ev": [_vp, _u32, _vp, _vp, _vp],
     "sdn_render_finish": [_vp, _f32, _vp, _vp, _vp],
+    "sdn_render_time_kernel": [_i32],
     "sdn_render_frame_f16": [_vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     "sdn_render_frames_pipelined_f16": [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp],
     "sdn_host_mailbox_free": [_vp],

@@ -172,3 +172,73 @@ def test_data_parallel_gradient_exchange_gloo(tmp_path):
     world = 2
     mp.spawn(_dp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all(bool(np.load(tmp_path / f"dp_{r}.npy")[0]) for r in range(world))
+
+
+def _hand_on_worker(rank, world, port, H, W, n_loops, out_dir):
+    """One rank of a ray-sharded job whose loops finish OUT OF ORDER (4 in flight, as the pipelined frame driver keeps them): a fake
+    driver thread publishes loop completions in a per-rank shuffled order, `InOrderHandOn` runs the per-loop gather from its helper
+    thread.  Collectives must be issued in loop order on every rank -- a rank that gathered loop 3 while another gathered loop 1
+    would exchange the wrong frames (or deadlock)."""
+    import threading
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dnerf_amd.dist import FrameGather, InOrderHandOn, shard_rays
+        n = H * W
+        idx, per = shard_rays(n, W, rank, world)
+        fg = FrameGather(n, W, world, "cpu")
+        ref = torch.arange(n, dtype=torch.float32)
+        # loop f renders "image" = ray id + 1000 f on this rank's shard
+        outputs = [(torch.stack([ref[idx] + 1000 * f, ref[idx] * 2, ref[idx] * 3], 1), ref[idx] * 0.5 + f) for f in range(n_loops)]
+        finished = [False] * n_loops
+        frames = {}
+
+        def on_done(f, img, dep):
+            frames[f] = fg(img, dep).clone()
+
+        def driver():   # 4 loops in flight; the one that finishes next is drawn at random (different on every rank)
+            rng = np.random.default_rng(100 + rank)
+            in_flight, nxt = list(range(min(4, n_loops))), min(4, n_loops)
+            while in_flight:
+                time.sleep(float(rng.uniform(0, 2e-3)))
+                f = in_flight.pop(int(rng.integers(len(in_flight))))
+                finished[f] = True
+                if nxt < n_loops:
+                    in_flight.append(nxt)
+                    nxt += 1
+        hand = InOrderHandOn(n_loops, lambda f: finished[f], on_done, outputs).start()
+        th = threading.Thread(target=driver)
+        th.start()
+        th.join()
+        hand.join()
+        ok = hand.order == list(range(n_loops)) and len(hand.stamps) == n_loops
+        ok = ok and all(hand.stamps[f][1] <= hand.stamps[f + 1][0] for f in range(n_loops - 1))       # one gather at a time, in order
+        for f in range(n_loops):
+            ok = ok and torch.equal(frames[f], torch.stack([ref + 1000 * f, ref * 2, ref * 3, ref * 0.5 + f], 1))
+        np.save(os.path.join(out_dir, f"ho_{rank}.npy"), np.array([ok]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gathers_are_handed_on_in_loop_order_with_four_loops_in_flight(tmp_path):
+    """nerf/utils.py:963-977 are the reference's only collectives (metric gathers); here the per-loop tile all-gather is issued by a
+    helper thread while later loops render: order and content across two ranks whose loops finish in different orders."""
+    world = 2
+    mp.spawn(_hand_on_worker, args=(world, _free_port(), 48, 64, 12, str(tmp_path)), nprocs=world, join=True)
+    assert all(bool(np.load(tmp_path / f"ho_{r}.npy")[0]) for r in range(world))
+
+
+def test_hand_on_surfaces_errors_and_can_be_cancelled():
+    from dnerf_amd.dist import InOrderHandOn
+
+    def boom(f, a, b):
+        raise RuntimeError("gather failed")
+    h = InOrderHandOn(2, lambda f: True, boom, [(None, None)] * 2).start()
+    with pytest.raises(RuntimeError, match="gather failed"):
+        h.join()
+    h = InOrderHandOn(2, lambda f: False, lambda *a: None, [(None, None)] * 2).start()
+    h.cancel()
+    h.join()
+    assert h.order == []

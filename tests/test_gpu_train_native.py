@@ -287,8 +287,9 @@ def test_reference_training_fixture_gradients():
         # the hash-grid gradient (gridencoder.cu:248-340 through the reference network's autograd; the fixture keeps per-level
         # (sum, sum |.|, sum of squares), 16 384 sampled rows and the count of touched rows): the native step's fp16 accumulator,
         # unscaled.  Bars are fp16-distance (an fp16 backward through the sigma / colour MLPs into fp16 atomics against an fp32 one):
-        # per level the L2 norm and the absolute sum to 5 % (measured <= 2 %), the sampled rows to 6 % in L2 (measured 3 %); the set of
-        # touched rows is an integer property of the samples and must be the fixture's up to entries whose fp16 gradient underflows.
+        # per level the L2 norm and the absolute sum to 0.5 % (measured 0.07 %), the sampled rows to 1.5 % in L2 (measured 0.4 %); the set of
+        # touched rows is an integer property of the samples and must be the fixture's up to entries whose fp16 gradient underflows
+        # (measured 76 924 of 76 929).
         ge = (grads["encoder.embeddings"].double() / 65536.0).cpu().numpy()
         off = model.encoder.offsets.cpu().numpy()
         ref_lv = fx["perturb_grad_emb_levels"]
@@ -300,8 +301,8 @@ def test_reference_training_fixture_gradients():
         row_err = float(np.linalg.norm(ge[rows] - vals) / np.linalg.norm(vals))
         nnz, ref_nnz = int((np.abs(ge).sum(1) != 0).sum()), int(fx["perturb_grad_emb_nnz_rows"])
         report = dict(level_l2=float(l2_err.max()), level_l1=float(l1_err.max()), level_sum=float(sum_err.max()), rows_l2=row_err, nnz=nnz, ref_nnz=ref_nnz)
-        assert l2_err.max() < 5e-2 and l1_err.max() < 5e-2 and sum_err.max() < 2e-2 and row_err < 6e-2, report
-        assert nnz <= ref_nnz and nnz >= 0.97 * ref_nnz, report
+        assert l2_err.max() < 5e-3 and l1_err.max() < 5e-3 and sum_err.max() < 5e-3 and row_err < 1.5e-2, report
+        assert nnz <= ref_nnz and nnz >= 0.999 * ref_nnz, report
         print("table gradient vs reference fixture:", report)
     finally:
         model.eval()
@@ -442,23 +443,52 @@ def test_marching_the_next_batch_ahead_changes_nothing():
         assert float(d.max()) <= (1.1e-1 if k == "encoder.embeddings" else 1.1e-2), k
 
 
+def _step_state(step, model, opt, scaler):
+    """Everything a native step reads: fp32 parameters, their fp16 copies, both Adam moments, the device step counts, the scaler's
+    scale and growth tracker, the table's gradient accumulator."""
+    rows = model.encoder.embeddings.shape[0]
+    s = {"adam_steps": step.adam_steps.clone(), "scale": scaler._scale.clone(), "tracker": scaler._growth_tracker.clone(),
+         "g_table": step.view("g_table", torch.float16, (rows, 2)).clone(), "w_table": step.view("w_table", torch.float16, (rows, 2)).clone(),
+         "w_deform": step.view("w_deform", torch.float16, (128 * 80 + 6 * 128 * 128 + 16 * 128,)).clone(),
+         "w_sigma0": step.view("w_sigma0", torch.float16, (64, 32)).clone(), "w_sigma1": step.view("w_sigma1", torch.float16, (16, 64)).clone(),
+         "w_color": step.view("w_color", torch.float16, (64 * 32 + 64 * 64 + 16 * 64,)).clone()}
+    for n, p in model.named_parameters():
+        s["p." + n], s["m." + n], s["v." + n] = p.detach().clone(), opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()
+    return s
+
+
 def test_checkpoint_round_trip_through_the_optimizer_and_scaler_state():
     """Three native steps, `sync_optimizer_state()`, state dicts of model / optimizer / scaler into fresh objects,
-    `refresh(optimizer_state=True)`, three more steps: the same parameters as six uninterrupted steps (up to the table's atomic
-    order)."""
+    `refresh(optimizer_state=True)`, three more steps, against six uninterrupted steps.
+
+    What is asserted, and why (round 2 loosened this test after it failed; `tools/resume_floor.py` then measured the cause):
+    * BEFORE any resumed step, everything the step reads is restored BITWISE (`_step_state`): parameters, fp16 copies, both Adam
+      moments, step counts, loss scale, growth tracker, gradient accumulator.  A moment, copy or count that is not restored fails here.
+    * The one order-dependent sum of a step is the table gradient's fp16 atomics, and Adam with eps = 1e-15 moves an element by
+      ~lr x sign(gradient) in its first steps, so gradient noise flips whole steps: two UNINTERRUPTED six-step runs from the same
+      state differ by up to 2.5 lr in single table entries and 1.8 lr in deformation-MLP weights, 4-9 % of whose elements differ by
+      more than 1e-5 (measured: profiles/r03_resume_floor.txt).  That run-to-run floor is measured here (run B against run A)
+      and the resumed run must stay within 3x of it per parameter -- it measures 20-50x BELOW the floor, since its first three steps
+      are run A's own."""
     from dnerf_amd.network import NeRFNetwork
     from dnerf_amd.train_native import NativeTrainStep
-    sc, model, opt, scaler, target = _setup()
-    step = NativeTrainStep(model, opt, scaler, N_RAYS, "cuda", perturb=False)
-    for _ in range(3):
-        step(sc.rays_o, sc.rays_d, target, sc.time)
-    step.sync_optimizer_state()
-    saved = {"model": copy.deepcopy(model.state_dict()), "opt": copy.deepcopy(opt.state_dict()), "scaler": scaler.state_dict(),
-             "mean_count": model.mean_count, "local_step": model.local_step}
-    for _ in range(3):
-        step(sc.rays_o, sc.rays_d, target, sc.time)
-    torch.cuda.synchronize()
-    want = {k: v.detach().clone() for k, v in model.named_parameters()}
+
+    def run(n, stop_at=None):
+        sc, model, opt, scaler, target = _setup()
+        step = NativeTrainStep(model, opt, scaler, N_RAYS, "cuda", perturb=False)
+        saved = None
+        for k in range(n):
+            step(sc.rays_o, sc.rays_d, target, sc.time)
+            if k + 1 == stop_at:
+                torch.cuda.synchronize()
+                step.sync_optimizer_state()
+                saved = {"state": _step_state(step, model, opt, scaler), "model": copy.deepcopy(model.state_dict()), "opt": copy.deepcopy(opt.state_dict()),
+                         "scaler": scaler.state_dict(), "mean_count": model.mean_count, "local_step": model.local_step}
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in model.named_parameters()}, saved, (sc, target)
+
+    A, saved, (sc, target) = run(6, stop_at=3)
+    B, _, _ = run(6)
     # resume in fresh objects
     model2 = NeRFNetwork(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1).cuda().train()
     model2.load_state_dict(saved["model"])
@@ -469,16 +499,18 @@ def test_checkpoint_round_trip_through_the_optimizer_and_scaler_state():
     opt2.load_state_dict(saved["opt"])
     scaler2.load_state_dict(saved["scaler"])
     step2.refresh(optimizer_state=True)
+    torch.cuda.synchronize()
     assert step2.adam_steps.tolist() == [3.0, 3.0]
+    restored = _step_state(step2, model2, opt2, scaler2)
+    not_restored = [k for k, v in saved["state"].items() if not torch.equal(restored[k], v)]
+    assert not not_restored, not_restored
     for _ in range(3):
         step2(sc.rays_o, sc.rays_d, target, sc.time)
     torch.cuda.synchronize()
     for k, v in model2.named_parameters():
-        d = (v.detach() - want[k]).abs()
-        # (bound, not tolerance: early Adam steps move an element by ~lr in the direction of sign(grad); one whose gradient is at the
-        # noise level of the table atomics' summation order may walk the other way for the three resumed steps)
-        assert float(d.max()) <= 2.5 * 3 * (1e-2 if k == "encoder.embeddings" else 1e-3), (k, float(d.max()))
-        assert float(d.mean()) <= 0.3 * 3 * (1e-2 if k == "encoder.embeddings" else 1e-3), (k, float(d.mean()))     # ... and few do
+        floor, got = (B[k] - A[k]).abs(), (v.detach() - A[k]).abs()
+        assert float(got.max()) <= 3 * float(floor.max()) + 1e-7, (k, float(got.max()), float(floor.max()))
+        assert float(got.mean()) <= 3 * float(floor.mean()) + 1e-9, (k, float(got.mean()), float(floor.mean()))
     assert float(step2.adam_steps[0]) == 6 and int(scaler2._growth_tracker) == 6
 
 

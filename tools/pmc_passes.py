@@ -43,21 +43,30 @@ def derive(e):
             if s(n) is not None:
                 d["wave_cycles_" + label] = s(n) / wc
     if s("SQ_VALU_MFMA_BUSY_CYCLES") is not None and s("SQ_BUSY_CU_CYCLES"):
-        # SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per 32x32x16 MFMA) summed over the SIMDs; SQ_BUSY_CU_CYCLES counts quad-cycles
-        # per busy CU (MI355X_MICROARCH.md, cycle constants).  4 SIMDs x 4 cycles per quad-cycle = 16 pipe-cycles per CU quad-cycle.
+        # SQ_VALU_MFMA_BUSY_CYCLES counts cycles (exactly 32 per v_mfma_f32_32x32x16: see mfma_busy_cycles_per_mfma_inst) summed over
+        # the SIMDs.  SQ_BUSY_CU_CYCLES, calibrated on this kernel against GRBM_GUI_ACTIVE / 8 (the launch's wall cycles): its sum over
+        # a launch is <= 256 CUs x wall cycles and ~0.57 of it for launches that leave CUs idle at the tail -- i.e. it counts CYCLES per
+        # busy CU (not quad-cycles).  Matrix-pipe busy fraction while the CU is busy = MFMA busy cycles / (4 SIMDs x busy-CU cycles).
         d["mfma_busy_over_busy_cu_raw"] = s("SQ_VALU_MFMA_BUSY_CYCLES") / s("SQ_BUSY_CU_CYCLES")
-        d["mfma_pipe_busy_frac_assuming_quad_cycles_x4_simds"] = s("SQ_VALU_MFMA_BUSY_CYCLES") / (16.0 * s("SQ_BUSY_CU_CYCLES"))
+        d["mfma_pipe_busy_frac_of_busy_cu_cycles"] = s("SQ_VALU_MFMA_BUSY_CYCLES") / (4.0 * s("SQ_BUSY_CU_CYCLES"))
+        if s("GRBM_GUI_ACTIVE"):
+            # over the launches' wall time and the whole chip: 1024 SIMDs x (GRBM_GUI_ACTIVE / 8 XCDs) cycles
+            d["mfma_pipe_busy_frac_of_chip_wall_cycles"] = s("SQ_VALU_MFMA_BUSY_CYCLES") / (1024.0 * s("GRBM_GUI_ACTIVE") / 8.0)
     if s("SQ_VALU_MFMA_BUSY_CYCLES") is not None and s("SQ_INSTS_MFMA"):
         d["mfma_busy_cycles_per_mfma_inst"] = s("SQ_VALU_MFMA_BUSY_CYCLES") / s("SQ_INSTS_MFMA")
     if s("SQ_THREAD_CYCLES_VALU") is not None and s("SQ_ACTIVE_INST_VALU"):
         d["valu_lane_utilisation"] = s("SQ_THREAD_CYCLES_VALU") / (64.0 * s("SQ_ACTIVE_INST_VALU"))
-    w = s("SQ_WAVES")
+    # (SQ_WAVES may be collected in several passes: compare per-dispatch means, not sums)
+    w = e["SQ_WAVES"]["sum"] / max(e["SQ_WAVES"]["dispatches"], 1) if "SQ_WAVES" in e else None
     if w:
+        def per_dispatch(n):
+            return e[n]["sum"] / max(e[n]["dispatches"], 1)
+        d["waves_per_dispatch"] = w
         for n in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM"):
             if s(n) is not None:
-                d[n.lower().replace("sq_insts_", "") + "_per_wave"] = s(n) / w
+                d[n.lower().replace("sq_insts_", "") + "_per_wave"] = per_dispatch(n) / w
         if wc:
-            d["wave_quad_cycles_per_wave"] = wc / w
+            d["wave_quad_cycles_per_wave"] = per_dispatch("SQ_WAVE_CYCLES") / w
     if s("SQ_LDS_BANK_CONFLICT") is not None and s("SQ_LDS_IDX_ACTIVE"):
         d["lds_bank_conflict_frac"] = s("SQ_LDS_BANK_CONFLICT") / s("SQ_LDS_IDX_ACTIVE")
     if s("GRBM_GUI_ACTIVE") is not None and e["GRBM_GUI_ACTIVE"]["dispatches"]:
