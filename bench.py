@@ -51,7 +51,7 @@ def parse():
                                                             "hardware queue per context + the default stream (GPU_MAX_HW_QUEUES, if unset)")
     ap.add_argument("--cameras", type=int, default=20, help="frames of the test sequence (camera orbit + time ramp 0..1); the timed steps cycle through it")
     ap.add_argument("--static-frame", action="store_true", help="render ONE camera at t = 0.5 over and over (the round-1 workload) instead of the sequence")
-    ap.add_argument("--group-frames", type=int, default=0, help="frames rendered together by one loop (frame group); 0 = --gpus (1 on one GPU); "
+    ap.add_argument("--group-frames", type=int, default=0, help="frames rendered together by one loop (frame group); 0 = --gpus (4 on one GPU); "
                                                                  "reduced to a divisor of --steps")
     ap.add_argument("--emulate-rank-of", type=int, default=1, metavar="N",
                     help="one GPU only: render rank 0's shard of an N-way ray split of every frame (what one rank of --gpus N does, without "
@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--train-native", type=int, default=1, help="--mode train: the step as ONE native call (sdn_train_step_f16, "
                                                                  "dnerf_amd/train_native.py); 0 = the autograd step (graphed or eager)")
     ap.add_argument("--train-prefetch", type=int, default=1, help="--mode train, native step: march batch k+1 on a second stream beside step k")
+    ap.add_argument("--train-overlap", type=int, default=1, help="--mode train, native step: the optimizer's pass over the embedding table on a "
+                                                                 "second stream, beside the next step's deformation-MLP forward")
     ap.add_argument("--gather-dtype", default="f32", choices=["f32", "f16", "u8"],
                     help="--gpus N: what the per-frame all-gather moves (fp32 as rendered; fp16; or the 8-bit pixels the reference writes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -126,7 +128,7 @@ def train_mode(args):
     model.mean_count = int(model.step_counter[:2, 0].sum().item() / 2)  # what update_extra_state does (dnerf/renderer.py:550-552)
     if native:
         from dnerf_amd.train_native import NativeTrainStep
-        nstep = NativeTrainStep(model, opt, scaler, n_rays, dev, perturb=True, bg_color=1)
+        nstep = NativeTrainStep(model, opt, scaler, n_rays, dev, perturb=True, bg_color=1, overlap_table_update=bool(args.train_overlap))
         nstep.load(rays_o, rays_d, target, sc.time)
         if args.train_prefetch:
             # the next batch is marched on a second stream beside the running step (a loader knows it one step early)
@@ -155,13 +157,15 @@ def train_mode(args):
         sdn_backend.timers = timers
         step()
     sdn_backend.timers = None
+    host_dt = time.perf_counter() - t0          # the host's share: enqueueing only (the calls are asynchronous)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     gc.enable()
     summ = timers.summary()
     print(json.dumps({"metric": "dnerf training step, 4096 rays (march_rays_train + field + composite_rays_train fwd/bwd + grid backward + Adam)",
                       "value": args.steps / dt, "unit": "steps/s", "points_per_s": n_points * args.steps / dt, "rays_per_s": n_rays * args.steps / dt,
-                      "ms_per_step": dt / args.steps * 1e3, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "dtype": "f32" if args.fp32 else "f16",
+                      "ms_per_step": dt / args.steps * 1e3, "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
+                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "dtype": "f32" if args.fp32 else "f16",
                       "data": "synthetic", "config": {"workload": "BASELINE config 3", "rays": n_rays, "sampled_points_per_step": n_points,
                                                       "mean_count": model.mean_count,
                                                       "mlps": ("deform + colour MLPs on the fused-MLP kernels, density MLP in a per-sample dot2 kernel" if native else
@@ -438,7 +442,11 @@ def main():
     n_local = cam_o[0].shape[0]
     # Frame groups: F consecutive frames' shards rendered by ONE loop (per-ray time constants), so that the ~30 dependent launches
     # of a loop are paid once per F frames; default F = gpus (a rank's batch keeps the size of one full frame), 1 on one GPU.
-    want_f = args.group_frames if args.group_frames > 0 else (world if world > 1 else 1)
+    # (one GPU: 4 consecutive frames per loop -- launches of ~300 K points instead of ~100 K fill the chip's 512 workgroup slots 2.3
+    # times instead of 0.9 times: field kernel 0.25 -> 0.35 of the MFMA peak, 2 % more frames per second; sweep in profiles/r03_*)
+    want_f = args.group_frames if args.group_frames > 0 else (world if world > 1 else (4 if args.emulate_rank_of <= 1 else 1))
+    if args.group_frames == 0 and (args.field == "ops" or args.fp32 or args.loop == "host"):
+        want_f = 1            # frame groups need the device loop with the fused field
     F = max(d for d in range(1, min(want_f, 16) + 1) if K % d == 0)
     n_groups = K // F
     frame_cam = [f % n_cams for f in range(K)]
@@ -618,11 +626,13 @@ def main():
     gc.disable()
     reps, marked, excl_set = 1, [], set()
     if ploop is not None:
-        warm_s, _, _, _ = stream_of_frames(min(n_groups, max(args.contexts, args.warmup)))           # warm every context
+        stream_of_frames(min(n_groups, max(args.contexts, args.warmup)))           # warm every context
         # The driver's command times K = 20 steps: 13 ms.  The K-step stream is therefore repeated inside the timed region until it
-        # lasts >= --min-timed-s (estimated from the warm-up stream); ms_per_step = elapsed / loops rendered.
-        est = warm_s / min(n_groups, max(args.contexts, args.warmup)) * n_groups
-        reps = max(1, int(np.ceil(args.min_timed_s / max(est, 1e-6)))) if args.min_timed_s > 0 else 1
+        # lasts >= --min-timed-s: a first un-instrumented pass of the K steps gives the rate, the timed pass then renders
+        # ceil(min / rate) repetitions as ONE stream; ms_per_step = elapsed / loops rendered.
+        if args.min_timed_s > 0:
+            probe_s, _, _, _ = stream_of_frames(n_groups)
+            reps = max(1, int(np.ceil(1.15 * args.min_timed_s / max(probe_s, 1e-6))))
         if world > 1:      # every rank must render the same number of loops
             rt = torch.tensor([reps], dtype=torch.int64, device="cpu" if rehearse else dev)
             dist.all_reduce(rt, op=dist.ReduceOp.MAX)
@@ -777,39 +787,61 @@ def marcher_roofline(dloop, grp_o, grp_d, grp_t, n_groups, distinct, frame_cam, 
 
 
 def grid_gather_rate(sc, dev, n_points=196352, launches=20):
-    """Stand-alone `grid_encode` forward (k_grid_fwd, gridencoder.cu:87-245) on the fp16 table, clean run (no profiler): n_points
-    uniformly random points inside the figure's bounding box per launch, HIP events around every launch.  `achieved` is the ALGORITHMIC
-    gather rate (588 B per point: 512 B of table gathers + 12 in + 64 out -- SURVEY 8(d)) over the average launch time; the HBM-side
-    traffic under rocprofv3 --pmc is 0.29-0.50 of it (profiles/r02_grid_pmc_summary.json: the table is served by L2 / Infinity Cache)."""
+    """Stand-alone `grid_encode` forward (k_grid_fwd, gridencoder.cu:87-245) on the fp16 table, clean run (no profiler): the first
+    n_points samples the marcher emits for the frame's rays (ray order: neighbours along a ray and across neighbouring rays, what an
+    iteration of the loop hands to the encoder), HIP events around every launch.  `achieved` is the ALGORITHMIC gather rate (588 B per
+    point: 512 B of table gathers + 12 in + 64 out -- SURVEY 8(d)) over the average launch time; the HBM-side traffic under
+    rocprofv3 --pmc is 0.29-0.50 of it (profiles/r02_grid_pmc_summary.json: the table is served by L2 / Infinity Cache).  A second
+    figure uses uniformly random points of the figure's bounding box: no locality between neighbouring lanes."""
     import sdn_backend
+    import raymarching
+    m = sc.model
+    with torch.no_grad():
+        side = int(round(sc.rays_o.shape[0] ** 0.5))
+        band = slice((side // 2 - side // 20) * side, (side // 2 + side // 20) * side)     # the middle tenth of the image rows
+        ro, rd = sc.rays_o[band].contiguous(), sc.rays_d[band].contiguous()
+        nears, fars = raymarching.near_far_from_aabb(ro, rd, m.aabb_infer, m.min_near)
+        counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        xyzs, _, _, _ = raymarching.march_rays_train(ro, rd, m.bound, m.density_bitfield[32], m.cascade, m.grid_size, nears, fars,
+                                                     counter, -1, False, 128, False, 0.0, 1024)
+        total = int(counter[0].item())
+    x = xyzs[:min(n_points, total)].clone()
+    del xyzs
+    n_points = int(x.shape[0])
     g = torch.Generator(device="cpu").manual_seed(5)
     lo, hi = torch.tensor([-0.35, -0.6, -0.2]), torch.tensor([0.35, 0.6, 0.2])
-    x = (lo + (hi - lo) * torch.rand(n_points, 3, generator=g)).to(dev)
-    enc = sc.model.encoder
-    t = sdn_backend.KernelTimers()
-    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-        enc(x, bound=sc.model.bound)
-        torch.cuda.synchronize()
-        sdn_backend.timers = t
-        for _ in range(launches):
-            enc(x, bound=sc.model.bound)
-        sdn_backend.timers = None
-    torch.cuda.synchronize()
-    summ = t.summary()
-    name = next((k for k in summ if k.startswith("grid_encode_fwd")), None)
+    xr = (lo + (hi - lo) * torch.rand(n_points, 3, generator=g)).to(dev)
+    enc = m.encoder
+
+    def timed(pts):
+        t = sdn_backend.KernelTimers()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            enc(pts, bound=m.bound)
+            torch.cuda.synchronize()
+            sdn_backend.timers = t
+            for _ in range(launches):
+                enc(pts, bound=m.bound)
+            sdn_backend.timers = None
+        summ = t.summary()
+        name = next((k for k in summ if k.startswith("grid_encode_fwd")), None)
+        return name, (summ[name]["avg_ms"] if name else None)
+    name, ms = timed(x)
+    _, ms_r = timed(xr)
     if name is None:
         return None
-    ms = summ[name]["avg_ms"]
     achieved = GRID_BYTES_PER_POINT["f16"] * n_points / (ms * 1e-3) / 1e9
     out = {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "bytes_per_point_algorithmic": GRID_BYTES_PER_POINT["f16"], "points_per_launch": n_points, "avg_launch_ms": ms, "launches": launches,
-           "note": "algorithmic gather rate of the stand-alone op, clean run; counter bytes are static (separate rocprofv3 --pmc passes)"}
+           "uniformly_random_points": {"avg_launch_ms": ms_r, "achieved": GRID_BYTES_PER_POINT["f16"] * n_points / (ms_r * 1e-3) / 1e9,
+                                       "frac": GRID_BYTES_PER_POINT["f16"] * n_points / (ms_r * 1e-3) / 1e9 / HBM_PEAK_GBS},
+           "note": "algorithmic gather rate of the stand-alone op on a frame's own samples, clean run; counter bytes are static (separate rocprofv3 --pmc passes)"}
     pmc = os.path.join(ROOT, "profiles", "r02_grid_pmc_summary.json")
     if os.path.exists(pmc):
         try:
-            k = json.load(open(pmc))["kernels"]["k_grid_fwd"]["hbm"]
-            out["traffic_static"] = {"hbm_bytes_per_point_raw": k.get("hbm_bytes_per_point_raw"), "hbm_bytes_per_point_fetch_x2": k.get("hbm_bytes_per_point_fetch_x2"),
-                                     "source": "profiles/r02_grid_pmc_summary.json"}
+            k = json.load(open(pmc))["kernels"]["k_grid_fwd"]
+            pts = k["FETCH_SIZE"]["dispatches"] * 196352.0
+            out["traffic_static"] = {"hbm_bytes_per_point_raw": k["hbm"]["hbm_bytes_raw"] / pts, "hbm_bytes_per_point_fetch_x2": k["hbm"]["hbm_bytes_fetch_x2"] / pts,
+                                     "source": "profiles/r02_grid_pmc_summary.json (FETCH_SIZE / WRITE_SIZE passes, 196 352 points per launch)"}
         except Exception:
             pass
     return out
@@ -819,9 +851,9 @@ def exclusive_frames(k):
     """Frames of a k-frame stream that are rendered with nothing else in flight so that their launch durations are the kernel's
     own: the LAST one (the pipeline is draining there anyway: holding it back until its predecessors are done costs the stream a
     fraction of one loop's latency; an exclusive FIRST frame -- round 1 and the start of round 2 -- delays every other context by a
-    whole loop, 7 % of a 20-frame stream).  A long stream affords three more (quarter points: each holds the pipeline back for
+    whole loop, 7 % of a 20-frame stream).  A stream of >= 64 loops affords three more (quarter points: each holds the pipeline back for
     about one loop latency, ~1 % of 384 frames together), which makes the figure an average over four different frames."""
-    return {k - 1} | ({k // 4, k // 2, 3 * k // 4} if k >= 128 else set())
+    return {k - 1} | ({k // 4, k // 2, 3 * k // 4} if k >= 64 else set())
 
 
 def roofline(timers, fp16, points_exclusive, points_overlapped=0):

@@ -497,6 +497,13 @@ typedef struct SdnTrainStep {
                                      * caller that knows the next batch early runs phase 1 for batch k+1 on a second stream beside
                                      * phase 2 of batch k (the optimizer pass and the marcher do not compete for the same unit) */
     int32_t sample_set;             /* 0 / 1: which of the workspace's two sample buffers */
+    /* Optional overlap of the optimizer's pass over the embedding table (12.2 M entries, 30 B each: 85 % of the pass, HBM-bound) with
+     * the NEXT step's deformation-MLP forward, which does not touch the table: with table_stream set (a second hipStream_t), that
+     * part of the pass is enqueued there behind `table_ready` (hipEvent_t, recorded on `stream` after the optimizer prologue) and
+     * `table_done` (hipEvent_t) is recorded behind it; the next sdn_train_step_f16 / sdn_train_refresh makes `stream` wait for
+     * table_done before its first access to the table.  A caller that touches the table, its moments or its EMA shadow itself must
+     * wait for table_done first (hipStreamWaitEvent / sdn_train_flush).  All three NULL: everything on `stream`, as before. */
+    void *table_stream, *table_ready, *table_done;
 } SdnTrainStep;
 
 /* Byte offsets into the workspace of what a caller or a test may want to look at.  fp16 "flat" networks are laid out as the fused
@@ -516,6 +523,8 @@ int sdn_train_layout(uint32_t N, uint32_t M, uint32_t max_steps, const int32_t *
 /* fp16 copies of all parameters from the fp32 masters; clears the gradient accumulator of the table. */
 int sdn_train_refresh(const SdnTrainStep *s, void *stream);
 int sdn_train_step_f16(const SdnTrainStep *s, void *stream);
+/* Makes `stream` wait for the table pass a previous step left on table_stream (no-op without one). */
+int sdn_train_flush(const SdnTrainStep *s, void *stream);
 
 #ifdef __cplusplus
 }

@@ -31,11 +31,19 @@
 //   * optional live-sample index list: only slots that hold a sample are evaluated (the reference evaluates
 //     the network on every padded slot).
 #include <math.h>
+#include <type_traits>
+#include <stdlib.h>
 
 #include "sdn_common.h"
 #include "grid_common.h"
 #include "sh_eval.h"
 
+
+// Staggered half-workgroups in the hidden layers (waves 4-7 half a layer behind waves 0-3): built and bit-identical, measured neutral
+// to -3 % (profiles/r03_rejected_field_stagger.txt) -- compiled out by default; `make -C seald-nerf_amd/csrc stagger` builds the variant.
+#ifndef SDN_FIELD_STAGGER
+#define SDN_FIELD_STAGGER 0
+#endif
 
 namespace {
 
@@ -310,12 +318,87 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     // needs the port for 8 of its 32 cycles: with the matrix phases at higher priority the other workgroup's VALU work
     // fills the remaining 24 and the two phases overlap.
     __builtin_amdgcn_s_setprio(2);
+#if SDN_FIELD_STAGGER
+    // ---- staggered half-workgroups (cdna_hip_programming.md / MI355X_MICROARCH.md "Two waves per SIMD", item 9) ---------------------------
+    // The eight waves of a workgroup used to pass every layer boundary together: accumulator -> operand conversion (~100 VALU
+    // instructions), stage barrier, then 32 MFMAs -- the matrix pipe idled through every conversion, and the co-resident workgroup ran
+    // the same phases at the same time more often than not (in-kernel stamps of round 2: 3.6 K cycles per hidden layer where the
+    // pipe needs 2.0 K).  Now waves 4-7 (a SIMD's second wave of this workgroup) run HALF A LAYER behind waves 0-3: a hidden layer is
+    // two units of 16 MFMAs (k-steps 0-3 / 4-7) with one barrier each, and while one half-workgroup converts and starts a layer the
+    // other issues the second half of the previous layer's MFMAs.  Waves 4-7 simply pass one barrier more before layer 0 and one
+    // less before the tail (different points, no data dependence -- only the two 32 KiB weight buffers are shared):
+    //   global phase p:   waves 0-3 run unit p (p = -1: layer 0, 0..11: hidden units, 12: tail), waves 4-7 unit p - 1.
+    //   stage s (2..7) refills buffer s & 1 in phase 2 s - 3: its previous content, stage s - 2, was last read by waves 4-7 in phase
+    //   2 s - 4, and waves 0-3 first read stage s in phase 2 s - 2, behind every wave's vmcnt(0) + the barrier of that phase.
+    const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4u;
+    stage_wait_and_sync();            // barrier of phase -1: D0 and D1 are resident
+    if (late) stage_wait_and_sync();  // barrier of phase 0 (waves 0-3 arrive at it after their layer 0)
+#else
     stage_wait_and_sync();  // D0 and D1 are resident
+#endif
     #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
         #pragma unroll
         for (int mt = 0; mt < 4; mt++) acc[mt] = mfma(lds_frag(s_w0, mt * 4 + ks, lane), bf[ks], acc[mt]);
     }
+#if SDN_FIELD_STAGGER
+    // One unit: half a hidden layer (k-steps 4 HALF .. 4 HALF + 3), fragments from `cur`; refill (wave-uniform, run time: it depends
+    // on the half-workgroup): this wave's four 1-KiB pieces of stage `stage` go to `other`, issued together in front of the MFMAs
+    // under ONE scalar branch (a branch per piece between the MFMAs cut the chain into scheduling regions and spilled registers).
+    auto unit = [&](auto half_c, bool refill, const unsigned char *cur, unsigned char *other, int stage) __attribute__((always_inline)) {
+        constexpr int half = decltype(half_c)::value;
+        stage_wait_and_sync();
+        if (refill) {
+            // (stage 7, the tail, follows D6 in the packed buffer: one formula for every stage)
+            const unsigned char *__restrict__ refill_src = P.weights + (size_t)(kBlkD1 + (stage - 1) * 32) * 1024;
+            #pragma unroll
+            for (int k = 0; k < kStageBytes / 1024 / kWaves; k++) stage_piece(refill_src, other, k, wave, lane);
+        }
+        if constexpr (half == 0) {
+            #pragma unroll
+            for (int t = 0; t < 4; t++) acc_to_frags<true>(acc[t], bf[2 * t], bf[2 * t + 1]);
+            __builtin_amdgcn_sched_barrier(0);     // (the fragment read-ahead must not be hoisted over the conversion: it spills at 128 VGPRs)
+        }
+        half8 ring[LA];
+        #pragma unroll
+        for (int j = 0; j < LA; j++) ring[j] = lds_frag(cur, (j & 3) * 8 + 4 * half + (j >> 2), lane);
+        #pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int ks = 4 * half + (i >> 2), mt = i & 3;
+            const half8 a = ring[i % LA];
+            if (i + LA < 16) ring[i % LA] = lds_frag(cur, ((i + LA) & 3) * 8 + 4 * half + ((i + LA) >> 2), lane);
+            if (ks == 0) {
+                f32x16 z;
+                #pragma unroll
+                for (int r = 0; r < 16; r++) z[r] = 0.0f;
+                acc[mt] = mfma(a, bf[0], z);
+            } else {
+                acc[mt] = mfma(a, bf[ks], acc[mt]);
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, LA, 0);
+        #pragma unroll
+        for (int i = 0; i < 16 - LA; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, LA, 0);
+    };
+    static_assert(LA <= 16 && kBlkD7 == kBlkD1 + 6 * 32, "look-ahead is per unit of 16 MFMAs; the tail stage follows D6");
+    constexpr std::integral_constant<int, 0> H1{};
+    constexpr std::integral_constant<int, 1> H2{};
+    #pragma unroll 1
+    for (int b2 = 0; b2 < 3; b2++) {      // layers 2 b2 + 1 (stage in s_w1) and 2 b2 + 2 (stage in s_w0): units 4 b2 .. 4 b2 + 3
+        // waves 0-3 refill in their odd units (stage (u + 3) / 2), waves 4-7 -- one phase behind -- in their even units (stage (u + 4) / 2)
+        unit(H1, late, s_w1, s_w0, 2 * b2 + 2);
+        unit(H2, !late, s_w1, s_w0, 2 * b2 + 2);
+        unit(H1, late, s_w0, s_w1, 2 * b2 + 3);
+        unit(H2, !late, s_w0, s_w1, 2 * b2 + 3);
+    }
+    #pragma unroll
+    for (int t = 0; t < 4; t++) acc_to_frags<true>(acc[t], bf[2 * t], bf[2 * t + 1]);
+    if (!late) stage_wait_and_sync();   // barrier of phase 12: the tail stage (D7 | S0 | S1 | C0 | C1 | C2) is resident in buffer 1 (waves 4-7 passed it before their last unit)
+#else
     // ---------------- deform layers 1..6 (128 -> 128, ReLU): stage l+1 uses buffer (l+1)&1 ----------------
     // One hidden layer: fragments from `cur`, refill of `other` (static arrays: see the comment at their declaration).
     auto hidden_layer = [&](int l, const unsigned char *cur, unsigned char *other) __attribute__((always_inline)) {
@@ -365,6 +448,7 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     #pragma unroll
     for (int t = 0; t < 4; t++) acc_to_frags<true>(acc[t], bf[2 * t], bf[2 * t + 1]);
     stage_wait_and_sync();  // tail stage (D7 | S0 | S1 | C0 | C1 | C2) resident in buffer 1
+#endif
     const unsigned char *tail = s_w1;
     constexpr int tD7 = 0, tS0 = kBlkS0 - kBlkD7, tS1 = kBlkS1 - kBlkD7, tC0 = kBlkC0 - kBlkD7, tC1 = kBlkC1 - kBlkD7, tC2 = kBlkC2 - kBlkD7;
 
@@ -631,7 +715,16 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
     // latency variant (one workgroup per CU, deep LDS read-ahead) while the launch is at most one workgroup per CU.  (Measured,
     // profiles/r02_field_latency_rounds.txt: running 2+ ROUNDS of lone workgroups instead of one round of co-resident pairs is
     // slower -- 57.6 vs 51.9 us at 126 976 points.)
-    const bool small = busy <= (uint32_t)cus;
+    bool small = busy <= (uint32_t)cus;
+    {   // SDN_FIELD_VARIANT=throughput / latency pins the variant (measurements only)
+        static int pin = -1;
+        if (pin < 0) {
+            const char *e = getenv("SDN_FIELD_VARIANT");
+            pin = !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'l' ? 2 : 0));
+        }
+        if (pin == 1) small = false;
+        if (pin == 2) small = true;
+    }
     if (table_is_padded(offsets_host)) {
         if (small) hipLaunchKernelGGL((k_field_f16<2, 8, false, true>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
         else hipLaunchKernelGGL((k_field_f16<4, 2, false, true>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);

@@ -144,9 +144,13 @@ __global__ void __launch_bounds__(256) k_train_rays(float *__restrict__ noises, 
 
 // freq(x, 10) ++ freq(t, 6) as the fp16 input rows of the deformation MLP (freqencoder.cu:30-58's formula; the autocast cast of
 // F.linear's input).  One thread per (sample, 16th of a row).
-__global__ void __launch_bounds__(256) k_train_encode(const float *__restrict__ xyzs, uint32_t M, float time, _Float16 *__restrict__ enc, Hyper *hyper) {
+__global__ void __launch_bounds__(256) k_train_encode(const float *__restrict__ xyzs, uint32_t M, float time, _Float16 *__restrict__ enc, Hyper *hyper,
+                                                      uint4 *__restrict__ zero_fill, uint32_t zero_n16) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) hyper->found_inf = 0.0f;       // first kernel of a step's own phase: the non-finite flag of this step's gradients
+    // the gradient rows the compositing backward fills only for the samples rays own (dcol_out .. dh0: 34 B per sample, i.e. at most
+    // three 16-byte words per 16 threads of a sample) are cleared here instead of by a fill of their own
+    if (t < zero_n16) zero_fill[t] = make_uint4(0u, 0u, 0u, 0u);
     const uint32_t b = t >> 4, j = t & 15u;
     if (b >= M) return;
     _Float16 *row = enc + (size_t)b * kDefIn;
@@ -392,6 +396,9 @@ __global__ void __launch_bounds__(256) k_train_composite_fwd(CompositeArgs P) {
 }
 
 // loss = mean over rays of the mean over channels of (pred - gt)^2 (utils.py:85, :125): a deterministic tree sum in ONE workgroup
+// (folding it into the last block of the compositing launch, or the optimizer prologue into the last block of the non-finite check,
+// was measured and reverted: the agent-scope release every block then needs before its ticket costs ~1.7 us per block, 5 -> 26 us
+// and 12 -> 19 us for the two launches)
 __global__ void __launch_bounds__(1024) k_train_loss(const float *__restrict__ sq_err, uint32_t N, float *__restrict__ loss_out) {
     __shared__ float s_part[16];
     float acc = 0.0f;
@@ -522,6 +529,17 @@ __global__ void __launch_bounds__(256) k_train_deform_grad(const _Float16 *__res
 // ---- optimizer ------------------------------------------------------------------------------------------------------------------
 struct CheckArgs { const _Float16 *g[5]; uint32_t n8[5]; uint32_t count; Hyper *hyper; uint32_t col_seg; };
 
+struct Prologue {
+    Hyper *hyper;
+    float *steps, *scale;
+    int32_t *tracker;
+    double beta1, beta2, lr_table, lr_net;
+    float growth, backoff;
+    uint32_t interval;
+    int deform_active;
+    float divisor;
+};
+
 // GradScaler's non-finite check over every gradient of the step (amp's _amp_foreach_non_finite_check_and_unscale_)
 __global__ void __launch_bounds__(256) k_train_check(CheckArgs A) {
     bool bad = false;
@@ -540,17 +558,6 @@ __global__ void __launch_bounds__(256) k_train_check(CheckArgs A) {
     }
     if (bad) A.hyper->found_inf = 1.0f;
 }
-
-struct Prologue {
-    Hyper *hyper;
-    float *steps, *scale;
-    int32_t *tracker;
-    double beta1, beta2, lr_table, lr_net;
-    float growth, backoff;
-    uint32_t interval;
-    int deform_active;
-    float divisor;
-};
 
 // One thread: the skip decision, bias corrections in double as torch's Adam computes them on the host (adam.py _single_tensor_adam:
 // 1 - beta ** step, lr / bias_correction1, bias_correction2 ** 0.5), and amp_update_scale (AmpKernels.cu) for the NEXT step.
@@ -703,9 +710,28 @@ uint32_t build_segments(const SdnTrainStep *s, const Layout &L, AdamArgs &A) {
     return blk;
 }
 
+// Adam over the segments [i0, i1) of a full segment list (workgroup ranges re-based)
+void launch_adam(const AdamArgs &all, uint32_t i0, uint32_t i1, hipStream_t st) {
+    AdamArgs A = all;
+    uint32_t blk = 0;
+    for (uint32_t i = i0; i < i1; i++) {
+        A.seg[i - i0] = all.seg[i];
+        A.seg[i - i0].blk_begin = blk;
+        blk += sdn_div_up(all.seg[i].n, 1024u);
+    }
+    A.nseg = i1 - i0;
+    hipLaunchKernelGGL(k_train_adam, dim3(blk), dim3(256), 0, st, A);
+}
+
+int table_wait(const SdnTrainStep *s, hipStream_t st) {
+    if (s->table_stream && s->table_done && hipStreamWaitEvent(st, (hipEvent_t)s->table_done, 0) != hipSuccess) return sdn_launch_status();
+    return 0;
+}
+
 bool step_ok(const SdnTrainStep *s) {
     if (!s || !s->workspace || ((uintptr_t)s->workspace & 255u)) return false;
     if (s->mode < 0 || s->mode > 2) return false;
+    if ((s->table_stream != nullptr) != (s->table_ready != nullptr) || (s->table_stream != nullptr) != (s->table_done != nullptr)) return false;
     if (s->phase < 0 || s->phase > 2 || (s->mode == 2 && s->phase != 0)) return false;
     if (s->mode != 2 && s->phase != 2 && (!s->rays_o || !s->rays_d || !s->bitfield || !s->aabb || !s->counter)) return false;
     if (s->mode != 2 && s->phase != 1 && (!s->target || !s->loss_out)) return false;
@@ -748,6 +774,7 @@ int sdn_train_refresh(const SdnTrainStep *s, void *stream) {
     if (!s || !s->workspace || ((uintptr_t)s->workspace & 255u)) return SDN_E_BADARG;
     for (int i = 0; i < SDN_TRAIN_N_PARAMS; i++) if (!s->params[i].param) return SDN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    if (int rc = table_wait(s, st)) return rc;
     const Layout L = make_layout(s->N, s->M, s->max_steps, (uint64_t)s->grid_offsets[kLevels] * 2);
     unsigned char *ws = (unsigned char *)s->workspace;
     // zero padding of the flat networks, and the table's gradient accumulator
@@ -758,6 +785,11 @@ int sdn_train_refresh(const SdnTrainStep *s, void *stream) {
     const uint32_t blocks = build_segments(s, L, A);
     hipLaunchKernelGGL(k_train_copy16, dim3(blocks), dim3(256), 0, st, A);
     return sdn_launch_status();
+}
+
+int sdn_train_flush(const SdnTrainStep *s, void *stream) {
+    if (!s) return SDN_E_BADARG;
+    return table_wait(s, (hipStream_t)stream);
 }
 
 int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
@@ -788,8 +820,13 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     }
     if (s->phase == 1) return sdn_launch_status();
     if (s->mode != 2) {
-    if (hipMemsetAsync(ws + L.dcol_out, 0, (L.dh0 - L.dcol_out) + (uint64_t)M * 2, st) != hipSuccess) return sdn_launch_status();
-    if (s->mode == 1 && hipMemsetAsync(ws + L.g_table, 0, (uint64_t)s->grid_offsets[kLevels] * 4, st) != hipSuccess) return sdn_launch_status();
+    // (dcol_out .. dh0 are cleared by k_train_encode below: both buffers are padded to 256 bytes, so rounding the range up to 16 is safe)
+    const uint32_t zero_n16 = (uint32_t)(((L.dh0 - L.dcol_out) + (uint64_t)M * 2 + 15u) / 16u);
+    static_assert(sizeof(uint4) == 16, "");
+    if (s->mode == 1) {
+        SDN_TRY(table_wait(s, st));
+        if (hipMemsetAsync(ws + L.g_table, 0, (uint64_t)s->grid_offsets[kLevels] * 4, st) != hipSuccess) return sdn_launch_status();
+    }
 
     // ---- this step's packed weights (both directions of both fused MLPs, one launch) ------------------------------------------------
     const sdn_ffh::PackJob packs[4] = {{ws + L.w_deform, ws + L.pk_def_f, kDefIn, kDefW, kDefL, 0, 1}, {ws + L.w_deform, ws + L.pk_def_b, kDefIn, kDefW, kDefL, 1, 0},
@@ -797,9 +834,12 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     SDN_TRY(sdn_ffh::pack_many(packs, 4, st));
 
     // ---- forward (network.py:123-169) ---------------------------------------------------------------------------------------------
-    hipLaunchKernelGGL(k_train_encode, dim3(sdn_div_up(M * 16u, 256u)), dim3(256), 0, st, xyzs, M, s->time, H(L.enc_in), hyper);
+    if (zero_n16 > M * 16u) return SDN_E_BADARG;     // (34 B per sample + padding: never more than one word per thread)
+    hipLaunchKernelGGL(k_train_encode, dim3(sdn_div_up(M * 16u, 256u)), dim3(256), 0, st, xyzs, M, s->time, H(L.enc_in), hyper,
+                       (uint4 *)(ws + L.dcol_out), zero_n16);
     SDN_TRY(sdn_ffh::forward_packed(H(L.enc_in), ws + L.pk_def_f, M, kDefIn, kDefW, kDefL, ACT_RELU, H(L.def_hidden), H(L.def_out), st));
     hipLaunchKernelGGL(k_train_xdef, dim3(sdn_div_up(M * 3u, 256u)), dim3(256), 0, st, xyzs, H(L.def_out), M, zero_deform, s->bound, F(L.xdef));
+    SDN_TRY(table_wait(s, st));       // the previous step's pass over the table (fp16 copy, gradient accumulator), if it ran on table_stream
     SDN_TRY(sdn_grid_encode_forward(F(L.xdef), ws + L.w_table, s->grid_offsets, ws + L.grid_out, M, 3, 2, kLevels, s->grid_S, s->grid_H,
                                     no_deform_grad ? nullptr : ws + L.dy_dx, 1, 0, 0, SDN_F16, st));
     const SigmaFwd sf{H(L.grid_out), H(L.w_sigma0), H(L.w_sigma1), dirs, H(L.enc_rm), H(L.h1), H(L.hout), H(L.col_in), F(L.sigmas), M, s->density_scale};
@@ -842,9 +882,9 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     ck.g[3] = H(L.g_color); ck.n8[3] = kColFlat / 8; ck.col_seg = 3;
     ck.count = 4;
     if (!freeze_deform) { ck.g[4] = H(L.g_deform); ck.n8[4] = kDefFlat / 8; ck.count = 5; }
-    hipLaunchKernelGGL(k_train_check, dim3(1024), dim3(256), 0, st, ck);
     const Prologue pr{hyper, s->adam_steps, s->loss_scale, s->growth_tracker, s->beta1, s->beta2, s->lr_table, s->lr_net, s->growth_factor, s->backoff_factor,
                       s->growth_interval, !freeze_deform, s->grad_divisor > 0.0f ? s->grad_divisor : 1.0f};
+    hipLaunchKernelGGL(k_train_check, dim3(1024), dim3(256), 0, st, ck);
     hipLaunchKernelGGL(k_train_prologue, dim3(1), dim3(1), 0, st, pr);
     AdamArgs A{};
     const uint32_t blocks = build_segments(s, L, A);
@@ -852,7 +892,18 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     A.hyper = hyper;
     A.one_minus_b1 = (float)(1.0 - s->beta1); A.b2 = (float)s->beta2; A.one_minus_b2 = (float)(1.0 - s->beta2); A.eps = (float)s->eps;
     A.ema_keep = 1.0f - s->ema_decay;
-    hipLaunchKernelGGL(k_train_adam, dim3(blocks), dim3(256), 0, st, A);
+    (void)blocks;
+    if (s->table_stream) {
+        if (s->mode == 2) SDN_TRY(table_wait(s, st));           // (optimizer-only call: nothing above waited)
+        hipStream_t ts = (hipStream_t)s->table_stream;
+        if (hipEventRecord((hipEvent_t)s->table_ready, st) != hipSuccess || hipStreamWaitEvent(ts, (hipEvent_t)s->table_ready, 0) != hipSuccess)
+            return sdn_launch_status();
+        launch_adam(A, 0, 1, ts);                                // the table: 366 MB of traffic, beside whatever `stream` runs next
+        if (hipEventRecord((hipEvent_t)s->table_done, ts) != hipSuccess) return sdn_launch_status();
+        launch_adam(A, 1, SDN_TRAIN_N_PARAMS, st);               // the MLPs (the next step's first kernels read their fp16 copies)
+    } else {
+        launch_adam(A, 0, SDN_TRAIN_N_PARAMS, st);
+    }
     #undef SDN_TRY
     return sdn_launch_status();
 }

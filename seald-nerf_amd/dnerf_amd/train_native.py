@@ -30,11 +30,15 @@ def _budget(mean_count, align=128):
 
 class NativeTrainStep:
     def __init__(self, model, optimizer, scaler, n_rays, device, ema_decay=None, perturb=True, bg_color=1, dt_gamma=0.0, max_steps=1024,
-                 T_thresh=1e-4, seed=0, grad_sync=None, train_deform=True):
+                 T_thresh=1e-4, seed=0, grad_sync=None, train_deform=True, overlap_table_update=False):
         """optimizer: a torch.optim.Adam over `model.get_params(lr, lr_net)` (or merged groups); scaler: torch.amp.GradScaler.
         ema_decay: None, or the decay of a torch_ema-style shadow kept in `self.ema_shadow` (nerf/utils.py:906).
         train_deform=False: the deformation MLP is evaluated but not trained (SealD-NeRF's edit training, SealDNeRF/utils.py:692-694;
         the optimizer then need not hold its parameters).
+        overlap_table_update: the optimizer's pass over the embedding table (366 MB of traffic, most of the pass) runs on a second
+        stream beside the NEXT step's deformation-MLP forward, which does not read the table (~35 us of a 0.27 ms step).  The next
+        step / `refresh()` / `flush()` order the caller's stream behind it; code that reads or writes `encoder.embeddings`, its Adam
+        moments or its EMA shadow on its own right after a step must call `flush()` first (a device-wide synchronize also does).
         grad_sync: a `dnerf_amd.dist.GradSync` for data-parallel training -- every rank runs forward + backward on its own batch, the
         fp16 gradient buffers of the step (24 MB table gradient + one 250 KB block with every MLP's) are all-reduced over RCCL, and
         the optimizer pass divides by the world size on top of the loss scale."""
@@ -102,6 +106,11 @@ class NativeTrainStep:
         self._cull_cache, self._cull_epoch = {}, None
         self._set, self._pending, self._side, self._before_step = 0, None, None, None
         self.grad_sync, self.train_deform = grad_sync, bool(train_deform)
+        self._table_side = None
+        if overlap_table_update:
+            self._table_side = (torch.cuda.Stream(device=self.device), torch.cuda.Event(), torch.cuda.Event())
+            for e in self._table_side[1:]:
+                e.record()                                # materialises the hipEvent_t handles; the native step re-records them
         self.noises = None          # optional [n_rays] f32 device tensor: the per-ray offsets of the next steps (instead of the generator)
         self._time_cache = (None, None, None)       # (tensor, _version, value) of the last `time` tensor read back
         self._lr_of = {}
@@ -146,6 +155,10 @@ class NativeTrainStep:
         r.growth_factor, r.backoff_factor = float(self.scaler.get_growth_factor()), float(self.scaler.get_backoff_factor())
         r.growth_interval = int(self.scaler.get_growth_interval())
         r.loss_out, r.image_out, r.workspace = self.loss.data_ptr(), self.image.data_ptr(), self._ws_ptr
+        if self._table_side is not None:
+            r.table_stream, r.table_ready, r.table_done = (self._table_side[0].cuda_stream, self._table_side[1].cuda_event, self._table_side[2].cuda_event)
+        if self._rec is not None:
+            self.flush()                                  # the old record's table pass may still be in flight: order this stream behind it
         self._rec, self._M = r, M
         self.refresh()
 
@@ -167,6 +180,12 @@ class NativeTrainStep:
             self._cull_cache[t_idx] = hit
         return hit.data_ptr()
 
+    def flush(self):
+        """Orders torch's current stream behind the table pass a previous step left on the second stream (overlap_table_update); a
+        no-op otherwise.  Call it before touching `encoder.embeddings`, its optimizer state or its EMA shadow outside the step."""
+        if self._table_side is not None and self._rec is not None:
+            _sdn.check(_sdn.lib.sdn_train_flush(ctypes.byref(self._rec), _sdn.stream()), "train_flush")
+
     def invalidate_cull_grids(self):
         """Forget the cached skip grids (the occupancy bitfield was rewritten by something this object cannot see)."""
         self._cull_cache, self._cull_epoch = {}, None
@@ -177,6 +196,7 @@ class NativeTrainStep:
         optimizer_state=True: also re-read the optimizer's state -- `optimizer.load_state_dict()` REPLACES the moment tensors and
         carries the step counts -- and the scaler's scale tensors (`scaler.load_state_dict()` replaces them too)."""
         self.invalidate_cull_grids()
+        self.flush()
         if optimizer_state:
             for i, p in enumerate(self.params):
                 if not self._trained[i]:
@@ -348,6 +368,7 @@ class NativeTrainStep:
     def sync_optimizer_state(self):
         """Writes the step counts the device keeps into the optimizer's per-parameter `step` entries (one host read-back): call before
         `optimizer.state_dict()` / an eager `optimizer.step()`."""
+        self.flush()
         main, deform = [float(v) for v in self.adam_steps.tolist()]
         for i, p in enumerate(self.params):
             if self._trained[i]:

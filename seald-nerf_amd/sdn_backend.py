@@ -108,7 +108,8 @@ class SdnTrainStep(ctypes.Structure):
                 + [(n, ctypes.c_double) for n in ("lr_table", "lr_net", "beta1", "beta2", "eps")]
                 + [("adam_steps", _vp), ("loss_scale", _vp), ("growth_tracker", _vp), ("growth_factor", _f32), ("backoff_factor", _f32),
                    ("growth_interval", _u32), ("ema_decay", _f32), ("loss_out", _vp), ("image_out", _vp), ("workspace", _vp),
-                   ("mode", ctypes.c_int32), ("keep_deform", ctypes.c_int32), ("grad_divisor", _f32), ("deform_frozen", ctypes.c_int32), ("phase", ctypes.c_int32), ("sample_set", ctypes.c_int32)])
+                   ("mode", ctypes.c_int32), ("keep_deform", ctypes.c_int32), ("grad_divisor", _f32), ("deform_frozen", ctypes.c_int32), ("phase", ctypes.c_int32), ("sample_set", ctypes.c_int32),
+                   ("table_stream", _vp), ("table_ready", _vp), ("table_done", _vp)])
 
 
 class SdnTrainLayout(ctypes.Structure):
@@ -122,6 +123,7 @@ PROTOTYPES.update({
     "sdn_train_layout": [_u32, _u32, _u32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(SdnTrainLayout)],
     "sdn_train_refresh": [ctypes.POINTER(SdnTrainStep), _vp],
     "sdn_train_step_f16": [ctypes.POINTER(SdnTrainStep), _vp],
+    "sdn_train_flush": [ctypes.POINTER(SdnTrainStep), _vp],
 })
 
 PROTOTYPES_U32 = {

@@ -48,7 +48,8 @@ def test_hip_ops_loop_fp32_reproduces_reference_run_cuda(model_bits, case, kw):
 @pytest.mark.parametrize("case,kw", CASES)
 def test_native_device_loop_f16_reproduces_reference_run_cuda(model_bits, case, kw):
     """The product path: fused MFMA field kernel (-O numerics) in the device-driven loop.  fp16 network => the per-iteration
-    survivor counts may differ by early-termination ties; image / depth within fp16 distance of the reference's fp32 render."""
+    survivor counts may differ by early-termination ties; image / depth within the distribution bars below of the reference's fp32
+    render (max 2e-3, p99.9 5e-4, p99 2.5e-4 for the image)."""
     from dnerf_amd.fused import FusedField
     from dnerf_amd.renderer import DeviceLoop
     fx = load("infer")
@@ -61,9 +62,16 @@ def test_native_device_loop_f16_reproduces_reference_run_cuda(model_bits, case, 
     assert tuple(tr[0]) == tuple(ref_tr[0]) and abs(len(tr) - len(ref_tr)) <= 1
     assert np.abs(tr[:len(ref_tr), 0] - ref_tr[:len(tr), 0]).max() <= 3
     img = out["image"].cpu().numpy()
-    assert np.abs(img - fx[f"{case}_image"]).max() < 2e-2 and np.abs(img - fx[f"{case}_image"]).mean() < 2e-4
+    # -O (fp16 network) against the reference's fp32 render, stated as a distribution (a single `max <` hides it).  Measured over the four
+    # fixture frames (round 3): image max 1.8e-4 .. 5.4e-4, p99.9 1.3e-4 .. 1.6e-4, p99 8e-5, mean 3e-6, NO pixel above 1e-3; depth max
+    # 2.4e-4 .. 1.1e-3, p99.9 2.5e-4, one ray of 3984 above 1e-3: the product path is within ~2-5x of the fp32 path's 1e-4 bar at the
+    # maximum and inside it at p99.
+    from tests_support import assert_dist
+    st = [assert_dist(img, fx[f"{case}_image"], "image, -O device loop vs reference run_cuda (fp32)", max=2e-3, p999=5e-4, p99=2.5e-4, mean=1e-5, frac_above_1e3=5e-4)]
     dep, miss = out["depth"].cpu().numpy(), np.isnan(fx[f"{case}_depth"])
-    assert np.array_equal(miss, np.isnan(dep)) and np.abs(dep[~miss] - fx[f"{case}_depth"][~miss]).max() < 2e-2
+    assert np.array_equal(miss, np.isnan(dep))
+    st.append(assert_dist(dep[~miss], fx[f"{case}_depth"][~miss], "depth, -O device loop vs reference run_cuda (fp32)", max=4e-3, p999=8e-4, frac_above_1e3=2e-3))
+    print(case, "distance to the reference fixture:", st)
 
 
 @pytest.mark.parametrize("t", [0.0, 0.5])
@@ -121,7 +129,9 @@ def test_seald_teacher_native_loop_reproduces_reference(model_bits):
         fast = loop.render(sc.rays_o, sc.rays_d, sc.time)
         torch.cuda.synchronize()
         img = fast["image"].cpu().numpy()
-        assert np.abs(img - fx["mapped_image"]).max() < 2e-2 and np.abs(img - fx["mapped_image"]).mean() < 2e-4
+        from tests_support import assert_dist
+        print("seald mapped frame, -O device loop vs reference teacher (fp32):",
+              assert_dist(img, fx["mapped_image"], "mapped image, -O device loop vs SealDNeRF teacher run_cuda (fp32)", max=4e-3, p999=1e-3, mean=2e-5, frac_above_1e3=2e-3))
         assert abs(len(fast["trace"]) - len(fx["mapped_trace"])) <= 1
     finally:
         model.density_bitfield.copy_(keep)

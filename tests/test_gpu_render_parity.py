@@ -156,14 +156,21 @@ def test_fused_field_f16_vs_ops_path_and_oracle(small_scene):
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         s_o, c_o, _ = sc.model(x, d, sc.time)
     s_o, c_o = s_o.float(), c_o.float()
+    # fp16-distance bars (the benchmarked path: -O numerics), stated as a distribution: sigma relative to max(|sigma|, 1e-3), colours
+    # absolute.  Measured (MI355X, round 3): sigma vs op-by-op max 3.9e-3 / p99.9 2.0e-3 / p99 0 (isolated fp16 rounding flips of the
+    # density logit, 1 ulp = 1e-3 relative after exp), 23 of 5000 above 1e-3; rgb max 4.9e-4, none above 1e-3; vs the fp16 oracle the same.
+    from tests_support import assert_dist
     rel = ((s_f - s_o).abs() / s_o.abs().clamp(min=1e-3))
-    assert float(rel.median()) < 2e-3 and float(rel.max()) < 5e-2, (float(rel.median()), float(rel.max()), s_f[:10].tolist(), s_o[:10].tolist())
-    assert float((c_f - c_o).abs().max()) < 1e-2 and float((c_f - c_o).abs().mean()) < 5e-4
+    assert float(rel.median()) < 2e-3, float(rel.median())
+    st = [assert_dist(s_f.cpu().numpy(), s_o.cpu().numpy(), "sigma, fused vs op-by-op", rel_floor=1e-3, max=1.5e-2, p999=6e-3, p99=1e-3, frac_above_1e3=0.02),
+          assert_dist(c_f.cpu().numpy(), c_o.cpu().numpy(), "rgb, fused vs op-by-op", max=2e-3, p999=1e-3, mean=1e-5, frac_above_1e3=1e-3)]
     fo = FieldOracle(orender.state_of(sc.model), mode="fp16")
     s_r, c_r, _ = fo.forward(pts, d.cpu().numpy(), 0.5)
     rel = np.abs(s_f.cpu().numpy() - s_r) / np.maximum(np.abs(s_r), 1e-3)
-    assert np.median(rel) < 2e-3 and rel.max() < 5e-2, (np.median(rel), rel.max())
-    assert np.abs(c_f.cpu().numpy() - c_r).max() < 1e-2
+    assert np.median(rel) < 2e-3, np.median(rel)
+    st += [assert_dist(s_f.cpu().numpy(), s_r, "sigma, fused vs fp16 oracle", rel_floor=1e-3, max=1e-2, p999=6e-3, p99=1e-3, frac_above_1e3=0.02),
+           assert_dist(c_f.cpu().numpy(), c_r, "rgb, fused vs fp16 oracle", max=2e-3, p999=1e-3, frac_above_1e3=1e-3)]
+    print("fused field distance:", st)
     # live-index form evaluates exactly the listed slots and leaves the others untouched
     idx = torch.arange(0, 5000, 3, dtype=torch.int32, device="cuda")
     cnt = torch.tensor([idx.shape[0]], dtype=torch.int32, device="cuda")
@@ -185,9 +192,12 @@ def test_render_frame_fused_f16_vs_oracle(small_scene):
     ref = orender.render_frame_oracle(sc, mode="fp16")
     img = out["image"].cpu().numpy()
     assert abs(out["n_samples"] - ref["n_samples"]) <= 0.002 * ref["n_samples"]
-    assert np.abs(img - ref["image"]).max() < 5e-3 and np.abs(img - ref["image"]).mean() < 2e-4
+    from tests_support import assert_dist
+    # (measured: max 3.2e-5, p99.9 1.3e-5, mean 5e-8, no pixel above 1e-3 -- the frame's -O numerics against the fp16-emulating oracle)
+    st = [assert_dist(img, ref["image"], "frame, fused -O vs fp16 oracle", max=2e-4, p999=6e-5, mean=1e-6, frac_above_1e3=0.0)]
     ops = render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=True)
-    assert np.abs(img - ops["image"].cpu().numpy()).max() < 5e-3
+    st.append(assert_dist(img, ops["image"].cpu().numpy(), "frame, fused vs op-by-op -O", max=2e-4, p999=6e-5, frac_above_1e3=0.0))
+    print("fused frame distance:", st)
 
 
 def test_device_driven_loop_is_bit_identical_to_host_loop(small_scene):

@@ -578,3 +578,32 @@ def test_skip_grids_follow_in_place_rewrites_of_the_occupancy():
     step.refresh()
     step(sc.rays_o, sc.rays_d, target, sc.time, grads_only=True)
     assert int(model.step_counter[(model.local_step - 1) % 16, 0]) == full
+
+
+def test_table_pass_on_a_second_stream_changes_nothing_but_the_schedule():
+    """`overlap_table_update`: the optimizer's pass over the embedding table runs on a second stream beside the next step's
+    deformation-MLP forward.  Same arithmetic on the same operands, so five steps give the parameters of the plain sequence up to
+    the table atomics' summation order (the bars of `test_marching_the_next_batch_ahead_changes_nothing`); `flush()` orders the
+    caller's stream behind the pass: a stream-ordered read of the table right after it equals the read after a device-wide
+    synchronisation; `refresh()` and `sync_optimizer_state()` flush by themselves."""
+    from dnerf_amd.train_native import NativeTrainStep
+    runs = []
+    for overlap in (False, True):
+        sc, model, opt, scaler, target = _setup()
+        step = NativeTrainStep(model, opt, scaler, N_RAYS, "cuda", perturb=True, seed=3, overlap_table_update=overlap)
+        losses = [step(sc.rays_o, sc.rays_d, target, t).clone() for t in (0.5, 0.25, 0.0, 0.75, 0.5)]
+        step.flush()
+        early = model.encoder.embeddings.detach().clone()          # stream-ordered read, no device-wide synchronisation before it
+        torch.cuda.synchronize()
+        assert torch.equal(early, model.encoder.embeddings.detach())
+        rows = model.encoder.embeddings.shape[0]
+        assert float(step.view("g_table", torch.float16, (rows, 2)).abs().max()) == 0      # cleared by the table pass
+        assert torch.equal(step.view("w_table", torch.float16, (rows, 2)), model.encoder.embeddings.detach().half())
+        step.sync_optimizer_state()
+        assert float(opt.state[model.encoder.embeddings]["step"]) == 5
+        runs.append(([float(x) for x in losses], {k: v.detach().clone() for k, v in model.named_parameters()}))
+    assert runs[0][0][0] == runs[1][0][0]
+    np.testing.assert_allclose(runs[0][0], runs[1][0], rtol=2e-3)
+    for k in runs[0][1]:
+        d = (runs[0][1][k] - runs[1][1][k]).abs()
+        assert float(d.max()) <= (1.1e-1 if k == "encoder.embeddings" else 1.1e-2), k

@@ -64,3 +64,23 @@ def oracle_fixture_cases():
         "grid_f32": lambda: _case_grid(False),
         "grid_f16": lambda: _case_grid(True),
     }
+
+
+def dist_stats(got, want, rel_floor=None):
+    """Distribution of |got - want| (or of the relative error with denominator max(|want|, rel_floor)): max, p99.9, p99, mean, the
+    count above 1e-3 and the size -- so a bar states more than one `max <`, and a failure message shows where the mass sits."""
+    got, want = np.asarray(got, np.float64).ravel(), np.asarray(want, np.float64).ravel()
+    err = np.abs(got - want)
+    if rel_floor is not None:
+        err = err / np.maximum(np.abs(want), rel_floor)
+    return {"max": float(err.max()), "p99.9": float(np.quantile(err, 0.999)), "p99": float(np.quantile(err, 0.99)), "mean": float(err.mean()),
+            "above_1e-3": int((err > 1e-3).sum()), "n": int(err.size)}
+
+
+def assert_dist(got, want, what, rel_floor=None, **bars):
+    """bars: any of max / p999 / p99 / mean / frac_above_1e3 (fraction of elements whose error exceeds 1e-3)."""
+    st = dist_stats(got, want, rel_floor)
+    key = {"max": "max", "p999": "p99.9", "p99": "p99", "mean": "mean"}
+    bad = [k for k, v in bars.items() if (st["above_1e-3"] / st["n"] if k == "frac_above_1e3" else st[key[k]]) > v]
+    assert not bad, (what, "exceeds", bad, "bars", bars, "measured", st)
+    return st
