@@ -775,14 +775,15 @@ def marcher_roofline(dloop, grp_o, grp_d, grp_t, n_groups, distinct, frame_cam, 
     summ = t.summary().get("field_forward_f16")      # (the event pairs keep their name; they bracketed the marcher launches here)
     if not summ:
         return None
+    loops, frames = frames, frames * F               # a loop renders F frames
     per_frame_ms = summ["total_ms"] / frames
     bytes_per_frame = (MARCH_BYTES_PER_SAMPLE + COMPOSITE_BYTES_PER_SAMPLE) * samples / frames
     achieved = bytes_per_frame / (per_frame_ms * 1e-3) / 1e9
-    return {"kernel": "inference marchers (k_march_rays_g / k_composite_march_g; lane-per-ray forms with SDN_GROUP_MARCH=0)", "bound": "hbm",
+    return {"kernel": "inference marchers (k_march_rays / k_composite_march, one lane per ray; the 16-lanes-per-ray forms with SDN_GROUP_MARCH=1)", "bound": "hbm",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "bytes_per_sample": MARCH_BYTES_PER_SAMPLE + COMPOSITE_BYTES_PER_SAMPLE, "launches_per_frame": summ["launches"] / frames,
-            "avg_launch_ms": summ["avg_ms"], "ms_per_frame": per_frame_ms, "frames": frames,
-            "note": "one frame at a time (nothing else in flight), HIP events around the marcher launch of every iteration; the steady-mode "
+            "avg_launch_ms": summ["avg_ms"], "ms_per_frame": per_frame_ms, "frames": frames, "frames_per_loop": F, "loops": loops,
+            "note": "one loop at a time (nothing else in flight), HIP events around the marcher launch of every iteration; the steady-mode "
                     "entry march (one more launch per frame) is not bracketed; latency-bound kernels: read ms_per_frame, not frac"}
 
 

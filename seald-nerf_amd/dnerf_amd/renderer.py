@@ -671,6 +671,28 @@ class DeviceLoop:
         return self.collect(nears, fars, want_stats)
 
 
+def _context_streams(k, device):
+    """One HIP stream per context.  SDN_CTX_PRIORITIES="p0,p1,..." (HIP stream priorities, -1 high / 0 normal / 1 low, used in turn) creates
+    them with `hipStreamCreateWithPriority` instead of torch's default-priority pool: contexts of different priority do not fall into
+    step with each other (pipelining)."""
+    import os
+    spec = os.environ.get("SDN_CTX_PRIORITIES", "").strip()
+    if not spec:
+        return [torch.cuda.Stream(device=device) for _ in range(k)]
+    import ctypes
+    prios = [int(x) for x in spec.split(",")]
+    hip = ctypes.CDLL("libamdhip64.so")
+    out = []
+    with torch.cuda.device(device):
+        for i in range(k):
+            h = ctypes.c_void_p()
+            rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(prios[i % len(prios)]))   # 1 = hipStreamNonBlocking
+            if rc != 0:
+                raise RuntimeError(f"hipStreamCreateWithPriority failed ({rc})")
+            out.append(torch.cuda.ExternalStream(h.value, device=device))
+    return out
+
+
 class PipelinedDeviceLoop:
     """A stream of frames (camera path / time steps of one model) through `contexts` `DeviceLoop` contexts used in turn, each on its
     own HIP stream, all driven by one host thread in `sdn_render_frames_pipelined_f16`: the next frame starts as soon as a
@@ -683,7 +705,7 @@ class PipelinedDeviceLoop:
         from sdn_backend import SdnRenderCtx, HostMailbox
         self.N, self.device, self.overlap_div, self.K = N, device, int(overlap_div), int(contexts)
         self.loops = [DeviceLoop(model, field, N, device, mailbox=mailbox, **kw) for _ in range(self.K)]
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(self.K)]
+        self.streams = _context_streams(self.K, device)
         # mailbox=False: ordinary pinned memory -> the driver's event + side-stream copy read-back (see DeviceLoop)
         self.host_state = HostMailbox(self.K) if mailbox else torch.zeros(self.K, 8, dtype=torch.int32).pin_memory()
         self._ctxs = (ctypes.POINTER(SdnRenderCtx) * self.K)(*[ctypes.pointer(lp.ctx) for lp in self.loops])

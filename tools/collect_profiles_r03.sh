@@ -11,6 +11,8 @@ stats() {  # name, bench args...
   cp $(find $OUT/tmp_$name -name "*kernel_stats.csv" | head -1) $OUT/${name}_kernel_stats.csv
   rm -rf $OUT/tmp_$name
 }
+PART=${1:-all}
+if [ "$PART" != "2" ]; then
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || exit 1; echo "bench default done"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2>/dev/null || exit 1; echo "driver cmd done"
 python3 bench.py --steps 20 --pipeline 0 --group-frames 1 --no-cpu-baseline > $OUT/bench_sequential.json 2>/dev/null || exit 1
@@ -26,6 +28,8 @@ stats default --no-cpu-baseline --no-secondary || exit 1
 stats sequential --steps 20 --warmup 3 --pipeline 0 --group-frames 1 --no-cpu-baseline --no-secondary || exit 1
 stats train --mode train --steps 100 --warmup 10 || exit 1
 echo "stats done"
+fi
+if [ "$PART" = "1" ]; then ls $OUT; exit 0; fi
 python3 bench.py --mode train --steps 300 --warmup 10 > $OUT/bench_train.json 2>/dev/null || exit 1
 python3 bench.py --mode train --steps 300 --warmup 10 --train-overlap 0 --train-prefetch 0 > $OUT/bench_train_no_overlap_no_prefetch.json 2>/dev/null || exit 1
 python3 bench.py --mode seald --steps 20 > $OUT/bench_seald.json 2>/dev/null || exit 1

@@ -24,6 +24,47 @@ def union(iv):
     return out
 
 
+def kind(n):
+    return "F" if "k_field_f16" in n else ("M" if ("k_composite_march" in n or "k_march_rays" in n) else "o")
+
+
+def per_queue(rows, t0):
+    """Per hardware queue (= loop context): time inside field kernels, marchers, other kernels, and the gaps between the end of one
+    kernel and the start of the next, split by what the next kernel is; plus the histogram of how many field kernels run at once."""
+    qs = {}
+    for s, e, n, q in rows:
+        if e > t0:
+            qs.setdefault(q, []).append((s, e, kind(n)))
+    out = {}
+    for q, lst in qs.items():
+        lst.sort()
+        if len(lst) < 50:
+            continue
+        tot = {"F": 0, "M": 0, "o": 0, "gap_before_F": 0, "gap_before_M": 0, "gap_before_o": 0}
+        gaps = {"F": [], "M": [], "o": []}
+        for i, (s, e, k) in enumerate(lst):
+            tot[k] += e - s
+            if i:
+                g = max(0, s - lst[i - 1][1])
+                tot["gap_before_" + k] += g
+                gaps[k].append(g)
+        span = lst[-1][1] - lst[0][0]
+        med = {k: (sorted(v)[len(v) // 2] / 1e3 if v else None) for k, v in gaps.items()}
+        p90 = {k: (sorted(v)[int(len(v) * 0.9)] / 1e3 if v else None) for k, v in gaps.items()}
+        out[q] = {"kernels": len(lst), "span_ms": span / 1e6, **{k: round(v / span, 4) for k, v in tot.items()}, "gap_us_median": med, "gap_us_p90": p90}
+    ev = []
+    for s, e, n, q in rows:
+        if e > t0 and kind(n) == "F":
+            ev += [(max(s, t0), 1), (e, -1)]
+    ev.sort()
+    hist, depth, last = {}, 0, t0
+    for t, d in ev:
+        hist[depth] = hist.get(depth, 0) + (t - last)
+        depth, last = depth + d, t
+    tot = sum(hist.values()) or 1
+    print(json.dumps({"per_queue": out, "field_kernels_running_at_once": {str(k): round(v / tot, 4) for k, v in sorted(hist.items())}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
@@ -31,10 +72,11 @@ def main():
     args = ap.parse_args()
     rows = []
     for r in csv.DictReader(open(args.trace)):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
-    t_end = max(e for _, e, _ in rows)
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0")))
+    t_end = max(r[1] for r in rows)
     t0 = t_end - int(args.window_ms * 1e6)
-    rows = [(max(s, t0), e, n) for s, e, n in rows if e > t0]
+    per_queue(rows, t0)
+    rows = [(max(s, t0), e, n) for s, e, n, _ in rows if e > t0]
     wall = t_end - t0
     field = [(s, e) for s, e, n in rows if "k_field_f16" in n]
     march = [(s, e) for s, e, n in rows if "k_composite_march" in n or "k_march_rays" in n]
