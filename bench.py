@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA
 GRID_BYTES_PER_POINT = {"f16": 588.0, "f32": 1164.0}  # gathers + 12 B in + outputs
 FIELD_FLOP_PER_POINT = 235520.0                          # 117 760 MAC
-PMC_SUMMARY = "r02_field_pmc_summary.json"               # rocprofv3 --pmc summary the static `traffic` figure comes from
+PMC_SUMMARY = "r03_field_pmc_summary.json"               # rocprofv3 --pmc summary the static `traffic` figure comes from
 
 
 def parse():
@@ -890,6 +890,13 @@ def roofline(timers, fp16, points_exclusive, points_overlapped=0):
             f = json.load(open(pmc))["field_forward_f16"]
             roof["traffic"] = f["hbm_bytes_per_point"] * s["avg_units"]
             roof["traffic_static"] = True
+            roof["traffic_fetch_x2"] = f.get("hbm_bytes_per_point_fetch_x2", 0.0) * s["avg_units"] or None   # FETCH_SIZE tallies wide reads at half their bytes (gfx950)
+            mp = f.get("matrix_pipe") or {}
+            if mp:   # counter evidence of the same kernel (static, from the committed passes): SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES
+                roof["matrix_pipe_counters_static"] = {"mfma_busy_over_busy_cu": mp.get("mfma_busy_over_busy_cu"),
+                                                       "busy_frac_while_cu_busy": mp.get("matrix_pipe_busy_frac_while_cu_busy"),
+                                                       "busy_frac_of_chip_wall_cycles": mp.get("matrix_pipe_busy_frac_of_chip_wall"),
+                                                       "source": f"profiles/{PMC_SUMMARY} (frame groups of 4, one loop at a time)"}
             roof["traffic_unit"] = f"HBM bytes per launch = bytes per point of profiles/{PMC_SUMMARY} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command) x points per launch; static, not measured in this run"
         if over and points_overlapped:  # the same launches while other loops' kernels share the device: durations are not the kernel's own
             units = points_overlapped / over["launches"]
