@@ -544,7 +544,7 @@ def main():
         # instrumented loops: the last is rendered with nothing else in flight -- the pipeline is draining there anyway -- and its
         # launch durations are the kernel's own (the roofline figure); every `every`-th loop before it is instrumented while it
         # overlaps like all the others (a launch while it shares the device)
-        excl_set = exclusive_frames(k) if every else set()
+        excl_set = (exclusive_frames(k) if world == 1 else {k - 1}) if every else set()
         marked = sorted(set(range(0, k, every)) | excl_set) if every else []
         timing = make_timing(len(marked))
         per_frame, it = [None] * k, iter(timing)
@@ -615,8 +615,8 @@ def main():
         torch.cuda.synchronize()
 
     every = max(1, args.time_every)
-    if world > 1:
-        every = 0    # multi-GPU runs are not instrumented: the roofline figure is a one-GPU quantity
+    # (multi-GPU: every rank instruments the same loops -- the ranks stay symmetric -- and only the LAST loop, where the pipeline drains
+    # anyway, runs with nothing else in flight on its GPU; rank 0's figures go into the line: a rank's shard-sized launches)
     n_instrumented = len(range(0, n_groups, every)) if every else 0
     # A generation-2 pass of CPython's cyclic collector costs tens of milliseconds with torch + numpy loaded and fires on allocation
     # counts, i.e. inside the timed region for some argument combinations and not for others (seen: 20 frames in 14 ms of driver
