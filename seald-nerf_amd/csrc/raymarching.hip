@@ -1553,6 +1553,7 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
         live_count += state[3];
         const uint32_t m0 = n_alive * n_step;
         M_pad = m0 + (128u - m0 % 128u);
+        if (blockIdx.x * 256u >= n_alive + 128u) return;   // workgroup-uniform: beyond the list and its alignment tail (the host sizes the grid by a bound)
     }
     __shared__ uint4 s_cull4[FAST ? 256 : 1];  // 32^3 bits = 4 KiB
     __shared__ unsigned long long s_fine[FAST ? kFineCacheCells : 1];  // <= 32 KiB
@@ -1734,6 +1735,52 @@ __device__ __forceinline__ void publish_snapshot(int32_t *__restrict__ state, in
     }
 }
 
+// Culled start of the device loop (FAST configuration with a cull grid and the per-ray t_end cache).  The reference's iteration 0 marches
+// all N rays by one step and the rays without a sample die in its compositing pass; here the exact cull test every ray would run on
+// its first march (ray_may_hit: same arguments, same result, the marks read from global memory instead of an LDS copy) runs up front
+// for all N rays -- filling the t_end cache -- and iteration 0 then works on the compacted list of the rays that MAY produce a sample:
+// dense waves instead of N-ray launches in which most lanes stop at the cull test.  Nothing observable changes: a ray the test rejects
+// produces no sample and dies in iteration 0 either way, the survivors of iteration 0 -- and therefore every later iteration, every
+// sample and every count -- are the same, and the trace logs N for iteration 0 (state[15], k_loop_advance / k_scatter_advance).
+__global__ void __launch_bounds__(256) k_cull_start(uint32_t N, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                    const float *__restrict__ nears, const float *__restrict__ fars,
+                                                    const uint32_t *__restrict__ cull, FrameSel fs, int32_t *__restrict__ alive_a,
+                                                    float *__restrict__ rays_tend) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const uint32_t frame = fs.n_frames > 1 ? n / fs.rays_per_frame : 0u;
+    const uint32_t *__restrict__ cull_f = fs.n_frames > 1 ? cull + (size_t)frame * fs.cull_stride : cull;
+    const int *meta = reinterpret_cast<const int *>(cull_f + kCullWords);
+    const int fx0 = meta[0], fy0 = meta[1], fz0 = meta[2];
+    const int fnx = meta[3] - fx0 + 1, fny = meta[4] - fy0 + 1, fnz = meta[5] - fz0 + 1;
+    const float t = nears[n], far = fars[n];
+    bool go = t < far;
+    float t_end = far;
+    if (go) {
+        go = ray_may_hit(cull_f, rays_o[(size_t)n * 3], rays_o[(size_t)n * 3 + 1], rays_o[(size_t)n * 3 + 2], rays_d[(size_t)n * 3],
+                         rays_d[(size_t)n * 3 + 1], rays_d[(size_t)n * 3 + 2], t, far, t_end, fx0, fy0, fz0, fnx, fny, fnz);
+        rays_tend[n] = go ? t_end : kTendDead;     // what march_ray would cache on the ray's first march
+    }
+    alive_a[n] = go ? (int32_t)n : -1;
+}
+
+// after the compaction of the culled start: the list is in alive_b (side 1), n_out[0] rays long
+__global__ void k_cull_advance(int32_t *__restrict__ state, const int32_t *__restrict__ n_out, int32_t *__restrict__ trace) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int32_t n0 = n_out[0];
+    state[4] = 1;
+    state[15] = 1;            // iteration 0 runs on the culled list: the trace logs N for it
+    if (n0 > 0) {
+        state[0] = n0;
+    } else {                  // no ray can produce a sample: the reference's iteration 0 (N rays, one step) finds nothing and the loop ends
+        trace[0] = state[5];
+        trace[1] = state[1];
+        state[2] += state[1];
+        state[3] = 1;
+        state[0] = 0;
+    }
+}
+
 // snap: 4 x {alive rays entering the next iteration, index of that iteration} -- an immutable per-iteration snapshot the
 // host copies out on a side stream while the main stream already runs the next iteration.
 __global__ void k_loop_advance(int32_t *__restrict__ state, const int32_t *__restrict__ n_out, int32_t *__restrict__ trace,
@@ -1743,7 +1790,7 @@ __global__ void k_loop_advance(int32_t *__restrict__ state, const int32_t *__res
     const int32_t call = state[7];  // number of advance calls so far (no-op iterations included)
     state[7] = call + 1;
     if (state[0] > 0) {  // log only iterations that did work: (n_alive, n_step)
-        trace[2 * it] = state[0];
+        trace[2 * it] = (it == 0 && state[15]) ? state[5] : state[0];   // culled start: iteration 0 is the reference's N-ray iteration
         trace[2 * it + 1] = state[1];
         state[2] += state[1];
         state[3] = it + 1;
@@ -1814,7 +1861,7 @@ __global__ void __launch_bounds__(256) k_scatter_advance(int32_t *__restrict__ a
         const int32_t call = state[7];
         state[7] = call + 1;
         if (state[0] > 0) {
-            trace[2 * it] = state[0];
+            trace[2 * it] = (it == 0 && state[15]) ? state[5] : state[0];
             trace[2 * it + 1] = state[1];
             state[2] += state[1];
             state[3] = it + 1;
@@ -2230,6 +2277,24 @@ int loop_begin(uint32_t N, uint32_t max_steps, const float *nears, int32_t *aliv
     const uint32_t threads = N > n_counters ? N : n_counters;
     hipLaunchKernelGGL(k_loop_init, dim3(sdn_div_up(threads, 256u)), dim3(256), 0, st, N, max_steps, nears, alive_a, rays_t, weights_sum, depth,
                        image, state, live_counts, n_counters, (unsigned long long)(uintptr_t)mailbox, frame_tag, rays_tend);
+    return sdn_launch_status();
+}
+
+// Culled start (see k_cull_start): after loop_begin and after the context's cull grid(s) are in place.  Returns 0 without doing
+// anything when the configuration has no exact cull test (not the FAST configuration, no cull grid, no t_end cache, cooperative marcher).
+int loop_cull_start(uint32_t N, const float *rays_o, const float *rays_d, const float *nears, const float *fars, float bound, float dt_gamma,
+                    uint32_t C, uint32_t H, const uint32_t *cull, const FrameSel &fs, int32_t *alive_a, int32_t *alive_b, float *rays_tend,
+                    int32_t *state, uint32_t *block_totals, int32_t *n_out, int32_t *trace, hipStream_t st) {
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("SDN_CULL_START"); off = (e && e[0] == '0') ? 1 : 0; }
+    if (off || !cull || !rays_tend || H != 128 || !fast_config(bound, C, H) || use_group_march(bound, dt_gamma, C, H)) return 0;
+    hipLaunchKernelGGL(k_cull_start, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, N, rays_o, rays_d, nears, fars, cull, fs, alive_a, rays_tend);
+    const uint32_t nb = sdn_div_up(N, kScanBlock);
+    hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(kScanBlock), 0, st, (const int32_t *)alive_a, N, block_totals, (const int32_t *)nullptr,
+                       (const int32_t *)nullptr);
+    hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(kScanBlock), 0, st, (const int32_t *)alive_a, N, (const uint32_t *)block_totals, alive_b, n_out,
+                       (const int32_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_cull_advance, dim3(1), dim3(64), 0, st, state, (const int32_t *)n_out, trace);
     return sdn_launch_status();
 }
 

@@ -31,6 +31,11 @@ int render_begin(const SdnRenderCtx *c, void *mailbox, uint32_t frame_tag, hipSt
         for (uint32_t f = 0; f < nf; f++) kept = kept && c->frame_cull[f] != nullptr;
         if (kept) rc = copy_cull(c->frame_cull, nf, (uint32_t *)c->cull_bits, st);
         else rc = c->n_group_frames > 1 ? build_cull_group(frame_sel(c), (uint32_t *)c->cull_bits, st) : build_cull(c->bitfield, (uint32_t *)c->cull_bits, st);
+        // iteration 0 on the rays that pass the exact cull test (same samples, same trace; raymarching.hip k_cull_start)
+        if (!rc && c->rays_tend)
+            rc = loop_cull_start(c->N, c->rays_o, c->rays_d, c->nears, c->fars, c->bound, c->dt_gamma, c->C, c->H, (const uint32_t *)c->cull_bits, frame_sel(c),
+                                 c->alive_a, c->alive_b, (float *)c->rays_tend, c->state, (uint32_t *)c->block_totals, c->trace + 2 * (size_t)c->n_counters + 8,
+                                 c->trace, st);
     }
     return rc;
 }
