@@ -1593,6 +1593,12 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
     if (live_idx) live_append(step, n, n_step, live_idx, live_count);  // kernel-uniform condition
 }
 
+// Length of the alive list the loop kernels walk: the frozen list of the steady mode (state[8], dead entries = -1 included) when one
+// exists -- the compositing + compaction pass then RE-compacts it (render.hip, FrameRun::enqueue) -- else the compacted list (state[0]).
+__device__ __forceinline__ uint32_t loop_list_len(const int32_t *__restrict__ state) {
+    return state[8] ? (uint32_t)state[8] : (uint32_t)state[0];
+}
+
 // raymarching.cu:819-905
 __global__ void __launch_bounds__(256) k_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *__restrict__ rays_alive,
                                                         float *__restrict__ rays_t, const float *__restrict__ sigmas,
@@ -1601,7 +1607,7 @@ __global__ void __launch_bounds__(256) k_composite_rays(uint32_t n_alive, uint32
                                                         const int32_t *__restrict__ state, int32_t *__restrict__ rays_alive_b,
                                                         uint32_t *__restrict__ block_totals) {
     if (state) {
-        n_alive = (uint32_t)state[0];
+        n_alive = loop_list_len(state);
         n_step = (uint32_t)state[1];
         if (state[4]) rays_alive = rays_alive_b;
     }
@@ -1609,9 +1615,11 @@ __global__ void __launch_bounds__(256) k_composite_rays(uint32_t n_alive, uint32
     bool survives = false;
     if (n < n_alive) {
         const int index = rays_alive[n];
-        survives = composite_ray(index, n_step, T_thresh, sigmas + (size_t)n * n_step, rgbs + (size_t)n * n_step * 3,
-                                 deltas + (size_t)n * n_step * 2, rays_t, weights_sum, depth, image);
-        if (!survives) rays_alive[n] = -1;
+        if (index >= 0) {    // (a frozen list holds dead entries)
+            survives = composite_ray(index, n_step, T_thresh, sigmas + (size_t)n * n_step, rgbs + (size_t)n * n_step * 3,
+                                     deltas + (size_t)n * n_step * 2, rays_t, weights_sum, depth, image);
+            if (!survives) rays_alive[n] = -1;
+        }
     }
     if (block_totals) {  // kernel-uniform: survivor count of this 256-ray block, for the fused compaction of the device loop
         __shared__ uint32_t s_cnt[4];
@@ -1629,7 +1637,7 @@ __global__ void __launch_bounds__(256) k_composite_rays(uint32_t n_alive, uint32
 __global__ void __launch_bounds__(kScanBlock) k_compact_count(const int32_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ block_totals,
                                                               const int32_t *__restrict__ state, const int32_t *__restrict__ in_b) {
     if (state) {
-        n = (uint32_t)state[0];
+        n = loop_list_len(state);
         if (state[4]) in = in_b;
         if (blockIdx.x * kScanBlock >= n) return;  // workgroup-uniform
     }
@@ -1652,7 +1660,7 @@ __global__ void __launch_bounds__(kScanBlock) k_compact_scatter(const int32_t *_
                                                                 int32_t *__restrict__ out_b) {
     uint32_t last_block = gridDim.x - 1;
     if (state) {
-        n = (uint32_t)state[0];
+        n = loop_list_len(state);
         if (state[4]) { in = in_b; out = out_b; }
         if (n == 0) {
             if (blockIdx.x == 0 && threadIdx.x == 0) n_out[0] = 0;
@@ -1823,7 +1831,7 @@ __global__ void __launch_bounds__(256) k_scatter_advance(int32_t *__restrict__ a
                                                          int32_t *__restrict__ ticket, int32_t *__restrict__ trace, int32_t *__restrict__ snap) {
     __shared__ uint32_t lds4[4];
     __shared__ int s_last;
-    const uint32_t n = (uint32_t)state[0];
+    const uint32_t n = loop_list_len(state);
     const int32_t *in = state[4] ? alive_b : alive_a;
     int32_t *out = state[4] ? alive_a : alive_b;
     const uint32_t nb = (n + 255u) / 256u;

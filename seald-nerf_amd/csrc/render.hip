@@ -138,6 +138,12 @@ int sdn_render_step_f16_ev(const SdnRenderCtx *c, uint32_t bound_alive, void *ev
 
 namespace {
 
+constexpr uint32_t kRecompactMin = 8192;   // below this many alive rays a launch is latency-bound whatever its list looks like
+bool recompact_enabled() {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("SDN_RECOMPACT"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
 constexpr int kDriverTimeoutSeconds = 20;   // no iteration of any frame in flight completes for this long: SDN_E_TIMEOUT
 
 // One ray group's loop as a two-phase state machine, so that one host thread can drive several groups round-robin.
@@ -149,6 +155,11 @@ struct FrameRun {
     uint32_t max_field_events;
     uint32_t bound, it;
     bool steady, done;   // steady: see k_composite_march -- two launches per iteration once n_alive <= N / 8
+    // Steady mode walks a FROZEN list (dead entries stay in it as -1): once half of it is dead, one iteration ends with the normal
+    // mode's compositing + stable compaction instead of the fused kernel and the list is frozen again at its new length -- the
+    // marcher's waves are dense again (same rays in the same order, same samples; four more launches on that iteration).
+    bool recompact = false;
+    uint32_t list_bound = 0;   // upper bound of the frozen list's length
     // Mailbox mode: host_snap is coherent (fine-grained) mapped host memory (sdn_host_mailbox_alloc), the kernels publish each
     // iteration's {tag : n_alive} into it with one 64-bit system-scope store and the host polls -- the main stream then carries
     // nothing but kernels (no event record / stream wait / copy / event wait per iteration).
@@ -158,7 +169,7 @@ struct FrameRun {
 
     int begin() {
         if (!ctx_ok(c)) return SDN_E_BADARG;
-        bound = c->N; it = 0; steady = false; done = false; last_alive = c->N;
+        bound = c->N; it = 0; steady = false; done = false; last_alive = c->N; recompact = false; list_bound = 0;
         mail_dev = nullptr;
         unsigned int flags = 0;
         void *dptr = nullptr;
@@ -198,7 +209,18 @@ struct FrameRun {
             if (e1) (void)hipEventRecord((hipEvent_t)e1, st);
             if (!rc) rc = seal_color(c, (uint32_t)m_bound, st);
             if (!rc && m0) (void)hipEventRecord((hipEvent_t)m0, st);
-            if (!rc)
+            if (!rc && recompact) {
+                // composite this iteration on the frozen list, compact it, freeze the shorter list and march the next iteration on it
+                rc = sdn_int::loop_composite_compact(bound, c->T_thresh, c->alive_a, c->alive_b, c->rays_t, c->sigmas, c->rgbs, c->deltas, c->weights_sum,
+                                                     c->depth, c->image, c->state, (uint32_t *)c->block_totals, c->n_out, c->trace, snap_dev, st);
+                const uint32_t nb = last_alive < bound ? last_alive : bound;     // the new list: at most the rays alive when this iteration began
+                if (!rc)
+                    rc = sdn_int::loop_steady_begin(nb, c->alive_a, c->alive_b, c->rays_t, c->rays_o, c->rays_d, c->bound, c->dt_gamma, c->max_steps, c->C,
+                                                    c->H, c->bitfield, c->fars, c->xyzs, c->dirs, c->deltas, cull(), c->live_idx, (uint32_t *)c->live_counts,
+                                                    c->state, sdn_int::frame_sel(c), st);
+                bound = list_bound = nb;
+                recompact = false;
+            } else if (!rc)
                 rc = sdn_int::loop_composite_march(bound, c->T_thresh, c->alive_a, c->alive_b, c->rays_t, c->rays_o, c->rays_d, c->bound,
                                                    c->dt_gamma, c->max_steps, c->C, c->H, c->bitfield, c->fars, c->sigmas, c->rgbs, c->xyzs,
                                                    c->dirs, c->deltas, c->weights_sum, c->depth, c->image, cull(), c->live_idx,
@@ -262,7 +284,10 @@ struct FrameRun {
                                                         c->live_idx, (uint32_t *)c->live_counts, c->state, sdn_int::frame_sel(c), st);
                     if (rc) return rc;
                     steady = true;
+                    list_bound = bound;
                 }
+            } else if (recompact_enabled() && (uint64_t)n_prev * 2u <= list_bound && (uint32_t)n_prev >= kRecompactMin) {
+                recompact = true;     // the iteration enqueued next ends with the compaction
             }
         }
         it++;
