@@ -148,11 +148,12 @@ bool recompact_enabled() {
 // (a group of 4 full frames freezes ~320 K entries) wants it on nearly every iteration -- 0.431 ms per frame at 95-100 % against 0.459 at
 // 50 % and 0.490 without; a short one (one frame, or 8 shards of a frame: ~80 K entries) is best left alone until half of it is dead
 // (0.487 / 0.0694 at 50 % against 0.50-0.52 / 0.072-0.076 at 95 %): the four extra launches of a compacting iteration are latency on
-// that loop, the waves it saves are proportional to the list.  SDN_RECOMPACT_PCT / SDN_RECOMPACT_MIN override (measurements).
+// that loop, the waves it saves are proportional to the list.  The cut sits above the longest list one 640 000-ray frame can freeze
+// (N / 8 = 80 000).  SDN_RECOMPACT_PCT / SDN_RECOMPACT_MIN override (measurements).
 uint32_t recompact_pct(uint32_t list_len) {
     static int v = -2;
     if (v == -2) { const char *e = getenv("SDN_RECOMPACT_PCT"); v = e ? atoi(e) : -1; }
-    return v >= 0 ? (uint32_t)v : (list_len >= 131072u ? 95u : 50u);
+    return v >= 0 ? (uint32_t)v : (list_len > 81920u ? 95u : 50u);
 }
 uint32_t recompact_min() { static int v = -1; if (v < 0) { const char *e = getenv("SDN_RECOMPACT_MIN"); v = e ? atoi(e) : (int)kRecompactMin; } return (uint32_t)v; }
 constexpr int kDriverTimeoutSeconds = 20;   // no iteration of any frame in flight completes for this long: SDN_E_TIMEOUT
