@@ -51,8 +51,8 @@ def parse():
                                                             "hardware queue per context + the default stream (GPU_MAX_HW_QUEUES, if unset)")
     ap.add_argument("--cameras", type=int, default=20, help="frames of the test sequence (camera orbit + time ramp 0..1); the timed steps cycle through it")
     ap.add_argument("--static-frame", action="store_true", help="render ONE camera at t = 0.5 over and over (the round-1 workload) instead of the sequence")
-    ap.add_argument("--group-frames", type=int, default=0, help="frames rendered together by one loop (frame group); 0 = --gpus (4 on one GPU); "
-                                                                 "reduced to a divisor of --steps")
+    ap.add_argument("--group-frames", type=int, default=0, help="frames rendered together by one loop (frame group); 0 = 4 x --gpus, at most 16; "
+                                                                 "moved to the nearest divisor of --steps")
     ap.add_argument("--emulate-rank-of", type=int, default=1, metavar="N",
                     help="one GPU only: render rank 0's shard of an N-way ray split of every frame (what one rank of --gpus N does, without "
                          "the gathers) -- to measure shard-sized loops / frame groups on one GPU; rays_per_s then counts shard rays")
@@ -444,10 +444,12 @@ def main():
     # of a loop are paid once per F frames; default F = gpus (a rank's batch keeps the size of one full frame), 1 on one GPU.
     # (one GPU: 4 consecutive frames per loop -- launches of ~300 K points instead of ~100 K fill the chip's 512 workgroup slots 2.3
     # times instead of 0.9 times: field kernel 0.25 -> 0.35 of the MFMA peak, 2 % more frames per second; sweep in profiles/r03_*)
-    want_f = args.group_frames if args.group_frames > 0 else (world if world > 1 else (4 if args.emulate_rank_of <= 1 else 1))
+    # (N GPUs: 4 N frames' shards per loop, i.e. the same 2.56 M rays per loop as 4 full frames on one GPU -- one rank of 8 at --steps 20:
+    # 0.0876 ms per frame with 5 frames per loop, 0.0713 with 10; profiles/r03_rank_frames_per_loop.txt)
+    want_f = args.group_frames if args.group_frames > 0 else (min(16, 4 * world) if world > 1 else (4 if args.emulate_rank_of <= 1 else 1))
     if args.group_frames == 0 and (args.field == "ops" or args.fp32 or args.loop == "host"):
         want_f = 1            # frame groups need the device loop with the fused field
-    F = max(d for d in range(1, min(want_f, 16) + 1) if K % d == 0)
+    F = min((d for d in range(1, 17) if K % d == 0), key=lambda d: (abs(d - min(want_f, 16)), -d))    # the divisor of --steps nearest to it
     n_groups = K // F
     frame_cam = [f % n_cams for f in range(K)]
     if F == 1:
