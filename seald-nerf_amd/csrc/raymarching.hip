@@ -1792,7 +1792,7 @@ __global__ void k_cull_advance(int32_t *__restrict__ state, const int32_t *__res
 // snap: 4 x {alive rays entering the next iteration, index of that iteration} -- an immutable per-iteration snapshot the
 // host copies out on a side stream while the main stream already runs the next iteration.
 __global__ void k_loop_advance(int32_t *__restrict__ state, const int32_t *__restrict__ n_out, int32_t *__restrict__ trace,
-                               int32_t *__restrict__ snap) {
+                               int32_t *__restrict__ snap, int freeze) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int32_t it = state[3];
     const int32_t call = state[7];  // number of advance calls so far (no-op iterations included)
@@ -1811,6 +1811,7 @@ __global__ void k_loop_advance(int32_t *__restrict__ state, const int32_t *__res
             state[1] = ns > 8 ? 8 : (ns < 1 ? 1 : ns);
         }
     }
+    if (freeze) { state[8] = state[0]; state[9] = 0; }   // k_steady_begin folded in: the compacted list is the steady mode's new frozen list
     publish_snapshot(state, snap, call);
 }
 
@@ -1828,7 +1829,8 @@ __device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t *lds4) {
 // record -- sums the totals and advances the record, so no workgroup can see a half-updated record.
 __global__ void __launch_bounds__(256) k_scatter_advance(int32_t *__restrict__ alive_a, int32_t *__restrict__ alive_b,
                                                          const uint32_t *__restrict__ block_totals, int32_t *__restrict__ state,
-                                                         int32_t *__restrict__ ticket, int32_t *__restrict__ trace, int32_t *__restrict__ snap) {
+                                                         int32_t *__restrict__ ticket, int32_t *__restrict__ trace, int32_t *__restrict__ snap,
+                                                         int freeze) {
     __shared__ uint32_t lds4[4];
     __shared__ int s_last;
     const uint32_t n = loop_list_len(state);
@@ -1882,6 +1884,7 @@ __global__ void __launch_bounds__(256) k_scatter_advance(int32_t *__restrict__ a
                 state[1] = ns > 8 ? 8 : (ns < 1 ? 1 : ns);
             }
         }
+        if (freeze) { state[8] = state[0]; state[9] = 0; }   // (k_steady_begin folded in)
         publish_snapshot(state, snap, call);
     }
 }
@@ -2328,11 +2331,13 @@ int loop_march(uint32_t bound_alive, const int32_t *alive_a, const int32_t *aliv
 
 int loop_composite_compact(uint32_t bound_alive, float T_thresh, int32_t *alive_a, int32_t *alive_b, float *rays_t, const float *sigmas,
                            const float *rgbs, const float *deltas, float *weights_sum, float *depth, float *image, int32_t *state,
-                           uint32_t *block_totals, int32_t *n_out, int32_t *trace, int32_t *snap, hipStream_t st) {
+                           uint32_t *block_totals, int32_t *n_out, int32_t *trace, int32_t *snap, hipStream_t st, bool freeze) {
     const dim3 g(sdn_div_up(bound_alive, 256u)), b(256);
     if (bound_alive > 65536u) {
         // many rays (the first one or two iterations): every scatter workgroup would re-sum thousands of 256-ray totals;
-        // use the 1024-ray count / scatter pair and a separate one-thread advance instead
+        // use the 1024-ray count / scatter pair and a separate one-thread advance instead.  (Measured again in round 3 with the fused pair up
+        // to 131 072 / 262 144 / 524 288 rays: 0.449 / 0.451 / 0.451 ms per frame against 0.441 -- every workgroup of the fused scatter pays a
+        // device-scope fence for the last-workgroup election.)
         hipLaunchKernelGGL(k_composite_rays, g, b, 0, st, 0u, 0u, T_thresh, alive_a, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
                            (const int32_t *)state, alive_b, (uint32_t *)nullptr);
         const uint32_t nb = sdn_div_up(bound_alive, kScanBlock);
@@ -2340,13 +2345,13 @@ int loop_composite_compact(uint32_t bound_alive, float T_thresh, int32_t *alive_
                            (const int32_t *)state, (const int32_t *)alive_b);
         hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(kScanBlock), 0, st, (const int32_t *)alive_a, 0u, (const uint32_t *)block_totals,
                            alive_b, snap + 8, (const int32_t *)state, (const int32_t *)alive_b, alive_a);
-        hipLaunchKernelGGL(k_loop_advance, dim3(1), dim3(64), 0, st, state, (const int32_t *)(snap + 8), trace, snap);
+        hipLaunchKernelGGL(k_loop_advance, dim3(1), dim3(64), 0, st, state, (const int32_t *)(snap + 8), trace, snap, freeze ? 1 : 0);
         return sdn_launch_status();
     }
     hipLaunchKernelGGL(k_composite_rays, g, b, 0, st, 0u, 0u, T_thresh, alive_a, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
                        (const int32_t *)state, alive_b, block_totals);
     // n_out doubles as the ticket counter (zero between launches)
-    hipLaunchKernelGGL(k_scatter_advance, g, b, 0, st, alive_a, alive_b, (const uint32_t *)block_totals, state, n_out, trace, snap);
+    hipLaunchKernelGGL(k_scatter_advance, g, b, 0, st, alive_a, alive_b, (const uint32_t *)block_totals, state, n_out, trace, snap, freeze ? 1 : 0);
     return sdn_launch_status();
 }
 
@@ -2354,8 +2359,8 @@ int loop_composite_compact(uint32_t bound_alive, float T_thresh, int32_t *alive_
 int loop_steady_begin(uint32_t bound_alive, const int32_t *alive_a, const int32_t *alive_b, const float *rays_t, const float *rays_o,
                       const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
                       const float *fars, float *xyzs, float *dirs, float *deltas, const uint32_t *cull, uint32_t *live_idx,
-                      uint32_t *live_counts, int32_t *state, const FrameSel &fs, hipStream_t st) {
-    hipLaunchKernelGGL(k_steady_begin, dim3(1), dim3(64), 0, st, state);
+                      uint32_t *live_counts, int32_t *state, const FrameSel &fs, hipStream_t st, bool frozen_already) {
+    if (!frozen_already) hipLaunchKernelGGL(k_steady_begin, dim3(1), dim3(64), 0, st, state);
     return loop_march(bound_alive, alive_a, alive_b, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas,
                       cull, live_idx, live_counts, state, fs, st);
 }

@@ -224,12 +224,12 @@ struct FrameRun {
             if (!rc && recompact) {
                 // composite this iteration on the frozen list, compact it, freeze the shorter list and march the next iteration on it
                 rc = sdn_int::loop_composite_compact(bound, c->T_thresh, c->alive_a, c->alive_b, c->rays_t, c->sigmas, c->rgbs, c->deltas, c->weights_sum,
-                                                     c->depth, c->image, c->state, (uint32_t *)c->block_totals, c->n_out, c->trace, snap_dev, st);
+                                                     c->depth, c->image, c->state, (uint32_t *)c->block_totals, c->n_out, c->trace, snap_dev, st, true);
                 const uint32_t nb = last_alive < bound ? last_alive : bound;     // the new list: at most the rays alive when this iteration began
                 if (!rc)
                     rc = sdn_int::loop_steady_begin(nb, c->alive_a, c->alive_b, c->rays_t, c->rays_o, c->rays_d, c->bound, c->dt_gamma, c->max_steps, c->C,
                                                     c->H, c->bitfield, c->fars, c->xyzs, c->dirs, c->deltas, cull(), c->live_idx, (uint32_t *)c->live_counts,
-                                                    c->state, sdn_int::frame_sel(c), st);
+                                                    c->state, sdn_int::frame_sel(c), st, true);
                 bound = list_bound = nb;
                 recompact = false;
             } else if (!rc)
