@@ -1026,10 +1026,13 @@ __device__ __forceinline__ float *state_tend(const int32_t *__restrict__ state) 
 }
 template <bool FAST>
 __device__ __forceinline__ uint32_t march_ray(MarcherT<FAST> &m, const OccCache &oc, float t, float far, uint32_t n_step, float *px, float *pd,
-                                              float *pl, float *tend = nullptr, uint8_t *psf = nullptr, uint32_t frame = 0) {
+                                              float *pl, float *tend = nullptr, uint8_t *psf = nullptr, uint32_t frame = 0,
+                                              const float *t_begin = nullptr) {
     m.fine = oc.fine; m.fx0 = oc.fx0; m.fy0 = oc.fy0; m.fz0 = oc.fz0; m.fnx = oc.fnx; m.fny = oc.fny; m.fnz = oc.fnz;
     uint32_t step = 0;
-    float last_t = t, x, y, z, dt;
+    // t_begin: the walk resumes at t, a later point of the chain that started at *t_begin (k_cull_start's certified jump): the first
+    // sample's second delta is measured from the chain's start, as the walk from there would have measured it
+    float last_t = t_begin ? *t_begin : t, x, y, z, dt;
     bool go = t < far;
     float t_end = far;
     if (FAST && oc.s_cull && go) {
@@ -1544,7 +1547,7 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
                                                     float *__restrict__ deltas, const float *__restrict__ noises, uint32_t M_pad,
                                                     const uint32_t *__restrict__ cull, uint32_t *__restrict__ live_idx,
                                                     uint32_t *__restrict__ live_count, const int32_t *__restrict__ state,
-                                                    const int32_t *__restrict__ rays_alive_b, FrameSel fs) {
+                                                    const int32_t *__restrict__ rays_alive_b, FrameSel fs, const float *__restrict__ jump) {
     if (state) {  // device-driven loop: sizes, ping-pong side and the iteration's live counter come from the loop state
         n_alive = (uint32_t)state[0];
         n_step = (uint32_t)state[1];
@@ -1553,6 +1556,7 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
         live_count += state[3];
         const uint32_t m0 = n_alive * n_step;
         M_pad = m0 + (128u - m0 % 128u);
+        if (!(state[15] && state[3] == 0)) jump = nullptr;   // the per-ray jump targets of k_cull_start hold for the first march only
         if (blockIdx.x * 256u >= n_alive + 128u) return;   // workgroup-uniform: beyond the list and its alignment tail (the host sizes the grid by a bound)
     }
     __shared__ uint4 s_cull4[FAST ? 256 : 1];  // 32^3 bits = 4 KiB
@@ -1576,8 +1580,10 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
             t += m.step_size(t) * (noises ? noises[n] : 0.0f);
             float *tend = state ? state_tend(state) : nullptr;
             if (tend) tend += index;
-            step = march_ray<FAST>(m, oc, t, fars[index], n_step, xyzs + (size_t)n * n_step * 3, dirs + (size_t)n * n_step * 3,
-                                   deltas + (size_t)n * n_step * 2, tend, grouped ? fs.slot_frame + (size_t)n * n_step : nullptr, frame);
+            const float t_walk = jump ? jump[index] : t;   // (== t where k_cull_start certified no jump)
+            step = march_ray<FAST>(m, oc, t_walk, fars[index], n_step, xyzs + (size_t)n * n_step * 3, dirs + (size_t)n * n_step * 3,
+                                   deltas + (size_t)n * n_step * 2, tend, grouped ? fs.slot_frame + (size_t)n * n_step : nullptr, frame,
+                                   jump ? &t : nullptr);
         }
         if (!grouped) break;
         fcur = block_min_256((frame != kNoFrame && frame > fcur) ? frame : kNoFrame, s_min4);   // (the barriers inside also fence the LDS caches)
@@ -1750,10 +1756,58 @@ __device__ __forceinline__ void publish_snapshot(int32_t *__restrict__ state, in
 // dense waves instead of N-ray launches in which most lanes stop at the cull test.  Nothing observable changes: a ray the test rejects
 // produces no sample and dies in iteration 0 either way, the survivors of iteration 0 -- and therefore every later iteration, every
 // sample and every count -- are the same, and the trace logs N for iteration 0 (state[15], k_loop_advance / k_scatter_advance).
+// The certified jump.  With a constant step every parameter the marcher visits is a point of the lattice L_0 = t, L_(k+1) = fl(L_k + dt);
+// the walk from t visits, of every voxel that holds lattice points, a first one, and leaves it for the first lattice point >= the
+// voxel's exit parameter.  Everything before `t_safe` (ray_may_hit) is >= 2 fine voxels away from any occupied voxel, so the walk emits
+// nothing there -- it only matters WHERE it stands when it gets there.  lattice_floor gives a lattice point L well before t_safe
+// (bit-exact, or it stops early at one); L lies in some run of consecutive lattice points that `locate` puts into the same voxel.
+// If every point q of that run has exit_t(q) <= L_a, the first lattice point behind the run, then the walk, wherever in the run it
+// lands (it cannot jump the run: the exit parameter of the voxel before it is at most a rounding error beyond the run's first
+// point), can never leave it for a point beyond L_a, and every hop advances: L_a is CERTAINLY visited.  The march may start there.
+// Returns t when anything is not provable (binade edge, rounding tie, long run).
+__device__ __forceinline__ float certified_jump(const MarcherT<true> &m, float t, float t_safe) {
+    const float dt = m.dt_const;
+    if (!(t_safe > t + 64.0f * dt)) return t;
+    const float L = lattice_floor(t, dt, t_safe - 18.0f * dt);
+    if (!(L > t)) return t;
+    // closed form of the lattice around L (the conditions of lattice_floor, for the 14 steps either side that are looked at)
+    const float c = (L + dt) - L, err = dt - c;
+    const uint32_t eb = __float_as_uint(L) >> 23;
+    if (!(L >= dt && dt > 0.0f && eb > 30u && eb < 254u)) return t;
+    const float half_ulp = __uint_as_float((eb - 24u) << 23), c_cap = __uint_as_float((eb - 5u) << 23);
+    if (!(fabsf(err) != half_ulp && c < c_cap && c > 0.0f)) return t;
+    if ((__float_as_uint(L - 14.0f * c) >> 23) != eb || (__float_as_uint(L + 14.0f * c) >> 23) != eb) return t;
+    float x, y, z;
+    int vx, vy, vz, nx, ny, nz;
+    m.locate(L, x, y, z, vx, vy, vz);
+    // back to the first lattice point of the run
+    float q = L;
+    int k = 0;
+    for (; k < 12; k++) {
+        const float qm = q - c;
+        if (!(qm > t) || (qm + dt) != q) return t;
+        m.locate(qm, x, y, z, nx, ny, nz);
+        if (nx != vx || ny != vy || nz != vz) break;
+        q = qm;
+    }
+    if (k == 12) return t;
+    // forward over the whole run: the largest exit parameter any of its points computes, and the first point behind it
+    float max_tt = -__FLT_MAX__;
+    for (k = 0; k < 26; k++) {
+        m.locate(q, x, y, z, nx, ny, nz);
+        if (nx != vx || ny != vy || nz != vz) break;
+        max_tt = fmaxf(max_tt, m.exit_t(q, x, y, z, nx, ny, nz));
+        q = q + dt;                                   // the lattice's own recurrence
+    }
+    if (k == 26 || !(max_tt <= q) || !(q < t_safe - 4.0f * dt)) return t;
+    return q;
+}
+
 __global__ void __launch_bounds__(256) k_cull_start(uint32_t N, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                     const float *__restrict__ nears, const float *__restrict__ fars,
                                                     const uint32_t *__restrict__ cull, FrameSel fs, int32_t *__restrict__ alive_a,
-                                                    float *__restrict__ rays_tend) {
+                                                    float *__restrict__ rays_tend, float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
+                                                    uint32_t H, float *__restrict__ jump) {
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
     if (n >= N) return;
     const uint32_t frame = fs.n_frames > 1 ? n / fs.rays_per_frame : 0u;
@@ -1763,13 +1817,17 @@ __global__ void __launch_bounds__(256) k_cull_start(uint32_t N, const float *__r
     const int fnx = meta[3] - fx0 + 1, fny = meta[4] - fy0 + 1, fnz = meta[5] - fz0 + 1;
     const float t = nears[n], far = fars[n];
     bool go = t < far;
-    float t_end = far;
+    float t_end = far, start = t;
     if (go) {
-        go = ray_may_hit(cull_f, rays_o[(size_t)n * 3], rays_o[(size_t)n * 3 + 1], rays_o[(size_t)n * 3 + 2], rays_d[(size_t)n * 3],
-                         rays_d[(size_t)n * 3 + 1], rays_d[(size_t)n * 3 + 2], t, far, t_end, fx0, fy0, fz0, fnx, fny, fnz);
+        MarcherT<true> m;
+        m.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, nullptr);
+        float t_safe;
+        go = ray_may_hit(cull_f, m.ox, m.oy, m.oz, m.dx, m.dy, m.dz, t, far, t_end, fx0, fy0, fz0, fnx, fny, fnz, &t_safe);
         rays_tend[n] = go ? t_end : kTendDead;     // what march_ray would cache on the ray's first march
+        if (go && jump && m.dt_is_const) start = certified_jump(m, t, fminf(t_safe, fminf(far, t_end)));
     }
     alive_a[n] = go ? (int32_t)n : -1;
+    if (jump) jump[n] = start;
 }
 
 // after the compaction of the culled start: the list is in alive_b (side 1), n_out[0] rays long
@@ -2295,11 +2353,14 @@ int loop_begin(uint32_t N, uint32_t max_steps, const float *nears, int32_t *aliv
 // anything when the configuration has no exact cull test (not the FAST configuration, no cull grid, no t_end cache, cooperative marcher).
 int loop_cull_start(uint32_t N, const float *rays_o, const float *rays_d, const float *nears, const float *fars, float bound, float dt_gamma,
                     uint32_t C, uint32_t H, const uint32_t *cull, const FrameSel &fs, int32_t *alive_a, int32_t *alive_b, float *rays_tend,
-                    int32_t *state, uint32_t *block_totals, int32_t *n_out, int32_t *trace, hipStream_t st) {
+                    int32_t *state, uint32_t *block_totals, int32_t *n_out, int32_t *trace, uint32_t max_steps, float *jump, hipStream_t st) {
     static int off = -1;
     if (off < 0) { const char *e = getenv("SDN_CULL_START"); off = (e && e[0] == '0') ? 1 : 0; }
     if (off || !cull || !rays_tend || H != 128 || !fast_config(bound, C, H) || use_group_march(bound, dt_gamma, C, H)) return 0;
-    hipLaunchKernelGGL(k_cull_start, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, N, rays_o, rays_d, nears, fars, cull, fs, alive_a, rays_tend);
+    static int no_jump = -1;
+    if (no_jump < 0) { const char *e = getenv("SDN_CULL_JUMP"); no_jump = (e && e[0] == '0') ? 1 : 0; }
+    hipLaunchKernelGGL(k_cull_start, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, N, rays_o, rays_d, nears, fars, cull, fs, alive_a, rays_tend, bound,
+                       dt_gamma, max_steps, C, H, no_jump ? (float *)nullptr : jump);
     const uint32_t nb = sdn_div_up(N, kScanBlock);
     hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(kScanBlock), 0, st, (const int32_t *)alive_a, N, block_totals, (const int32_t *)nullptr,
                        (const int32_t *)nullptr);
@@ -2312,8 +2373,11 @@ int loop_cull_start(uint32_t N, const float *rays_o, const float *rays_d, const 
 int loop_march(uint32_t bound_alive, const int32_t *alive_a, const int32_t *alive_b, const float *rays_t, const float *rays_o,
                const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
                const float *fars, float *xyzs, float *dirs, float *deltas, const uint32_t *cull, uint32_t *live_idx,
-               uint32_t *live_counts, const int32_t *state, const FrameSel &fs, hipStream_t st) {
+               uint32_t *live_counts, const int32_t *state, const FrameSel &fs, hipStream_t st, const float *jump) {
     const dim3 g(sdn_div_up(bound_alive + 128u, 256u)), b(256);
+    static int no_jump = -1;
+    if (no_jump < 0) { const char *e = getenv("SDN_CULL_JUMP"); no_jump = (e && e[0] == '0') ? 1 : 0; }
+    if (no_jump) jump = nullptr;
     if (use_group_march(bound, dt_gamma, C, H)) {
         if (cull && H != 128) cull = nullptr;
         hipLaunchKernelGGL(k_march_rays_g, dim3(sdn_div_up(bound_alive + 128u, kGW)), b, 0, st, 0u, 0u, alive_a, rays_t, rays_o, rays_d, bound, max_steps, H, grid, fars, xyzs, dirs, deltas,
@@ -2321,10 +2385,11 @@ int loop_march(uint32_t bound_alive, const int32_t *alive_a, const int32_t *aliv
     } else if (fast_config(bound, C, H)) {
         if (cull && H != 128) cull = nullptr;
         hipLaunchKernelGGL(k_march_rays<true>, g, b, 0, st, 0u, 0u, alive_a, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars,
-                           xyzs, dirs, deltas, (const float *)nullptr, 0u, cull, live_idx, live_counts, state, alive_b, fs);
+                           xyzs, dirs, deltas, (const float *)nullptr, 0u, cull, live_idx, live_counts, state, alive_b, fs, cull ? jump : (const float *)nullptr);
     } else {
         hipLaunchKernelGGL(k_march_rays<false>, g, b, 0, st, 0u, 0u, alive_a, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars,
-                           xyzs, dirs, deltas, (const float *)nullptr, 0u, (const uint32_t *)nullptr, live_idx, live_counts, state, alive_b, fs);
+                           xyzs, dirs, deltas, (const float *)nullptr, 0u, (const uint32_t *)nullptr, live_idx, live_counts, state, alive_b, fs,
+                           (const float *)nullptr);
     }
     return sdn_launch_status();
 }
@@ -2362,7 +2427,7 @@ int loop_steady_begin(uint32_t bound_alive, const int32_t *alive_a, const int32_
                       uint32_t *live_counts, int32_t *state, const FrameSel &fs, hipStream_t st, bool frozen_already) {
     if (!frozen_already) hipLaunchKernelGGL(k_steady_begin, dim3(1), dim3(64), 0, st, state);
     return loop_march(bound_alive, alive_a, alive_b, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas,
-                      cull, live_idx, live_counts, state, fs, st);
+                      cull, live_idx, live_counts, state, fs, st, nullptr);
 }
 
 int loop_composite_march(uint32_t bound_list, float T_thresh, int32_t *alive_a, int32_t *alive_b, float *rays_t, const float *rays_o,
@@ -2606,11 +2671,11 @@ static int launch_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *r
         if (cull && H != 128) cull = nullptr;  // the cull grid is built for the 128^3 grid only
         hipLaunchKernelGGL(k_march_rays<true>, g, b, 0, st, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
                            grid, fars, xyzs, dirs, deltas, noises, M_pad, cull, live_idx, live_count, (const int32_t *)nullptr,
-                           (const int32_t *)nullptr, FrameSel());
+                           (const int32_t *)nullptr, FrameSel(), (const float *)nullptr);
     } else {
         hipLaunchKernelGGL(k_march_rays<false>, g, b, 0, st, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
                            grid, fars, xyzs, dirs, deltas, noises, M_pad, (const uint32_t *)nullptr, live_idx, live_count,
-                           (const int32_t *)nullptr, (const int32_t *)nullptr, FrameSel());
+                           (const int32_t *)nullptr, (const int32_t *)nullptr, FrameSel(), (const float *)nullptr);
     }
     return sdn_launch_status();
 }

@@ -35,7 +35,7 @@ int render_begin(const SdnRenderCtx *c, void *mailbox, uint32_t frame_tag, hipSt
         if (!rc && c->rays_tend)
             rc = loop_cull_start(c->N, c->rays_o, c->rays_d, c->nears, c->fars, c->bound, c->dt_gamma, c->C, c->H, (const uint32_t *)c->cull_bits, frame_sel(c),
                                  c->alive_a, c->alive_b, (float *)c->rays_tend, c->state, (uint32_t *)c->block_totals, c->trace + 2 * (size_t)c->n_counters + 8,
-                                 c->trace, st);
+                                 c->trace, c->max_steps, c->sigmas, st);   // (sigmas: unused until the first field launch -- holds the per-ray jump targets)
     }
     return rc;
 }
@@ -104,7 +104,7 @@ int sdn_render_step_f16_ev(const SdnRenderCtx *c, uint32_t bound_alive, void *ev
     if (time_march && ev_field_begin) (void)hipEventRecord((hipEvent_t)ev_field_begin, st);
     int rc = sdn_int::loop_march(bound_alive, c->alive_a, c->alive_b, c->rays_t, c->rays_o, c->rays_d, c->bound, c->dt_gamma, c->max_steps,
                                  c->C, c->H, c->bitfield, c->fars, c->xyzs, c->dirs, c->deltas, cull, c->live_idx,
-                                 (uint32_t *)c->live_counts, c->state, sdn_int::frame_sel(c), st);
+                                 (uint32_t *)c->live_counts, c->state, sdn_int::frame_sel(c), st, c->rays_tend ? c->sigmas : nullptr);
     if (time_march && ev_field_end) (void)hipEventRecord((hipEvent_t)ev_field_end, st);
     if (time_march) ev_field_begin = ev_field_end = nullptr;
     if (rc) return rc;

@@ -21,11 +21,11 @@ int loop_begin(uint32_t N, uint32_t max_steps, const float *nears, int32_t *aliv
                hipStream_t st);
 int loop_cull_start(uint32_t N, const float *rays_o, const float *rays_d, const float *nears, const float *fars, float bound, float dt_gamma,
                     uint32_t C, uint32_t H, const uint32_t *cull, const FrameSel &fs, int32_t *alive_a, int32_t *alive_b, float *rays_tend,
-                    int32_t *state, uint32_t *block_totals, int32_t *n_out, int32_t *trace, hipStream_t st);
+                    int32_t *state, uint32_t *block_totals, int32_t *n_out, int32_t *trace, uint32_t max_steps, float *jump, hipStream_t st);
 int loop_march(uint32_t bound_alive, const int32_t *alive_a, const int32_t *alive_b, const float *rays_t, const float *rays_o,
                const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
                const float *fars, float *xyzs, float *dirs, float *deltas, const uint32_t *cull, uint32_t *live_idx,
-               uint32_t *live_counts, const int32_t *state, const FrameSel &fs, hipStream_t st);
+               uint32_t *live_counts, const int32_t *state, const FrameSel &fs, hipStream_t st, const float *jump = nullptr);
 int loop_composite_compact(uint32_t bound_alive, float T_thresh, int32_t *alive_a, int32_t *alive_b, float *rays_t, const float *sigmas,
                            const float *rgbs, const float *deltas, float *weights_sum, float *depth, float *image, int32_t *state,
                            uint32_t *block_totals, int32_t *n_out, int32_t *trace, int32_t *snap, hipStream_t st, bool freeze = false);

@@ -440,6 +440,41 @@ def test_pipelined_default_configuration_800x800_equals_device_loop():
     assert not torch.equal(outs[0][0], outs[3][0])
 
 
+@pytest.mark.parametrize("kind", ["jumpingjacks", "lego"])
+def test_culled_start_recompaction_and_certified_jump_change_nothing_800x800(kind):
+    """The frame driver's shortcuts (round 3: the cull test of all N rays up front with iteration 0 on the compacted list, the first
+    march starting at a certified later point of each ray's step lattice, the re-compaction of the steady mode's frozen list) against
+    the host-stepped loop over the plain operators, which has none of them: image, depth, weights, the whole trace (iteration 0
+    logs N rays) and the sample count bit for bit -- full 800x800 frames, three cameras / time stamps incl. the canonical t = 0, and a
+    group of four frames through one loop (long frozen list: re-compacted on nearly every iteration) against the frames alone."""
+    from dnerf_amd.bench_scene import build_scene, camera_path
+    from dnerf_amd import fused
+    from dnerf_amd.renderer import render_frame, DeviceLoop
+    sc = build_scene(H=800, W=800, device="cuda", seed=0, kind=kind)
+    ros, rds, times = camera_path(sc, 4)
+    N = 800 * 800
+    loop = DeviceLoop(sc.model, fused.FusedField(sc.model, sc.time, fp16=True), N, "cuda")
+    alone = []
+    for k in range(4):
+        tk = torch.tensor([[times[k]]], dtype=torch.float32, device="cuda")
+        f = fused.FusedField(sc.model, tk, fp16=True)
+        a = render_frame(sc.model, ros[k], rds[k], tk, fp16=True, field=f)
+        b = loop.render(ros[k], rds[k], times[k])
+        torch.cuda.synchronize()
+        assert torch.equal(a["image"], b["image"]), k
+        assert torch.equal(torch.nan_to_num(a["depth"]), torch.nan_to_num(b["depth"])), k
+        assert torch.equal(a["weights_sum"], b["weights_sum"]), k
+        assert [tuple(t) for t in a["trace"]] == [tuple(t) for t in b["trace"]], k
+        assert a["trace"][0][0] == N and a["n_samples"] == b["n_samples"] > 300000
+        alone.append((b["image"].clone(), b["depth"].clone()))
+    group = DeviceLoop(sc.model, fused.FusedField(sc.model, sc.time, fp16=True), 4 * N, "cuda", frames=4)
+    g = group.render(torch.cat(ros), torch.cat(rds), list(times))
+    torch.cuda.synchronize()
+    for k in range(4):
+        assert torch.equal(g["image"][k * N:(k + 1) * N], alone[k][0]), k
+        assert torch.equal(torch.nan_to_num(g["depth"][k * N:(k + 1) * N]), torch.nan_to_num(alone[k][1])), k
+
+
 @pytest.fixture(scope="module")
 def lego_scene():
     from dnerf_amd.bench_scene import build_scene
