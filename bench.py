@@ -196,7 +196,18 @@ def seald_mode(args):
     N = sc.rays_o.shape[0]
     one = DeviceLoop(sc.model, field, N, dev, T_thresh=1e-4, mapper=mapper)
     first = one.render(sc.rays_o, sc.rays_d, sc.time)
-    pl = PipelinedDeviceLoop(sc.model, field, N, dev, contexts=args.contexts, overlap_div=max(1, args.pipeline), T_thresh=1e-4, mapper=mapper)
+    # frames per loop (as in the default mode: a group of 4 copies of the frame through one loop; --group-frames 1 = one frame per loop)
+    F = args.group_frames if args.group_frames > 0 else 4
+    F = max(d for d in range(1, min(F, 16) + 1) if args.steps % d == 0)
+    if F > 1:
+        field = fused.FusedField(sc.model, sc.time, fp16=True, max_points=N * F + 128)
+        grp_o, grp_d = torch.cat([sc.rays_o] * F).contiguous(), torch.cat([sc.rays_d] * F).contiguous()
+        tval = float(sc.time.reshape(-1)[0])
+        grp_t = [tval] * F
+    else:
+        grp_o, grp_d, grp_t = sc.rays_o, sc.rays_d, sc.time
+    pl = PipelinedDeviceLoop(sc.model, field, N * F, dev, contexts=args.contexts, overlap_div=max(1, args.pipeline), T_thresh=1e-4, mapper=mapper, frames=F)
+    n_loops = args.steps // F
     import gc
 
     def timed(fn):
@@ -210,9 +221,10 @@ def seald_mode(args):
         return dt
     for _ in range(args.warmup):
         one.render(sc.rays_o, sc.rays_d, sc.time, want_stats=False)
-    pl.render_frames([sc.rays_o] * args.contexts, [sc.rays_d] * args.contexts, sc.time)
+    times = (lambda k: [grp_t] * k) if F > 1 else (lambda k: sc.time)
+    pl.render_frames([grp_o] * args.contexts, [grp_d] * args.contexts, times(args.contexts))
     dt_one = timed(lambda: [one.render(sc.rays_o, sc.rays_d, sc.time, want_stats=False) for _ in range(args.steps)])
-    dt = timed(lambda: pl.render_frames([sc.rays_o] * args.steps, [sc.rays_d] * args.steps, sc.time))
+    dt = timed(lambda: pl.render_frames([grp_o] * n_loops, [grp_d] * n_loops, times(n_loops)))
     print(json.dumps({"metric": "SealD-NeRF teacher edit render (bbox seal mapper), 800x800 jumpingjacks-like frame", "value": first["n_samples"] * args.steps / dt,
                       "unit": "sampled-points/s", "rays_per_s": N * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
                       "ms_per_step_one_frame_at_a_time": dt_one / args.steps * 1e3, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -220,7 +232,7 @@ def seald_mode(args):
                       "config": {"workload": "BASELINE config 4", "rays": int(N), "sampled_points_per_frame": first["n_samples"],
                                  "loop_iterations": len(first["trace"]), "T_thresh": 1e-4,
                                  "mapper": "SealBBoxMapper: sdn_seal_bbox_map / sdn_seal_modify_hsv inside the native frame driver, between the marcher and the fused field",
-                                 "loop": "device", "frames_in_flight": args.contexts}}))
+                                 "loop": "device", "frames_per_loop": F, "frames_in_flight": f"{args.contexts} loops of {F} frame(s)"}}))
 
 
 def seald_train_mode(args):
