@@ -12,18 +12,26 @@ stats() {  # name, bench args...
   rm -rf $OUT/tmp_$name
 }
 PART=${1:-all}
-if [ "$PART" != "2" ]; then
+if [ "$PART" = "groups" ]; then rm -f $OUT/frame_groups_one_gpu.txt; fi
+if [ "$PART" != "2" ] && [ "$PART" != "groups" ]; then
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || exit 1; echo "bench default done"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2>/dev/null || exit 1; echo "driver cmd done"
 python3 bench.py --steps 20 --pipeline 0 --group-frames 1 --no-cpu-baseline > $OUT/bench_sequential.json 2>/dev/null || exit 1
 python3 bench.py --steps 384 --scene lego --no-cpu-baseline --no-secondary > $OUT/bench_lego.json 2>/dev/null || exit 1
 python3 bench.py --field ops --steps 5 --warmup 1 --static-frame --no-cpu-baseline > $OUT/bench_ops_f16.json 2>/dev/null || exit 1
 echo "bench lines done"
+fi
+if [ "$PART" != "2" ]; then
 for cfg in "--steps 384 --group-frames 1" "--steps 384 --group-frames 2" "--steps 384 --group-frames 4" "--steps 384 --group-frames 8" \
-           "--emulate-rank-of 8 --group-frames 8 --steps 384" "--emulate-rank-of 8 --group-frames 5 --steps 20" "--emulate-rank-of 4 --group-frames 4 --steps 384" "--emulate-rank-of 2 --group-frames 2 --steps 384"; do
+           "--emulate-rank-of 8 --group-frames 16 --steps 384" "--emulate-rank-of 8 --group-frames 8 --steps 384" "--emulate-rank-of 8 --group-frames 10 --steps 20 --warmup 5" \
+           "--emulate-rank-of 4 --group-frames 16 --steps 384" "--emulate-rank-of 4 --group-frames 10 --steps 20 --warmup 5" "--emulate-rank-of 2 --group-frames 8 --steps 384" \
+           "--emulate-rank-of 2 --group-frames 10 --steps 20 --warmup 5" "--steps 20 --warmup 5"; do
   python3 bench.py $cfg --no-cpu-baseline --no-secondary 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}; print(sys.argv[1], '| ms/frame', round(d['ms_per_step'],4), 'points/s', '%.4g'%d['value'], 'repeats', d['repeats'], 'exclusive frac', round(r.get('frac',0),4), 'whole-job', round(r.get('whole_job_mfma_frac',0),4), 'rays/loop', d['config']['rays_per_loop_on_this_gpu'])" "$cfg" >> $OUT/frame_groups_one_gpu.txt || exit 1
 done
 echo "frame groups done"
+fi
+if [ "$PART" = "groups" ]; then cat $OUT/frame_groups_one_gpu.txt; exit 0; fi
+if [ "$PART" != "2" ]; then
 stats default --no-cpu-baseline --no-secondary || exit 1
 stats sequential --steps 20 --warmup 3 --pipeline 0 --group-frames 1 --no-cpu-baseline --no-secondary || exit 1
 stats train --mode train --steps 100 --warmup 10 || exit 1
