@@ -672,16 +672,23 @@ class DeviceLoop:
 
 
 def _context_streams(k, device):
-    """One HIP stream per context.  SDN_CTX_PRIORITIES="p0,p1,..." (HIP stream priorities, -1 high / 0 normal / 1 low, used in turn) creates
-    them with `hipStreamCreateWithPriority` instead of torch's default-priority pool: contexts of different priority do not fall into
-    step with each other (pipelining)."""
+    """One HIP stream per loop context, created here with `hipStreamCreateWithPriority` rather than taken from torch's pool: which
+    hardware queue a pool stream lands on depends on how many of the pool's streams the process has touched before, and a context
+    that shares its queue with another stream loses its overlap (measured, 4 contexts: 0.437 ms per frame with 5-6 hardware queues,
+    0.52 with 7, 8 or 16, 0.49 with 3-4 from the pool; own streams: 0.435-0.439 for 5..9 queues -- profiles/r03_hw_queues.txt).  The
+    process still needs GPU_MAX_HW_QUEUES >= contexts + 1 (set before the HIP runtime starts; bench.py does).
+    SDN_CTX_PRIORITIES="p0,p1,..." (HIP priorities, -1 high / 0 normal / 1 low, used in turn; measured: no effect);
+    SDN_CTX_STREAMS=torch falls back to the pool."""
     import os
-    spec = os.environ.get("SDN_CTX_PRIORITIES", "").strip()
-    if not spec:
+    if os.environ.get("SDN_CTX_STREAMS", "") == "torch":
         return [torch.cuda.Stream(device=device) for _ in range(k)]
     import ctypes
+    spec = os.environ.get("SDN_CTX_PRIORITIES", "").strip() or "0"
     prios = [int(x) for x in spec.split(",")]
-    hip = ctypes.CDLL("libamdhip64.so")
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+    except OSError:
+        return [torch.cuda.Stream(device=device) for _ in range(k)]
     out = []
     with torch.cuda.device(device):
         for i in range(k):
