@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--fp32", action="store_true", help="fp32 field network instead of the -O (fp16) configuration")
     ap.add_argument("--field", default="auto", choices=["auto", "ops", "fused"], help="field network implementation")
     ap.add_argument("--loop", default="auto", choices=["auto", "host", "device"], help="loop driver: per-iteration host sync, or device-driven")
-    ap.add_argument("--time-every", type=int, default=4, help="record the per-launch HIP events of the tracked kernels on every K-th timed step "
+    ap.add_argument("--time-every", type=int, default=8, help="record the per-launch HIP events of the tracked kernels on every K-th timed step "
                     "(each event record costs ~5 us of queue time between two dependent launches; K = 1 instruments every step)")
     ap.add_argument("--pipeline", type=int, default=2, metavar="DIV",
                     help="device loop: render the timed steps as a stream of frames through --contexts loop contexts; the next frame "
@@ -558,7 +558,7 @@ def main():
         # instrumented loops: the last is rendered with nothing else in flight -- the pipeline is draining there anyway -- and its
         # launch durations are the kernel's own (the roofline figure); every `every`-th loop before it is instrumented while it
         # overlaps like all the others (a launch while it shares the device)
-        excl_set = (exclusive_frames(k) if world == 1 else {k - 1}) if every else set()
+        excl_set = (exclusive_frames(k, F) if world == 1 else {k - 1}) if every else set()
         marked = sorted(set(range(0, k, every)) | excl_set) if every else []
         timing = make_timing(len(marked))
         per_frame, it = [None] * k, iter(timing)
@@ -745,7 +745,7 @@ def main():
         if result["roofline"]:
             result["roofline"]["instrumented_steps"] = (
                 f"{n_instrumented} of {n_groups * reps} timed loops (every {every}th" + (", plus the last" if ploop is not None else "") + ")"
-                + (f"; {n_excl} of them (the last" + (" and the quarter points" if n_excl > 1 else "") + ") rendered with nothing else in flight -- their launches give achieved / frac -- and "
+                + (f"; {n_excl} of them (the last" + (" and the quarter points" if n_excl > 2 else (" and the midpoint" if n_excl == 2 else "")) + ") rendered with nothing else in flight -- their launches give achieved / frac -- and "
                    f"{n_instrumented - n_excl} overlapped like the uninstrumented ones (the `overlapped` entry)" if ploop is not None else ""))
             # field FLOPs of the whole timed region over its wall time: a lower bound of the kernel's rate that no overlap can inflate
             result["roofline"]["whole_job_mfma_frac"] = FIELD_FLOP_PER_POINT * n_samples / elapsed / 1e12 / MFMA_F16_PEAK_TFLOPS
@@ -862,13 +862,16 @@ def grid_gather_rate(sc, dev, n_points=196352, launches=20):
     return out
 
 
-def exclusive_frames(k):
-    """Frames of a k-frame stream that are rendered with nothing else in flight so that their launch durations are the kernel's
+def exclusive_frames(k, frames_per_loop=1):
+    """Loops of a k-loop stream that are rendered with nothing else in flight so that their launch durations are the kernel's
     own: the LAST one (the pipeline is draining there anyway: holding it back until its predecessors are done costs the stream a
     fraction of one loop's latency; an exclusive FIRST frame -- round 1 and the start of round 2 -- delays every other context by a
-    whole loop, 7 % of a 20-frame stream).  A stream of >= 64 loops affords three more (quarter points: each holds the pipeline back for
-    about one loop latency, ~1 % of 384 frames together), which makes the figure an average over four different frames."""
-    return {k - 1} | ({k // 4, k // 2, 3 * k // 4} if k >= 64 else set())
+    whole loop, 7 % of a 20-frame stream).  A stream of >= 64 loops affords more (each holds the pipeline back for about one loop
+    latency): the quarter points when a loop is one frame, the midpoint when a loop is a frame group -- the figure is then an average over
+    >= 4 (one frame per loop) / >= 2 x 4 (groups of 4) different frames."""
+    if k < 64:
+        return {k - 1}
+    return {k - 1, k // 2} if frames_per_loop >= 4 else {k - 1, k // 4, k // 2, 3 * k // 4}
 
 
 def roofline(timers, fp16, points_exclusive, points_overlapped=0):
