@@ -1663,7 +1663,9 @@ __global__ void __launch_bounds__(kScanBlock) k_compact_count(const int32_t *__r
 __global__ void __launch_bounds__(kScanBlock) k_compact_scatter(const int32_t *__restrict__ in, uint32_t n, const uint32_t *__restrict__ block_totals,
                                                                 int32_t *__restrict__ out, int32_t *__restrict__ n_out,
                                                                 const int32_t *__restrict__ state, const int32_t *__restrict__ in_b,
-                                                                int32_t *__restrict__ out_b) {
+                                                                int32_t *__restrict__ out_b, uint32_t totals_per_block) {
+    // totals_per_block: block_totals holds one count per (kScanBlock / totals_per_block) entries -- 1: k_compact_count's, 4: the
+    // per-256-ray survivor counts k_composite_rays wrote (the device loop skips the count launch)
     uint32_t last_block = gridDim.x - 1;
     if (state) {
         n = loop_list_len(state);
@@ -1678,7 +1680,7 @@ __global__ void __launch_bounds__(kScanBlock) k_compact_scatter(const int32_t *_
     __shared__ uint32_t lds[16];
     __shared__ uint32_t s_prev;
     uint32_t part = 0;
-    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kScanBlock) part += block_totals[b];
+    for (uint32_t b = threadIdx.x; b < blockIdx.x * totals_per_block; b += kScanBlock) part += block_totals[b];
     uint32_t prev_total;
     block_inclusive_scan(part, lds, prev_total);
     if (threadIdx.x == 0) s_prev = prev_total;
@@ -2365,7 +2367,7 @@ int loop_cull_start(uint32_t N, const float *rays_o, const float *rays_d, const 
     hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(kScanBlock), 0, st, (const int32_t *)alive_a, N, block_totals, (const int32_t *)nullptr,
                        (const int32_t *)nullptr);
     hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(kScanBlock), 0, st, (const int32_t *)alive_a, N, (const uint32_t *)block_totals, alive_b, n_out,
-                       (const int32_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr);
+                       (const int32_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr, 1u);
     hipLaunchKernelGGL(k_cull_advance, dim3(1), dim3(64), 0, st, state, (const int32_t *)n_out, trace);
     return sdn_launch_status();
 }
@@ -2403,13 +2405,12 @@ int loop_composite_compact(uint32_t bound_alive, float T_thresh, int32_t *alive_
         // use the 1024-ray count / scatter pair and a separate one-thread advance instead.  (Measured again in round 3 with the fused pair up
         // to 131 072 / 262 144 / 524 288 rays: 0.449 / 0.451 / 0.451 ms per frame against 0.441 -- every workgroup of the fused scatter pays a
         // device-scope fence for the last-workgroup election.)
+        static_assert(kScanBlock == 1024, "the compositing kernel's 256-ray survivor counts are summed four to a scatter block");
         hipLaunchKernelGGL(k_composite_rays, g, b, 0, st, 0u, 0u, T_thresh, alive_a, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
-                           (const int32_t *)state, alive_b, (uint32_t *)nullptr);
+                           (const int32_t *)state, alive_b, block_totals);          // (+ survivors per 256 rays: no separate count launch)
         const uint32_t nb = sdn_div_up(bound_alive, kScanBlock);
-        hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(kScanBlock), 0, st, (const int32_t *)alive_a, 0u, block_totals,
-                           (const int32_t *)state, (const int32_t *)alive_b);
         hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(kScanBlock), 0, st, (const int32_t *)alive_a, 0u, (const uint32_t *)block_totals,
-                           alive_b, snap + 8, (const int32_t *)state, (const int32_t *)alive_b, alive_a);
+                           alive_b, snap + 8, (const int32_t *)state, (const int32_t *)alive_b, alive_a, 4u);
         hipLaunchKernelGGL(k_loop_advance, dim3(1), dim3(64), 0, st, state, (const int32_t *)(snap + 8), trace, snap, freeze ? 1 : 0);
         return sdn_launch_status();
     }
@@ -2741,7 +2742,7 @@ int sdn_compact_alive(const int32_t *in, uint32_t n, int32_t *out, int32_t *n_ou
     hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(kScanBlock), 0, st, in, n, (uint32_t *)scratch, (const int32_t *)nullptr,
                        (const int32_t *)nullptr);
     hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(kScanBlock), 0, st, in, n, (const uint32_t *)scratch, out, n_out,
-                       (const int32_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr);
+                       (const int32_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr, 1u);
     return sdn_launch_status();
 }
 

@@ -1,11 +1,13 @@
 #!/bin/bash
 set -o pipefail
 OUT=gpurun_out/r03_chk; mkdir -p $OUT
+timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $OUT/tests.log 2>&1; rc=$?; tail -2 $OUT/tests.log; [ $rc -eq 0 ] || exit 1
 run() { # tag args
   local tag=$1; shift
   python3 bench.py "$@" --no-cpu-baseline --no-secondary > $OUT/b_${tag}.json 2>$OUT/b_${tag}.err || return 1
-  python3 -c "import json,sys; d=json.loads(open('$OUT/b_${tag}.json').read().strip().splitlines()[-1]); r=d['roofline']; print('$tag', '$*', 'ms/frame', round(d['ms_per_step'],4), 'whole-job', round(r['whole_job_mfma_frac'],4))"
+  python3 -c "import json,sys; d=json.loads(open('$OUT/b_${tag}.json').read().strip().splitlines()[-1]); r=d['roofline']; print('$tag', '$*', 'ms/frame', round(d['ms_per_step'],4), 'excl', round(r['frac'],4), 'whole-job', round(r['whole_job_mfma_frac'],4), 'lat', round(d['latency_ms_one_loop_at_a_time'],3))"
 }
-for q in 7 8 9 10 11 12 13 14; do GPU_MAX_HW_QUEUES=$q run k8_q$q --steps 384 --contexts 8 || exit 1; done
-for q in 7 8 9 10 11 12; do GPU_MAX_HW_QUEUES=$q run k6_q$q --steps 384 --contexts 6 || exit 1; done
-for q in 4 5 6 7 8 9; do SDN_CTX_PRIORITIES=0 GPU_MAX_HW_QUEUES=$q run k4own_q$q --steps 384 || exit 1; done
+run f4a --steps 384 || exit 1
+run f4b --steps 384 || exit 1
+run drv --steps 20 --warmup 5 || exit 1
+run seq --steps 20 --pipeline 0 --group-frames 1 || exit 1
