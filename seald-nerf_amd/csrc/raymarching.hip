@@ -1805,13 +1805,10 @@ __device__ __forceinline__ float certified_jump(const MarcherT<true> &m, float t
     return q;
 }
 
-__global__ void __launch_bounds__(256) k_cull_start(uint32_t N, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                                                    const float *__restrict__ nears, const float *__restrict__ fars,
-                                                    const uint32_t *__restrict__ cull, FrameSel fs, int32_t *__restrict__ alive_a,
-                                                    float *__restrict__ rays_tend, float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
-                                                    uint32_t H, float *__restrict__ jump) {
-    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
-    if (n >= N) return;
+__device__ __forceinline__ bool cull_start_ray(uint32_t n, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                               const float *__restrict__ nears, const float *__restrict__ fars, const uint32_t *__restrict__ cull,
+                                               const FrameSel &fs, int32_t *__restrict__ alive_a, float *__restrict__ rays_tend, float bound,
+                                               float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, float *__restrict__ jump) {
     const uint32_t frame = fs.n_frames > 1 ? n / fs.rays_per_frame : 0u;
     const uint32_t *__restrict__ cull_f = fs.n_frames > 1 ? cull + (size_t)frame * fs.cull_stride : cull;
     const int *meta = reinterpret_cast<const int *>(cull_f + kCullWords);
@@ -1830,6 +1827,23 @@ __global__ void __launch_bounds__(256) k_cull_start(uint32_t N, const float *__r
     }
     alive_a[n] = go ? (int32_t)n : -1;
     if (jump) jump[n] = start;
+    return go;
+}
+
+__global__ void __launch_bounds__(256) k_cull_start(uint32_t N, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                    const float *__restrict__ nears, const float *__restrict__ fars,
+                                                    const uint32_t *__restrict__ cull, FrameSel fs, int32_t *__restrict__ alive_a,
+                                                    float *__restrict__ rays_tend, float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
+                                                    uint32_t H, float *__restrict__ jump, uint32_t *__restrict__ block_totals) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    bool go = false;
+    if (n < N) go = cull_start_ray(n, rays_o, rays_d, nears, fars, cull, fs, alive_a, rays_tend, bound, dt_gamma, max_steps, C, H, jump);
+    // rays of this 256-ray block that go on: the compaction's scatter sums these (no separate count launch)
+    __shared__ uint32_t s_cnt[4];
+    const unsigned long long m = __ballot(go);
+    if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) block_totals[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
 // after the compaction of the culled start: the list is in alive_b (side 1), n_out[0] rays long
@@ -2362,12 +2376,10 @@ int loop_cull_start(uint32_t N, const float *rays_o, const float *rays_d, const 
     static int no_jump = -1;
     if (no_jump < 0) { const char *e = getenv("SDN_CULL_JUMP"); no_jump = (e && e[0] == '0') ? 1 : 0; }
     hipLaunchKernelGGL(k_cull_start, dim3(sdn_div_up(N, 256u)), dim3(256), 0, st, N, rays_o, rays_d, nears, fars, cull, fs, alive_a, rays_tend, bound,
-                       dt_gamma, max_steps, C, H, no_jump ? (float *)nullptr : jump);
+                       dt_gamma, max_steps, C, H, no_jump ? (float *)nullptr : jump, block_totals);
     const uint32_t nb = sdn_div_up(N, kScanBlock);
-    hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(kScanBlock), 0, st, (const int32_t *)alive_a, N, block_totals, (const int32_t *)nullptr,
-                       (const int32_t *)nullptr);
     hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(kScanBlock), 0, st, (const int32_t *)alive_a, N, (const uint32_t *)block_totals, alive_b, n_out,
-                       (const int32_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr, 1u);
+                       (const int32_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr, 4u);
     hipLaunchKernelGGL(k_cull_advance, dim3(1), dim3(64), 0, st, state, (const int32_t *)n_out, trace);
     return sdn_launch_status();
 }
