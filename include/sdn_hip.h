@@ -334,7 +334,11 @@ typedef struct SdnRenderCtx {
     float min_near;
     int32_t reserved_;
     /* optional [N] scratch: per-ray cache of the cull-grid scan (the parameter beyond which a ray meets no marked cell), so
-     * that only a ray's first march of a frame scans; NULL = scan in every iteration */
+     * that only a ray's first march of a frame scans; NULL = scan in every iteration.  With it (and the H = 128, C = 1, bound = 1
+     * configuration) sdn_render_begin also runs the CULLED START: the scan of all N rays up front, iteration 0 on the compacted
+     * list of the rays that may produce a sample, the first march from a certified later point of each ray's step lattice --
+     * samples, survivors and the trace (which logs N for iteration 0) are unchanged; `sigmas` holds the per-ray start parameters
+     * between sdn_render_begin and the first field launch. */
     float *rays_tend;
     /* optional SealD edit: a bounding-box seal mapper applied to every iteration's samples between the marcher and the field
      * network (sdn_seal_bbox_map) and to the colours of the mapped samples after it (sdn_seal_modify_hsv); NULL = no edit */
