@@ -1567,6 +1567,15 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
     const bool grouped = fs.n_frames > 1;  // kernel-uniform
     const uint32_t frame = (grouped && index >= 0) ? (uint32_t)index / fs.rays_per_frame : (grouped ? kNoFrame : 0u);
     uint32_t step = 0;
+    // the ray's inputs are fetched NOW: they land under the workgroup's barriers and its LDS fill instead of behind them
+    float ro[3] = {0, 0, 0}, rdv[3] = {0, 0, 1}, t_ray = 0, far_ray = 0, t_jump = 0, noise = 0;
+    if (index >= 0) {
+        ro[0] = rays_o[(size_t)index * 3]; ro[1] = rays_o[(size_t)index * 3 + 1]; ro[2] = rays_o[(size_t)index * 3 + 2];
+        rdv[0] = rays_d[(size_t)index * 3]; rdv[1] = rays_d[(size_t)index * 3 + 1]; rdv[2] = rays_d[(size_t)index * 3 + 2];
+        t_ray = rays_t[index]; far_ray = fars[index];
+        if (jump) t_jump = jump[index];
+        if (noises) noise = noises[n];
+    }
     uint32_t fcur = grouped ? block_min_256(frame, s_min4) : 0u;
     while (fcur != kNoFrame) {   // one round per frame present in this workgroup (exactly one without a frame group)
         const uint8_t *grid_f = grouped ? frame_grid_uniform(fs, fcur) : grid;
@@ -1575,13 +1584,13 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
         occ_cache_load<FAST>(cull_f, grid_f, s_cull4, s_fine, oc);
         if (index >= 0 && frame == fcur) {
             MarcherT<FAST> m;
-            m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid_f);
-            float t = rays_t[index];
-            t += m.step_size(t) * (noises ? noises[n] : 0.0f);
+            m.init(ro, rdv, bound, dt_gamma, max_steps, C, H, grid_f);
+            float t = t_ray;
+            t += m.step_size(t) * noise;
             float *tend = state ? state_tend(state) : nullptr;
             if (tend) tend += index;
-            const float t_walk = jump ? jump[index] : t;   // (== t where k_cull_start certified no jump)
-            step = march_ray<FAST>(m, oc, t_walk, fars[index], n_step, xyzs + (size_t)n * n_step * 3, dirs + (size_t)n * n_step * 3,
+            const float t_walk = jump ? t_jump : t;   // (== t where k_cull_start certified no jump)
+            step = march_ray<FAST>(m, oc, t_walk, far_ray, n_step, xyzs + (size_t)n * n_step * 3, dirs + (size_t)n * n_step * 3,
                                    deltas + (size_t)n * n_step * 2, tend, grouped ? fs.slot_frame + (size_t)n * n_step : nullptr, frame,
                                    jump ? &t : nullptr);
         }
@@ -1999,10 +2008,17 @@ __global__ void __launch_bounds__(256) k_composite_march(float T_thresh, int32_t
     uint32_t emitted = 0;
     if (n_alive > 0 && blockIdx.x * 256u < list_len) {  // workgroup-uniform
         const int index = n < list_len ? alive[n] : -1;
-        // composite iteration `it` of this ray; survivors march iteration it + 1 below
+        // composite iteration `it` of this ray; survivors march iteration it + 1 below.  The marcher's inputs are fetched together with
+        // the compositing's (they land under it, the barriers and the LDS fill), and the ray's new t travels in a register
+        float ro[3] = {0, 0, 0}, rdv[3] = {0, 0, 1}, far_ray = 0, t_new = 0;
         if (index >= 0) {
+            if (march_next) {
+                ro[0] = rays_o[(size_t)index * 3]; ro[1] = rays_o[(size_t)index * 3 + 1]; ro[2] = rays_o[(size_t)index * 3 + 2];
+                rdv[0] = rays_d[(size_t)index * 3]; rdv[1] = rays_d[(size_t)index * 3 + 1]; rdv[2] = rays_d[(size_t)index * 3 + 2];
+                far_ray = fars[index];
+            }
             survives = composite_ray(index, n_step, T_thresh, sigmas + (size_t)n * n_step, rgbs + (size_t)n * n_step * 3,
-                                     deltas + (size_t)n * n_step * 2, rays_t, weights_sum, depth, image);
+                                     deltas + (size_t)n * n_step * 2, rays_t, weights_sum, depth, image, &t_new);
             if (!survives) alive[n] = -1;
         }
         const bool marches = survives && march_next;
@@ -2017,10 +2033,10 @@ __global__ void __launch_bounds__(256) k_composite_march(float T_thresh, int32_t
             if (marches && frame == fcur) {
                 float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3, *pl = deltas + (size_t)n * n_step * 2;
                 MarcherT<FAST> m;
-                m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid_f);
+                m.init(ro, rdv, bound, dt_gamma, max_steps, C, H, grid_f);
                 float *tend = state_tend(state);
                 if (tend) tend += index;
-                emitted = march_ray<FAST>(m, oc, rays_t[index], fars[index], n_step, px, pd, pl, tend,
+                emitted = march_ray<FAST>(m, oc, t_new, far_ray, n_step, px, pd, pl, tend,
                                           grouped ? fs.slot_frame + (size_t)n * n_step : nullptr, frame);
             }
             if (!grouped) break;
