@@ -468,8 +468,8 @@ def test_checkpoint_round_trip_through_the_optimizer_and_scaler_state():
       ~lr x sign(gradient) in its first steps, so gradient noise flips whole steps: two UNINTERRUPTED six-step runs from the same
       state differ by up to 2.5 lr in single table entries and 1.8 lr in deformation-MLP weights, 4-9 % of whose elements differ by
       more than 1e-5 (measured: profiles/r03_resume_floor.txt).  That run-to-run floor is measured here (run B against run A)
-      and the resumed run must stay within 3x of it per parameter -- it measures 20-50x BELOW the floor, since its first three steps
-      are run A's own."""
+      and the resumed run must stay within 3x of it per parameter, or inside the floor's recorded envelope -- it measures 20-50x BELOW
+      the floor, since its first three steps are run A's own."""
     from dnerf_amd.network import NeRFNetwork
     from dnerf_amd.train_native import NativeTrainStep
 
@@ -507,10 +507,16 @@ def test_checkpoint_round_trip_through_the_optimizer_and_scaler_state():
     for _ in range(3):
         step2(sc.rays_o, sc.rays_d, target, sc.time)
     torch.cuda.synchronize()
+    # The floor of THIS process (run B against run A) is itself one draw of the noise: for a small tensor it can come out several times
+    # below its usual size (seen once in ~15 runs of the suite: a resumed run 3.x times above that draw).  The resumed run therefore has to
+    # stay within 3x of this draw OR inside the floor's recorded envelope (profiles/r03_resume_floor.txt: max 2.49 lr, mean 0.0054 lr over all
+    # parameters; the resumed run measures 0.05 lr / 2.4e-5 lr) -- a moment, copy or step count that is not restored moves every element by
+    # ~lr per step (mean >= 0.3 lr) and fails both, besides failing the bitwise check above.
     for k, v in model2.named_parameters():
+        lr = 1e-2 if k == "encoder.embeddings" else 1e-3
         floor, got = (B[k] - A[k]).abs(), (v.detach() - A[k]).abs()
-        assert float(got.max()) <= 3 * float(floor.max()) + 1e-7, (k, float(got.max()), float(floor.max()))
-        assert float(got.mean()) <= 3 * float(floor.mean()) + 1e-9, (k, float(got.mean()), float(floor.mean()))
+        assert float(got.max()) <= max(3 * float(floor.max()), 2.5 * lr) + 1e-7, (k, float(got.max()), float(floor.max()))
+        assert float(got.mean()) <= max(3 * float(floor.mean()), 0.006 * lr) + 1e-9, (k, float(got.mean()), float(floor.mean()))
     assert float(step2.adam_steps[0]) == 6 and int(scaler2._growth_tracker) == 6
 
 
