@@ -3,7 +3,8 @@
 (BASELINE.json config[1]: `-O`, i.e. fp16 field network, HIP gridencoder + raymarching + shencoder on one
 MI355X; with --gpus N the frame's rays are sharded N-way and the rendered tiles all-gathered over RCCL).
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W        (N > 1: under torch.distributed.run, or alone -- it then starts the N ranks
+                                                          itself as a child `python -m torch.distributed.run ... bench.py <same args>`)
 
 One "step" = one full pass of the hot path over one batch = one rendered frame (all rays of the frame,
 or this rank's shard of them).  Inputs (rays, weights, occupancy bitfield) are resident in HBM before the
@@ -381,8 +382,31 @@ def density_mode(args):
                                  "op_by_op": "renderer mirror on the HIP operators (the reference's structure)"}}))
 
 
+def self_launch(args):
+    """`python3 bench.py --gpus N` (N > 1) started as ONE process, the shape of the driver's N = 1 command: start the N ranks ourselves as
+    a CHILD process -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    <same arguments>` -- before this process has made any GPU / HIP call (importing torch makes none), relay the child's output (rank 0
+    prints the JSON line) and exit with its code.  Nothing is exec'ed: the parent only waits."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env)
+    raise SystemExit(proc.returncode)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.mode == "render":
+        self_launch(args)
     # One hardware queue per stream in use (the loop contexts + torch's default stream), set before the HIP runtime starts: with the
     # runtime's default of 4 a fifth stream shares a queue with another frame's chain of dependent launches (4 contexts: 0.42 ms per
     # shard-sized frame), with more queues than streams three contexts got slower (0.85 ms); measured best: contexts + 1.
@@ -405,8 +429,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world} (start `python bench.py --gpus N` alone, or under "
+                         f"`python -m torch.distributed.run --nproc-per-node N`)")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
     # rehearsal switch for a one-GPU box: every rank renders on device 0 and the frame is gathered over gloo (host staging);
     # exercises the sharding / gather / timing protocol only -- never use its numbers
