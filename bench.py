@@ -776,6 +776,11 @@ def main():
         if world == 1 and dloop is not None and not args.no_secondary and args.emulate_rank_of <= 1:
             result["roofline_secondary"] = marcher_roofline(dloop, grp_o, grp_d, grp_t, n_groups, distinct, frame_cam, F)
             result["grid_gather_rate"] = grid_gather_rate(sc, dev)
+            # ONE frame with nothing else in flight (F = 1, --pipeline 0): what an interactive edit preview waits for
+            result["latency_ms_one_frame"] = one_frame_latency(sc, field, cam_o, cam_d, cam_t, dev)
+            # the reference's own caller, unchanged, over the drop-in operators: model.render -> run_cuda's loop (dnerf/renderer.py:350-376),
+            # eval + no_grad + fp16 autocast, NeRFNetwork.forward dispatching each iteration's field evaluation to the fused kernel
+            result["reference_shaped"] = reference_shaped(sc, cam_o, cam_d, cam_t)
         if world > 1:
             result["ranks"] = all_rank_stats
         if world == 1 and not args.no_cpu_baseline:
@@ -783,6 +788,48 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def one_frame_latency(sc, field, cam_o, cam_d, cam_t, dev, frames=8):
+    """Median wall time of ONE 800x800 frame rendered alone by the device-driven loop (enqueue -> image complete), over the first frames of
+    the sequence, after one warm-up pass."""
+    from dnerf_amd.renderer import DeviceLoop
+    loop = DeviceLoop(sc.model, field, cam_o[0].shape[0], dev, keep_cull_grids=True)
+    k = min(frames, len(cam_o))
+    for i in range(k):
+        loop.render(cam_o[i], cam_d[i], cam_t[i], want_stats=False)
+    torch.cuda.synchronize()
+    lat = []
+    for i in range(k):
+        t0 = time.perf_counter()
+        loop.render(cam_o[i], cam_d[i], cam_t[i], want_stats=False)
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t0) * 1e3)
+    return sorted(lat)[len(lat) // 2]
+
+
+def reference_shaped(sc, cam_o, cam_d, cam_t, frames=4):
+    """ms per frame of `model.render` (the mirror of the reference's NeRFRenderer.render -> run_cuda, control flow unchanged: march_rays,
+    self(xyzs, dirs, time), composite_rays, boolean-mask compaction with its host read-back every iteration) in the reference's `-O`
+    inference mode: eval, no_grad, fp16 autocast."""
+    model = sc.model.eval()
+    dev = cam_o[0].device
+    k = min(frames, len(cam_o))
+
+    def frame(i):
+        t = torch.tensor([[cam_t[i]]], dtype=torch.float32, device=dev)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            return model.render(cam_o[i][None], cam_d[i][None], t, staged=False, perturb=False, bg_color=1, max_steps=1024)
+    for i in range(k):
+        frame(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(k):
+        frame(i)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / k
+    return {"ms_per_frame": ms, "rays_per_s": cam_o[0].shape[0] / ms * 1e3, "frames": k,
+            "path": "dnerf_amd.NeRFNetwork.render -> run_cuda (reference control flow) on the drop-in operators; field = fused dispatch of NeRFNetwork.forward (sdn_field_forward_f16)"}
 
 
 MARCH_BYTES_PER_SAMPLE = 33.0       # SURVEY 8(d): 32 B written per emitted sample (xyz, dir, 2 deltas) + ~1 B of occupancy bits per probe

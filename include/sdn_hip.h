@@ -207,11 +207,21 @@ uint32_t sdn_field_weight_blocks(void);
  * on the device.  bias0 [128] f32: W0[:,63:76] . freq(t, 6).  offsets_host [17]: level row offsets.  The table may be in the
  * reference's layout (level sizes multiples of 8 rows, grid.py:124) or PADDED -- every level followed by one extra row that
  * repeats the level's row 0 (level sizes == 1 mod 8; the layout is recognised from the offsets) -- which takes the wrap
- * bookkeeping of `(index + 1) % hashmap_size` out of the gather path (dnerf_amd/fused.py builds this layout). */
+ * bookkeeping of `(index + 1) % hashmap_size` out of the gather path -- or the QUAD layout of sdn_field_build_quad_table
+ * (level sizes == 2 mod 8): 16-byte blocks holding the four (x, y) corners of a cell, two gathers per level instead of four
+ * (dnerf_amd/fused.py builds it; the product path). */
 int sdn_field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count,
                           uint32_t M, const void *weights, const float *bias0, const void *table,
                           const int32_t *offsets_host, float S, uint32_t H, float bound, float density_scale,
                           int zero_deform, float *sigmas, float *rgbs, void *stream);
+
+/* The fused kernel's QUAD table from embeddings in the reference's layout (gridencoder/grid.py:118-140; cast to fp16 as grid.py:43-44
+ * does under autocast): embeddings [ref_offsets_host[16], 2] of `dtype` (SDN_F32 / SDN_F16), ref_offsets_host [17] the reference's level
+ * offsets.  out: (ref_offsets_host[16] + 32) blocks of 16 bytes; block ref_offsets_host[l] + 2 l + r holds rows {r, r+1, r+s1, r+s1+1}
+ * of level l (each mod the level's row count; s1 = the row stride of +1 in y of get_grid_index, gridencoder.cu:66-84, 0 if the
+ * dimension is dropped) as fp16 pairs.  Pass offsets_host[l] = ref_offsets_host[l] + 2 l to the field entry points. */
+int sdn_field_build_quad_table(const void *embeddings, int dtype, const int32_t *ref_offsets_host, float S, uint32_t H, void *out,
+                               void *stream);
 
 /* ---------------------------------------------------------------------------
  * density-grid maintenance  (reference: NeRFRenderer.update_extra_state, dnerf/renderer.py:453-555; the network queries of

@@ -50,6 +50,20 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef SDN_STAMPS
+// Diagnostic build only (make diag; the product library has no stamp): raw shader-clock stamps of k_field_f16, stored as they are taken
+// (nothing is kept in registers: the throughput variant has none to spare) by lane 0 of waves 0 and 7 of the first 2048 workgroups.
+// g_field_stamps[(2 wg + w) * 32 + k] (w = 0: wave 0, 1: wave 7):
+//   k = 0 entry  1 point loaded + freq features  2 first stage barrier passed  3 D0 issued  4..9 hidden layers D1..D6 issued
+//   10 last conversion + tail-stage barrier  11 D7 + deformation  12 grid encode  13 sigma net  14 SH + colour net  15 sigmoid + stores
+//   16 HW_ID register (CU / SE / SIMD of the wave)  17 XCC_ID register
+constexpr uint32_t kStampWGs = 2048;
+__device__ unsigned long long g_field_stamps[kStampWGs * 2 * 32];
+#define FSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (stamp_on) { stamp_slot[k] = __builtin_amdgcn_s_memtime(); } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FSTAMP(k) ((void)0)
+#endif
+
 // fragment (1 KiB block) indices inside the packed weight buffer
 constexpr int kBlkD0 = 0;                 // 4 Mt x 4 ks
 constexpr int kBlkD1 = kBlkD0 + 16;       // 6 layers x (4 Mt x 8 ks)
@@ -89,6 +103,7 @@ struct FieldArgs {
     float *sigmas;            // [M]
     float *rgbs;              // [M,3]
     float bound;
+    float inv_2bound;         // 1 / (2 bound) if that is a power of two (the division is then an exact multiplication), else 0
     float density_scale;
     int zero_deform;          // bit f: frame f is at t == 0, the canonical frame (dnerf/network.py:140-141); a single frame uses bit 0
     const uint8_t *slot_frame;  // frame group: frame of every sample slot (selects bias0 + 128 f and bit f of zero_deform), or nullptr
@@ -98,6 +113,10 @@ struct FieldArgs {
     float cell_inv;           // 1 / (grid_size - 1) in fp32: torch divides a tensor by a host scalar as a multiplication by its reciprocal
     float cell_span;          // bound_cas - half_grid   (dnerf/renderer.py:484-488)
     float cell_half;          // half_grid = bound_cas / grid_size
+    // workgroup stagger: workgroups [stagger_lo, stagger_hi) -- the second workgroup of every CU in the launch's first wave of
+    // workgroups -- start `stagger_cycles` shader cycles late, so that the two workgroups of a CU run their matrix and vector phases out
+    // of step (0 = off)
+    uint32_t stagger_cycles, stagger_lo, stagger_hi;
 };
 
 // Morton code -> one coordinate (bits 0, 3, 6, ...): raymarching.cu:282-289
@@ -214,10 +233,19 @@ __device__ __forceinline__ half8 lds_frag(const unsigned char *buf, int blk, uin
 //           fragments is read ahead (256-VGPR budget).
 // CELLS: the density-grid query of update_extra_state (dnerf/renderer.py:453-555): slot p is a Morton cell index, the point is
 //   that cell's jittered centre, only sigma is evaluated and it is stored at sigmas[p] (a slice of tmp_grid).
-// PAD: the table is the PADDED layout (every level followed by one extra row that repeats the level's row 0): the (x, x+1) row
-//   pair of a gather is then always two consecutive rows -- no clamp, no wrap bookkeeping, no patch path.
-template <int OCC, int LA, bool CELLS, bool PAD>
+// LAYOUT of the fp16 table:
+//   kLayoutRef   the reference's (grid.py:118-127): the (x, x+1) pair of a gather is clamped into the level, a wrap is patched;
+//   kLayoutPad   every level followed by one extra row that repeats the level's row 0: the (x, x+1) row pair of a gather is always two
+//                consecutive rows -- no clamp, no wrap bookkeeping, no patch path; 4 gathers of 8 B per level;
+//   kLayoutQuad  one 16-byte BLOCK per row r of a level: rows {r, r+1, r+s1, r+s1+1} (each mod the level's row count) -- the four
+//                (x, y) corners of the cell whose low corner is row r (sdn_field_build_quad_table): 2 gathers of 16 B per level.  The
+//                phase is bound by the rate at which the texture-address unit takes divergent lane addresses (~1 per cycle and CU:
+//                64 gathers per point are as many cycles of that unit as the point's 240 MFMAs are of a matrix pipe), not by bytes:
+//                half the gathers, the same values into the same arithmetic.
+constexpr int kLayoutRef = 0, kLayoutPad = 1, kLayoutQuad = 2;
+template <int OCC, int LA, bool CELLS, int LAYOUT>
 __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, TiledLevels lv) {
+    constexpr bool PAD = LAYOUT != kLayoutRef;   // (no clamp / wrap bookkeeping in either derived layout)
     constexpr int kGridBatch = OCC >= 4 ? 4 : 8;   // grid levels (per lane-half) whose gathers are in flight together (register budget)
     // Two SEPARATE LDS arrays, and a hidden-layer loop unrolled so that every access names its array at compile time: the compiler
     // treats a direct-to-LDS load as a store to LDS and puts `s_waitcnt vmcnt(0)` in front of every later LDS read it cannot prove
@@ -225,8 +253,20 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     // NEXT layer's 32 KiB to land before it issued its first MFMA (found in the ISA; ~600 cycles per layer).
     __shared__ __attribute__((aligned(16))) unsigned char s_w0[kStageBytes];
     __shared__ __attribute__((aligned(16))) unsigned char s_w1[kStageBytes];
-    __shared__ uint4 s_lv[16][2];   // per grid level: {offset, s1, s2, hsize}, {mask, scale, -, -}
+    // (the largest alignment of the three: the LDS layout pass then places it at offset 0, where its 32 per-level reads address it with
+    //  the instructions' 16-bit immediate offsets instead of one v_or_b32 each -- behind the two 32 KiB arrays it sat at 0x10000)
+    __shared__ __attribute__((aligned(4096))) uint4 s_lv[16][2];   // per grid level: {offset, s1, s2, hsize}, {mask, scale, -, -}
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#ifdef SDN_STAMPS
+    const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool stamp_on = ((wave_u == 0u) | (wave_u == 7u)) && lane == 0 && blockIdx.x < kStampWGs;
+    unsigned long long *stamp_slot = g_field_stamps + ((size_t)blockIdx.x * 2 + (wave_u ? 1 : 0)) * 32;
+    FSTAMP(0);
+    if (stamp_on) {
+        stamp_slot[16] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
+        stamp_slot[17] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
+    }
+#endif
     if (threadIdx.x < 16) {         // visible to everyone after the first stage barrier below
         const uint32_t l = threadIdx.x;
         s_lv[l][0] = make_uint4(lv.offset[l], lv.s1[l], lv.s2[l], lv.hsize[l]);
@@ -234,6 +274,10 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     }
     const uint32_t count = P.state ? P.live_count[P.state[3]] : (P.live_idx ? *P.live_count : P.M);
     if (blockIdx.x * (uint32_t)kPointsPerWG >= count) return;  // workgroup-uniform: nothing to do, no barrier touched
+    if (P.stagger_cycles != 0u && blockIdx.x >= P.stagger_lo && blockIdx.x < P.stagger_hi) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)P.stagger_cycles) __builtin_amdgcn_s_sleep(64);
+    }
     const uint32_t n = lane & 31u, h = lane >> 5;
     const uint32_t i = blockIdx.x * (uint32_t)kPointsPerWG + wave * 32u + n;
     const bool valid = i < count;
@@ -275,13 +319,15 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
         float sv[5][3], cv[5][3];
         #pragma unroll
         for (int dd = 0; dd < 3; dd++) {
+            // (v_sin_f32 / v_cos_f32 on revolutions here measured no faster and leave 1.6 % of the fp16 features off the exactly rounded
+            //  value against 0.14 % for this pair and 0.40 % for the reference's own float form: profiles/r04_field_valu_diet.txt)
             fast_sincos(xs[dd] * fscale, sv[0][dd], cv[0][dd]);
             #pragma unroll
             for (int f = 1; f < 5; f++) {
                 const float sp = sv[f - 1][dd], cp = cv[f - 1][dd];
-                const float t = sp * cp;
-                sv[f][dd] = t + t;
-                cv[f][dd] = __builtin_fmaf(sp * -2.0f, sp, 1.0f);
+                const float s2 = sp + sp;                         // (2 s) c and 1 - (2 s) s: the same roundings as 2 (s c) and 1 - 2 s^2
+                sv[f][dd] = s2 * cp;
+                cv[f][dd] = __builtin_fmaf(-s2, sp, 1.0f);
             }
         }
         #pragma unroll
@@ -317,6 +363,7 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     // the second workgroup of a CU made no progress until the first had retired -- two tiles took 28 + 23 us, not ~35).  An MFMA
     // needs the port for 8 of its 32 cycles: with the matrix phases at higher priority the other workgroup's VALU work
     // fills the remaining 24 and the two phases overlap.
+    FSTAMP(1);
     __builtin_amdgcn_s_setprio(2);
 #if SDN_FIELD_STAGGER
     // ---- staggered half-workgroups (cdna_hip_programming.md / MI355X_MICROARCH.md "Two waves per SIMD", item 9) ---------------------------
@@ -336,11 +383,13 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
 #else
     stage_wait_and_sync();  // D0 and D1 are resident
 #endif
+    FSTAMP(2);
     #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
         #pragma unroll
         for (int mt = 0; mt < 4; mt++) acc[mt] = mfma(lds_frag(s_w0, mt * 4 + ks, lane), bf[ks], acc[mt]);
     }
+    FSTAMP(3);
 #if SDN_FIELD_STAGGER
     // One unit: half a hidden layer (k-steps 4 HALF .. 4 HALF + 3), fragments from `cur`; refill (wave-uniform, run time: it depends
     // on the half-workgroup): this wave's four 1-KiB pieces of stage `stage` go to `other`, issued together in front of the MFMAs
@@ -443,11 +492,14 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     #pragma unroll 1
     for (int lp = 0; lp < 3; lp++) {      // layers 2 lp (reads s_w1, refills s_w0) and 2 lp + 1 (the other way round)
         hidden_layer(2 * lp, s_w1, s_w0);
+        FSTAMP(4 + 2 * lp);
         hidden_layer(2 * lp + 1, s_w0, s_w1);
+        FSTAMP(5 + 2 * lp);
     }
     #pragma unroll
     for (int t = 0; t < 4; t++) acc_to_frags<true>(acc[t], bf[2 * t], bf[2 * t + 1]);
     stage_wait_and_sync();  // tail stage (D7 | S0 | S1 | C0 | C1 | C2) resident in buffer 1
+    FSTAMP(10);
 #endif
     const unsigned char *tail = s_w1;
     constexpr int tD7 = 0, tS0 = kBlkS0 - kBlkD7, tS1 = kBlkS1 - kBlkD7, tC0 = kBlkC0 - kBlkD7, tC1 = kBlkC1 - kBlkD7, tC2 = kBlkC2 - kBlkD7;
@@ -468,100 +520,128 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
         #pragma unroll
         for (int c = 0; c < 3; c++) {
             const float xd = ((P.zero_deform >> frame) & 1) ? xs[c] : xs[c] + df[c];
-            u[c] = (xd + P.bound) / (2 * P.bound);  // GridEncoder.forward (grid.py:149)
+            // GridEncoder.forward (grid.py:149): (x + bound) / (2 bound); for 2 bound a power of two the quotient is the exact product
+            u[c] = P.inv_2bound != 0.0f ? (xd + P.bound) * P.inv_2bound : (xd + P.bound) / (2 * P.bound);
         }
     }
     __builtin_amdgcn_s_setprio(0);
+    FSTAMP(11);
     // ---------------- grid encode: lane-half h evaluates levels 8h .. 8h+7 ----------------
     half8 gf[2];
     uint32_t gfw[2][4];   // the same 2 x 8 halfs as packed pairs
     {
         const bool oob = (u[0] < 0) | (u[0] > 1) | (u[1] < 0) | (u[1] > 1) | (u[2] < 0) | (u[2] > 1);
-        // The x and x+1 corners of a (y, z) corner pair are neighbouring table rows, so one 8-byte gather fetches both:
-        // 4 gathers per level instead of 8 (the gather address rate, not bytes, is what this phase is bound by).  The loads of
-        // kGridBatch levels are issued back to back (independent, L2 / Infinity Cache latency overlapped) before any is consumed.
+        const unsigned char *__restrict__ table_bytes = reinterpret_cast<const unsigned char *>(P.table);
+        // Per level: cell coordinates, fractions and the row of the cell's low corner.  The level's constants come from the LDS copy made
+        // at kernel start (two 16-byte reads per level instead of six per-lane selects between kernarg values, which the compiler turns
+        // into six per-lane global loads).
+        //   pos = u scale + 0.5 >= 0.5 for every point that is not zeroed as out of range: the truncating conversion IS floor, and
+        //   v_fract_f32 returns pos - floor(pos), which is exact in fp32 -- the reference's `pos -= (float)pos_grid` (gridencoder.cu:147-151);
+        //   rows: cell coordinates <= 2049 and strides <= 2049^2 < 2^24: the low 32 bits of the 24 x 24-bit products are the uint32
+        //   products of get_grid_index (gridencoder.cu:66-84), wrap-around included (v_mad_u32_u24, not the quarter-rate v_mul_lo_u32);
+        //   `index % hashmap_size` without a division: capped levels have a power-of-two row count (AND); dense levels hold every
+        //   (res+1)^3 corner, so an in-range point never wraps.
+        struct LevelCell { uint32_t offset, s1, s2, hsize, mask, base; };
+        auto level_cell = [&](int li, float (&fr)[3]) {
+            const uint4 k0 = s_lv[8 * h + li][0], k1 = s_lv[8 * h + li][1];
+            LevelCell c;
+            c.offset = k0.x; c.s1 = k0.y; c.s2 = k0.z; c.hsize = k0.w; c.mask = k1.x;
+            const float scale = __uint_as_float(k1.y);
+            uint32_t pg[3];
+            #pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const float q = u[d] * scale + 0.5f;
+                pg[d] = (uint32_t)q;
+                fr[d] = __builtin_amdgcn_fractf(q);
+            }
+            c.base = oob ? 0u : pg[0] + __umul24(pg[1], c.s1) + __umul24(pg[2], c.s2);
+            return c;
+        };
+        // kernel_grid (gridencoder.cu:187-189), scalar_t = at::Half:  results[ch] += w * grid[index + ch]  is
+        //   t = Half(w * float(val));  results = Half(float(results) + float(t))
+        // -- the float product is converted to Half first (the only `Half += x` takes a Half).  The products come from
+        // v_fma_mix_f32 reading the fp16 halves of the gathered word in place (w * val as fma(w, val, -0): the individually
+        // rounded fp32 product), one v_cvt_pk_f16_f32 rounds both channels, and the Half + Half sum is ONE v_pk_add_f16:
+        // for two fp16 operands the fp16-rounded exact sum equals Half(fp32 sum) (24 >= 2 * 11 + 2 bits: no double-rounding
+        // case exists).  4 VALU instructions per corner for both channels.  `corner_bits(idx)` = the half2 of corner idx (bit d set:
+        // +1 along dimension d), in the reference's corner order.
+        auto interpolate = [&](const float (&fr)[3], auto corner_bits) {
+            typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+            half2v accv = {(_Float16)0.0f, (_Float16)0.0f};
+            #pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) {
+                float w = 1;
+                #pragma unroll
+                for (uint32_t d = 0; d < 3; d++) w *= (idx & (1u << d)) ? fr[d] : 1 - fr[d];
+                const uint32_t bits = corner_bits(idx);
+                const half2v t = {(_Float16)mix_mul_lo(w, bits), (_Float16)mix_mul_hi(w, bits)};
+                accv = accv + t;
+            }
+            const uint32_t acc2 = __builtin_bit_cast(uint32_t, accv);
+            return oob ? 0u : acc2;
+        };
         #pragma unroll
         for (int lb = 0; lb < 8 / kGridBatch; lb++) {
-            uint2 pairs[kGridBatch][4];
             float pos[kGridBatch][3];
-            const unsigned char *__restrict__ table_bytes = reinterpret_cast<const unsigned char *>(P.table);
-            uint32_t wrapbits = 0;   // bit 4 lq + c: that gather's x corner is the last row of a capped level (x+1 wraps to row 0)
-            // (tab, row0, mask) of corner pair c of level lq -- also recomputed by the rare wrap patch below instead of being kept
-            auto corner = [&](int lq, uint32_t c, uint32_t &tab, uint32_t &row0, uint32_t &mask, uint32_t &hsize, float (&ps)[3]) {
-                const int li = lb * kGridBatch + lq;
-                // the level's constants come from the LDS copy made at kernel start: two 16-byte reads per level instead of six
-                // per-lane selects between kernarg values (which the compiler turns into six per-lane global loads)
-                const uint4 k0 = s_lv[8 * h + li][0], k1 = s_lv[8 * h + li][1];
-                const uint32_t offset = k0.x, s1 = k0.y, s2 = k0.z;
-                hsize = k0.w;
-                mask = k1.x;
-                const float scale = __uint_as_float(k1.y);
-                tab = offset;   // first row of the level; one row = one half2, addressed as uniform base + 32-bit byte offset
-                uint32_t pg[3];
-                #pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    ps[d] = u[d] * scale + 0.5f;
-                    pg[d] = (uint32_t)floorf(ps[d]);
-                    ps[d] -= (float)pg[d];
-                }
-                const uint32_t base = oob ? 0u : pg[0] + pg[1] * s1 + pg[2] * s2;  // uint32 wrap-around as in get_grid_index
-                // `index % hashmap_size` of get_grid_index without a division: capped levels have a power-of-two row count
-                // (AND); dense levels hold every (res+1)^3 corner, so an in-range point never wraps and x+1 is the next row.
-                row0 = (base + ((c & 1u) ? s1 : 0u) + ((c & 2u) ? s2 : 0u)) & mask;
-            };
-            #pragma unroll
-            for (int lq = 0; lq < kGridBatch; lq++) {
-                #pragma unroll
-                for (uint32_t c = 0; c < 4; c++) {
-                    uint32_t tab, row0, mask, hsize;
-                    corner(lq, c, tab, row0, mask, hsize, pos[lq]);
-                    // the pair (rl, rl + 1) is always inside the level (PAD: row hsize exists and repeats row 0)
-                    const uint32_t rl = PAD ? row0 : min(row0, hsize - 2u);
-                    __builtin_memcpy(&pairs[lq][c], table_bytes + ((tab + rl) << 2), 8);   // 4-byte aligned 8-byte gather
-                    if (!PAD && row0 > rl) wrapbits |= 1u << (4 * lq + (int)c);
-                }
-            }
-            // On a capped level the x corner may be the LAST row: it is then the second row of the pair that was fetched and the
-            // x+1 corner is row 0.  Patched after every gather of the batch has been issued (a branch per gather would make each
-            // wait for its own data); practically never taken (1 row in 2^19).
-            if (!PAD && __builtin_expect(wrapbits != 0u, 0)) {
+            if constexpr (LAYOUT == kLayoutQuad) {
+                // one 16-byte block = the four (x, y) corners of a cell: 2 gathers per level (z and z + 1).  All gathers of the batch are
+                // issued back to back (independent, L2 / Infinity Cache latency overlapped) before any is consumed.
+                uint4 quads[kGridBatch][2];
                 #pragma unroll
                 for (int lq = 0; lq < kGridBatch; lq++) {
+                    const LevelCell c = level_cell(lb * kGridBatch + lq, pos[lq]);
+                    const uint32_t r0 = c.base & c.mask, r1 = (c.base + c.s2) & c.mask;
+                    // (uniform 64-bit base + 32-bit byte offset: the host refuses tables of 2^28 blocks or more)
+                    __builtin_memcpy(&quads[lq][0], table_bytes + ((c.offset + r0) << 4), 16);
+                    __builtin_memcpy(&quads[lq][1], table_bytes + ((c.offset + r1) << 4), 16);
+                }
+                #pragma unroll
+                for (int lq = 0; lq < kGridBatch; lq++) {
+                    const int li = lb * kGridBatch + lq;
+                    gfw[li >> 2][li & 3] = interpolate(pos[lq], [&](uint32_t idx) {
+                        const uint4 &q = quads[lq][idx >> 2];
+                        return (idx & 3u) == 0u ? q.x : ((idx & 3u) == 1u ? q.y : ((idx & 3u) == 2u ? q.z : q.w));
+                    });
+                }
+            } else {
+                // The x and x+1 corners of a (y, z) corner pair are neighbouring table rows, so one 8-byte gather fetches both:
+                // 4 gathers per level instead of 8.
+                uint2 pairs[kGridBatch][4];
+                uint32_t wrapbits = 0;   // bit 4 lq + c: that gather's x corner is the last row of a capped level (x+1 wraps to row 0)
+                #pragma unroll
+                for (int lq = 0; lq < kGridBatch; lq++) {
+                    const LevelCell lc = level_cell(lb * kGridBatch + lq, pos[lq]);
                     #pragma unroll
                     for (uint32_t c = 0; c < 4; c++) {
-                        if ((wrapbits >> (4 * lq + (int)c)) & 1u) {
-                            const int li = lb * kGridBatch + lq;   // wrapped: row0 == mask, so the x+1 corner is row 0 of the level
-                            const uint32_t offset = s_lv[8 * h + li][0].x;
-                            pairs[lq][c].x = pairs[lq][c].y;
-                            pairs[lq][c].y = *reinterpret_cast<const uint32_t *>(table_bytes + (offset << 2));
+                        const uint32_t row0 = (lc.base + ((c & 1u) ? lc.s1 : 0u) + ((c & 2u) ? lc.s2 : 0u)) & lc.mask;
+                        // the pair (rl, rl + 1) is always inside the level (PAD: row hsize exists and repeats row 0)
+                        const uint32_t rl = PAD ? row0 : min(row0, lc.hsize - 2u);
+                        __builtin_memcpy(&pairs[lq][c], table_bytes + ((lc.offset + rl) << 2), 8);   // 4-byte aligned 8-byte gather
+                        if (!PAD && row0 > rl) wrapbits |= 1u << (4 * lq + (int)c);
+                    }
+                }
+                // On a capped level the x corner may be the LAST row: it is then the second row of the pair that was fetched and the
+                // x+1 corner is row 0.  Patched after every gather of the batch has been issued (a branch per gather would make each
+                // wait for its own data); practically never taken (1 row in 2^19).
+                if (!PAD && __builtin_expect(wrapbits != 0u, 0)) {
+                    #pragma unroll
+                    for (int lq = 0; lq < kGridBatch; lq++) {
+                        #pragma unroll
+                        for (uint32_t c = 0; c < 4; c++) {
+                            if ((wrapbits >> (4 * lq + (int)c)) & 1u) {
+                                const int li = lb * kGridBatch + lq;   // wrapped: row0 == mask, so the x+1 corner is row 0 of the level
+                                const uint32_t offset = s_lv[8 * h + li][0].x;
+                                pairs[lq][c].x = pairs[lq][c].y;
+                                pairs[lq][c].y = *reinterpret_cast<const uint32_t *>(table_bytes + (offset << 2));
+                            }
                         }
                     }
                 }
-            }
-            #pragma unroll
-            for (int lq = 0; lq < kGridBatch; lq++) {
-                // kernel_grid (gridencoder.cu:187-189), scalar_t = at::Half:  results[ch] += w * grid[index + ch]  is
-                //   t = Half(w * float(val));  results = Half(float(results) + float(t))
-                // -- the float product is converted to Half first (the only `Half += x` takes a Half).  The products come from
-                // v_fma_mix_f32 reading the fp16 halves of the gathered pair in place (w * val as fma(w, val, -0): the individually
-                // rounded fp32 product), one v_cvt_pk_f16_f32 rounds both channels, and the Half + Half sum is ONE v_pk_add_f16:
-                // for two fp16 operands the fp16-rounded exact sum equals Half(fp32 sum) (24 >= 2 * 11 + 2 bits: no double-rounding
-                // case exists).  4 VALU instructions per corner for both channels.
-                typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-                half2v accv = {(_Float16)0.0f, (_Float16)0.0f};
                 #pragma unroll
-                for (uint32_t idx = 0; idx < 8; idx++) {
-                    float w = 1;
-                    #pragma unroll
-                    for (uint32_t d = 0; d < 3; d++) w *= (idx & (1u << d)) ? pos[lq][d] : 1 - pos[lq][d];
-                    const uint32_t bits = (idx & 1u) ? pairs[lq][idx >> 1].y : pairs[lq][idx >> 1].x;
-                    const half2v t = {(_Float16)mix_mul_lo(w, bits), (_Float16)mix_mul_hi(w, bits)};
-                    accv = accv + t;
+                for (int lq = 0; lq < kGridBatch; lq++) {
+                    const int li = lb * kGridBatch + lq;
+                    gfw[li >> 2][li & 3] = interpolate(pos[lq], [&](uint32_t idx) { return (idx & 1u) ? pairs[lq][idx >> 1].y : pairs[lq][idx >> 1].x; });
                 }
-                uint32_t acc2 = __builtin_bit_cast(uint32_t, accv);
-                if (oob) acc2 = 0u;
-                const int li = lb * kGridBatch + lq;
-                gfw[li >> 2][li & 3] = acc2;
             }
             // keep the batches apart: hoisting the next batch's index math and gathers above this batch's interpolation doubles the
             // live registers (spills under the 128-VGPR cap of the throughput variant)
@@ -574,6 +654,7 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         gf[q] = __builtin_bit_cast(half8, (u32x4){gfw[q][0], gfw[q][1], gfw[q][2], gfw[q][3]});
     }
+    FSTAMP(12);
     // ---------------- sigma net: 32 -> 64 (ReLU) -> 16 ----------------
     f32x16 s0[2];
     #pragma unroll
@@ -592,11 +673,14 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     #pragma unroll
     for (int ks = 0; ks < 4; ks++) hv = mfma(lds_frag(tail, tS1 + ks, lane), sf[ks], hv);
     // h[0] (lane-half 0, register 0) is the density logit; trunc_exp = exp in fp32 of the fp16 value
-    const float sigma = P.density_scale * expf(round_h(hv[0]));
+    // (v_exp_f32 on h log2(e): 1 ulp of the hardware exponential plus |h| 2^-24 from the product -- the reference's own operators use the
+    //  fast intrinsics of their platform here (__expf), and sigma feeds a compositing sum that is compared at 1e-4 / fp16 distance)
+    const float sigma = P.density_scale * __builtin_amdgcn_exp2f(round_h(hv[0]) * 1.4426950408889634f);
     if constexpr (CELLS) {
         if (h == 0 && valid) P.sigmas[p] = sigma;   // duplicates in the list: any one of them wins, as with tmp_grid[indices] = sigmas
         return;
     }
+    FSTAMP(13);
     // ---------------- colour net: [SH(16) ++ geo_feat(15)] -> 64 -> 64 -> 3 ----------------
     half8 cf[2], dummy;
     acc_to_frags<false>(hv, cf[0], dummy);  // registers 0..7 of every lane = h[0..15]; column of h[0] is zero in the packed weights
@@ -640,29 +724,44 @@ __global__ void __launch_bounds__(64 * kWaves, OCC) k_field_f16(FieldArgs P, Til
     for (int r = 0; r < 16; r++) co[r] = 0.0f;
     #pragma unroll
     for (int ks = 0; ks < 4; ks++) co = mfma(lds_frag(tail, tC2 + ks, lane), c2f[ks], co);
+    FSTAMP(14);
     if (h == 0 && valid) {
         P.sigmas[p] = sigma;
         #pragma unroll
         for (int c = 0; c < 3; c++) {
             const float logit = round_h(co[c]);
-            P.rgbs[(size_t)p * 3 + c] = round_h(1.0f / (1.0f + expf(-logit)));  // torch.sigmoid on fp16: fp32 math, fp16 result
+            // torch.sigmoid on fp16: fp32 math, fp16 result
+            P.rgbs[(size_t)p * 3 + c] = round_h(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(logit * -1.4426950408889634f)));
         }
     }
+    FSTAMP(15);
 }
 
-// The reference sizes every level to a multiple of 8 rows (grid.py:124); a PADDED table (one extra row per level repeating the
-// level's row 0, built by dnerf_amd/fused.py) has level sizes == 1 mod 8, so the layout is self-describing.
-bool table_is_padded(const int32_t *offsets_host) {
-    for (uint32_t l = 0; l < 16; l++)
-        if (((uint32_t)(offsets_host[l + 1] - offsets_host[l]) & 7u) != 1u) return false;
-    return true;
+// The reference sizes every level to a multiple of 8 rows (grid.py:124).  The two derived layouts are self-describing through the
+// offsets they come with: a PADDED table (one extra row per level repeating the level's row 0) has level sizes == 1 mod 8, a QUAD table
+// (one 16-byte block per row, two unused blocks behind every level) == 2 mod 8 (dnerf_amd/fused.py builds both).
+int table_layout(const int32_t *offsets_host) {
+    uint32_t seen = 0;
+    for (uint32_t l = 0; l < 16; l++) {
+        const uint32_t r = (uint32_t)(offsets_host[l + 1] - offsets_host[l]) & 7u;
+        seen |= 1u << r;
+    }
+    return seen == 2u ? kLayoutPad : (seen == 4u ? kLayoutQuad : kLayoutRef);
+}
+bool table_is_padded(const int32_t *offsets_host) { return table_layout(offsets_host) == kLayoutPad; }
+
+// 1 / v when v is a (normal) power of two -- x / v == x * (1 / v) exactly for every x -- else 0
+float exact_reciprocal(float v) {
+    int e = 0;
+    if (!(v > 0.0f) || !isfinite(v) || frexpf(v, &e) != 0.5f || e < -100 || e > 100) return 0.0f;
+    return 1.0f / v;
 }
 
 int fill_tiled_levels(TiledLevels &lv, const int32_t *offsets_host, float S, uint32_t H) {
-    const bool padded = table_is_padded(offsets_host);
+    const int layout = table_layout(offsets_host);
     for (uint32_t l = 0; l < 16; l++) {
-        const uint32_t hsize = (uint32_t)(offsets_host[l + 1] - offsets_host[l]) - (padded ? 1u : 0u);
-        if (hsize == 0) return SDN_E_BADARG;
+        const uint32_t hsize = (uint32_t)(offsets_host[l + 1] - offsets_host[l]) - (layout == kLayoutPad ? 1u : (layout == kLayoutQuad ? 2u : 0u));
+        if (hsize == 0 || (uint32_t)offsets_host[16] >= (1u << 28)) return SDN_E_BADARG;   // (32-bit byte offsets into the table)
         const float scale = exp2f((float)l * S) * (float)H - 1.0f;  // gridencoder.cu:138
         const uint32_t res = (uint32_t)ceil((double)scale) + 1;      // gridencoder.cu:139
         // get_grid_index (gridencoder.cu:66-84) for D = 3, align_corners = false, gridtype = tiled:
@@ -685,6 +784,26 @@ int fill_tiled_levels(TiledLevels &lv, const int32_t *offsets_host, float S, uin
     return 0;
 }
 
+// Quad table: block (offset_q[l] + r) of level l = rows {r, r + 1, r + s1, r + s1 + 1} of the level, each mod its row count, as fp16 pairs
+// (the corners (x, y), (x+1, y), (x, y+1), (x+1, y+1) of the cell whose low corner is row r: get_grid_index adds 1 / s1 per step and
+// takes the sum mod the row count, gridencoder.cu:66-84).  T = float or __half (rounded to fp16 as grid.py:43-44's `.half()` does).
+struct QuadLevels { uint32_t src[17]; uint32_t s1[16]; };
+template <typename T>
+__global__ void k_build_quad_table(const T *__restrict__ emb, QuadLevels q, uint4 *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // source row
+    if (i >= q.src[16]) return;
+    uint32_t l = 0;
+    #pragma unroll
+    for (uint32_t k = 1; k < 16; k++) l += (i >= q.src[k]) ? 1u : 0u;
+    const uint32_t a = q.src[l], hs = q.src[l + 1] - a, r = i - a, s1 = q.s1[l];
+    auto row = [&](uint32_t rr) {
+        const T *p = emb + (size_t)(a + rr % hs) * 2;
+        const __half2 v = __halves2half2(__float2half_rn((float)p[0]), __float2half_rn((float)p[1]));
+        return __builtin_bit_cast(uint32_t, v);
+    };
+    out[i + 2u * l] = make_uint4(row(r), row(r + 1u), row(r + s1), row(r + s1 + 1u));
+}
+
 }  // namespace
 
 namespace sdn_int {
@@ -701,6 +820,7 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
     a.xyzs = xyzs; a.dirs = dirs; a.live_idx = live_idx; a.live_count = live_count; a.state = state; a.M = M;
     a.weights = (const unsigned char *)weights; a.bias0 = bias0; a.table = (const __half *)table;
     a.sigmas = sigmas; a.rgbs = rgbs; a.bound = bound; a.density_scale = density_scale; a.zero_deform = zero_deform;
+    a.inv_2bound = exact_reciprocal(2 * bound);
     a.slot_frame = slot_frame;
     a.cell_noise = nullptr; a.cell_seed = 0; a.cell_inv = a.cell_span = a.cell_half = 0;
     const uint32_t wgs = sdn_div_up(M, (uint32_t)kPointsPerWG);
@@ -725,13 +845,26 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
         if (pin == 1) small = false;
         if (pin == 2) small = true;
     }
-    if (table_is_padded(offsets_host)) {
-        if (small) hipLaunchKernelGGL((k_field_f16<2, 8, false, true>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
-        else hipLaunchKernelGGL((k_field_f16<4, 2, false, true>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+    a.stagger_cycles = 0; a.stagger_lo = a.stagger_hi = 0;
+    if (!small) {
+        static int stag = -1;
+        if (stag < 0) {
+            const char *e = getenv("SDN_FIELD_STAGGER_CYCLES");
+            stag = e ? atoi(e) : 0;
+        }
+        a.stagger_cycles = (uint32_t)stag; a.stagger_lo = (uint32_t)cus; a.stagger_hi = 2u * (uint32_t)cus;
+    }
+    const int layout = table_layout(offsets_host);
+    if (layout == kLayoutQuad) {
+        if (small) hipLaunchKernelGGL((k_field_f16<2, 8, false, kLayoutQuad>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+        else hipLaunchKernelGGL((k_field_f16<4, 2, false, kLayoutQuad>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+    } else if (layout == kLayoutPad) {
+        if (small) hipLaunchKernelGGL((k_field_f16<2, 8, false, kLayoutPad>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+        else hipLaunchKernelGGL((k_field_f16<4, 2, false, kLayoutPad>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
     } else {
         // reference-layout table (the public entry point with a caller's own table): one variant only -- with the wrap bookkeeping
-        // the throughput variant does not fit 128 VGPRs without spilling; the padded layout is the product path
-        hipLaunchKernelGGL((k_field_f16<2, 8, false, false>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+        // the throughput variant does not fit 128 VGPRs without spilling; the derived layouts are the product path
+        hipLaunchKernelGGL((k_field_f16<2, 8, false, kLayoutRef>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
     }
     return sdn_launch_status();
 }
@@ -747,16 +880,22 @@ int field_cells_f16(const int32_t *cells, const uint32_t *cell_count, uint32_t n
     a.xyzs = nullptr; a.dirs = nullptr; a.live_idx = (const uint32_t *)cells; a.live_count = cell_count; a.state = nullptr; a.M = n;
     a.weights = (const unsigned char *)weights; a.bias0 = bias0; a.table = (const __half *)table;
     a.sigmas = tmp_slice; a.rgbs = nullptr; a.bound = bound; a.density_scale = density_scale; a.zero_deform = zero_deform ? 1 : 0;
+    a.inv_2bound = exact_reciprocal(2 * bound);
     a.slot_frame = nullptr;
     a.cell_noise = noise; a.cell_seed = seed;
+    a.stagger_cycles = 0; a.stagger_lo = a.stagger_hi = 0;
     const float half_grid = cas_bound / (float)grid_size;
     a.cell_inv = 1.0f / (float)(grid_size - 1); a.cell_span = cas_bound - half_grid; a.cell_half = half_grid;
     const uint32_t wgs = sdn_div_up(n, (uint32_t)kPointsPerWG);
-    if (!table_is_padded(offsets_host)) return SDN_E_UNSUPPORTED;   // the density query is only built for the padded layout
-    if (wgs <= 256u)
-        hipLaunchKernelGGL((k_field_f16<2, 8, true, true>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
-    else
-        hipLaunchKernelGGL((k_field_f16<4, 2, true, true>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+    const int layout = table_layout(offsets_host);
+    if (layout == kLayoutRef) return SDN_E_UNSUPPORTED;   // the density query is only built for the derived layouts
+    if (layout == kLayoutQuad) {
+        if (wgs <= 256u) hipLaunchKernelGGL((k_field_f16<2, 8, true, kLayoutQuad>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+        else hipLaunchKernelGGL((k_field_f16<4, 2, true, kLayoutQuad>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+    } else {
+        if (wgs <= 256u) hipLaunchKernelGGL((k_field_f16<2, 8, true, kLayoutPad>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+        else hipLaunchKernelGGL((k_field_f16<4, 2, true, kLayoutPad>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
+    }
     return sdn_launch_status();
 }
 
@@ -765,6 +904,44 @@ int field_cells_f16(const int32_t *cells, const uint32_t *cell_count, uint32_t n
 extern "C" {
 
 uint32_t sdn_field_weight_blocks(void) { return (uint32_t)kBlkTotal; }
+
+// Builds the fused kernel's QUAD table (16 bytes per row, see kLayoutQuad) from embeddings in the reference layout.
+//   embeddings [ref_offsets_host[16], 2] of dtype (SDN_F32 / SDN_F16), ref_offsets_host [17] the reference's level offsets (grid.py:118-127);
+//   out: (ref_offsets_host[16] + 32) blocks of 16 bytes -- level l starts at block ref_offsets_host[l] + 2 l (pass those 17 values as
+//   `offsets_host` to the field entry points: level sizes == 2 mod 8 announce the layout).
+int sdn_field_build_quad_table(const void *embeddings, int dtype, const int32_t *ref_offsets_host, float S, uint32_t H, void *out, void *stream) {
+    if (!embeddings || !ref_offsets_host || !out || ((uintptr_t)out & 15u) != 0) return SDN_E_BADARG;
+    TiledLevels lv;
+    int rc = fill_tiled_levels(lv, ref_offsets_host, S, H);   // (reference offsets: level sizes are multiples of 8)
+    if (rc) return rc;
+    QuadLevels q;
+    for (int l = 0; l < 17; l++) q.src[l] = (uint32_t)ref_offsets_host[l];
+    for (int l = 0; l < 16; l++) q.s1[l] = lv.s1[l];
+    const uint32_t rows = q.src[16];
+    if (rows == 0) return SDN_E_BADARG;
+    if (hipMemsetAsync(out, 0, ((size_t)rows + 32) * 16, (hipStream_t)stream) != hipSuccess) return sdn_launch_status();
+    if (dtype == SDN_F32)
+        hipLaunchKernelGGL(k_build_quad_table<float>, dim3(sdn_div_up(rows, 256u)), dim3(256), 0, (hipStream_t)stream, (const float *)embeddings, q, (uint4 *)out);
+    else if (dtype == SDN_F16)
+        hipLaunchKernelGGL(k_build_quad_table<__half>, dim3(sdn_div_up(rows, 256u)), dim3(256), 0, (hipStream_t)stream, (const __half *)embeddings, q, (uint4 *)out);
+    else
+        return SDN_E_BADARG;
+    return sdn_launch_status();
+}
+
+#ifdef SDN_STAMPS
+// diagnostic build only: copies out and clears the field kernel's stamp sums (see g_field_stamps)
+// (out: sdn_debug_field_stamp_words() 64-bit words; the buffer is cleared behind the copy)
+uint32_t sdn_debug_field_stamp_words(void) { return kStampWGs * 2 * 32; }
+int sdn_debug_field_stamps(unsigned long long *out) {
+    if (!out) return SDN_E_BADARG;
+    if (hipDeviceSynchronize() != hipSuccess) return sdn_launch_status();
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_field_stamps), sizeof(unsigned long long) * kStampWGs * 2 * 32) != hipSuccess) return sdn_launch_status();
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_field_stamps)) != hipSuccess) return sdn_launch_status();
+    return (int)hipMemset(p, 0, sizeof(unsigned long long) * kStampWGs * 2 * 32);
+}
+#endif
 
 // Fused field forward, `-O` numerics (fp16 MLPs / table, fp32 encoders).  weights: packed by dnerf_amd/fused.py
 // (sdn_field_weight_blocks() KiB); bias0 [128] f32; table fp16 [rows,2]; offsets_host [17] (16 levels).

@@ -12,6 +12,8 @@ k position means for that layer:
   * first colour layer: k-step 0 = the 16 outputs of the sigma net in accumulator order (the density logit gets a
     zero column), k-step 1 = SH coefficient 8h + j.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -103,7 +105,7 @@ def pack_weights(model):
 class FusedField:
     """Callable (xyzs [M,3], dirs [M,3]) -> (sigmas [M] f32, rgbs [M,3] f32) with the reference's -O numerics."""
 
-    def __init__(self, model, time, fp16=True, max_points=None):
+    def __init__(self, model, time, fp16=True, max_points=None, table_layout=None):
         if not fp16:
             raise NotImplementedError("the fused field kernel implements the -O (fp16) configuration; use the op-by-op network for fp32")
         if not available():
@@ -113,17 +115,28 @@ class FusedField:
         dev = enc.embeddings.device
         self.model = model
         self.weights = torch.from_numpy(pack_weights(model)).to(dev).contiguous()
-        # fp16 copy of the table (grid.py:43-44 under autocast) in the PADDED layout: level l moves down by l rows and is followed by
-        # one extra row that repeats its row 0, so that the (x, x+1) row pair of every gather is two consecutive rows even when x is
-        # the level's last row (`(index + 1) % hashmap_size` == 0, gridencoder.cu:66-84) -- the kernel's gather path then needs no
-        # clamp / wrap bookkeeping (csrc/field.hip, PAD variants)
+        # fp16 copy of the table (grid.py:43-44 under autocast) in a layout of the kernel's own (csrc/field.hip, kLayout*):
+        #   "quad" (default): one 16-byte block per row r of a level = rows {r, r+1, r+s1, r+s1+1} mod the level's size -- the four (x, y)
+        #       corners of a cell -- so a level costs TWO gathers instead of four: the phase is bound by the rate at which a CU takes
+        #       divergent gather addresses, not by bytes (4 x the table: 93 MiB for the default geometry, held in the Infinity Cache);
+        #   "pad": level l moves down by l rows and is followed by one extra row that repeats its row 0, so that the (x, x+1) row pair of
+        #       every gather is two consecutive rows even when x is the level's last row (`(index + 1) % hashmap_size` == 0,
+        #       gridencoder.cu:66-84): four 8-byte gathers per level, no clamp / wrap bookkeeping.
+        # Either is recognised by the kernel from the offsets that come with it (level sizes == 2 / 1 mod 8).
+        self.layout = table_layout or os.environ.get("SDN_FIELD_TABLE", "quad")
+        assert self.layout in ("quad", "pad"), self.layout
         off = enc.offsets.cpu().numpy().astype(np.int64)
+        self._ref_offsets = np.ascontiguousarray(off.astype(np.int32))
         self._level_rows = [(int(off[l]), int(off[l + 1])) for l in range(16)]
-        self.offsets_host = np.ascontiguousarray((off + np.arange(17)).astype(np.int32))
-        self.table = torch.empty(int(self.offsets_host[-1]), 2, dtype=torch.float16, device=dev)
-        self.load_table(enc.embeddings)
         self.S = float(np.log2(enc.per_level_scale))
         self.H = int(enc.base_resolution)
+        if self.layout == "quad":
+            self.offsets_host = np.ascontiguousarray((off + 2 * np.arange(17)).astype(np.int32))
+            self.table = torch.empty(int(self.offsets_host[-1]), 4, 2, dtype=torch.float16, device=dev)
+        else:
+            self.offsets_host = np.ascontiguousarray((off + np.arange(17)).astype(np.int32))
+            self.table = torch.empty(int(self.offsets_host[-1]), 2, dtype=torch.float16, device=dev)
+        self.load_table(enc.embeddings)
         self.bound = float(model.bound)
         self.density_scale = float(model.density_scale)
         self._time_cache, self._group_cache = {}, {}
@@ -134,7 +147,15 @@ class FusedField:
 
     @torch.no_grad()
     def load_table(self, embeddings):
-        """(Re)fills the padded fp16 table from the network's embeddings [rows, 2] (any float dtype)."""
+        """(Re)fills the kernel's fp16 table from the network's embeddings [rows, 2] (float32 or float16, reference layout)."""
+        if self.layout == "quad":
+            emb = embeddings.detach()
+            if emb.dtype not in (torch.float32, torch.float16):
+                emb = emb.float()
+            emb = emb.contiguous()
+            check(sdn_backend.lib.sdn_field_build_quad_table(ptr(emb), sdn_backend.dtype_id(emb.dtype), self._ref_offsets.ctypes.data,
+                                                             self.S, self.H, ptr(self.table), stream()), "field_build_quad_table")
+            return
         for l, (a, b) in enumerate(self._level_rows):
             dst = int(self.offsets_host[l])
             self.table[dst:dst + (b - a)].copy_(embeddings[a:b])

@@ -5,11 +5,14 @@ parameter names (`encoder_deform`, `encoder_time`, `deform_net.{l}.weight`, `enc
 `encoder.offsets`, `sigma_net`, `encoder_dir`, `color_net`), so a reference checkpoint's model state
 dict loads with `strict=False` exactly as the reference's own loader does (nerf/utils.py:1095-1154).
 
-Two evaluation paths produce the same numbers:
+Two evaluation paths:
   * `forward` / `density` / `color`  -- the reference's op sequence on the drop-in operators
     (`freq_encode`, `grid_encode`, `sh_encode`) with the MLPs as `F.linear` calls; differentiable.
-  * `forward_fused` -- the MI355X-native inference path (fused encoders + MLPs on MFMA, see
-    csrc/field.hip) used by the native render loop when available.
+  * the fused dispatch inside `forward`: in eval mode, without autograd, under fp16 autocast (the reference's `-O`) and with
+    the default geometry the whole network is ONE launch of the fused MFMA kernel (csrc/field.hip, `sdn_field_forward_f16`), so the
+    reference-shaped loop of `run_cuda` (dnerf/renderer.py:350-376; SealDNeRF/renderer.py:250-276 with the mapper hooks) costs
+    march + one field launch + composite per iteration.  Same numbers as the native loops' field (`FusedField`), fp16 distance
+    from the op-by-op path; `model.fused_inference = False` switches it off.
 """
 import torch
 import torch.nn as nn
@@ -106,8 +109,53 @@ class NeRFNetwork(NeRFRenderer):
         h = torch.cat([self.encoder_dir(d), geo_feat], dim=-1)
         return torch.sigmoid(_run_mlp(self.color_net, h))
 
+    # -- fused inference dispatch -----------------------------------------------------------------
+    fused_inference = True       # class default; set False on a model to keep `forward` on the op-by-op path in every mode
+
+    def _fused_inference_ok(self, x, d):
+        if not self.fused_inference or self.training or torch.is_grad_enabled() or not x.is_cuda or x.dim() != 2 or x.shape[0] == 0:
+            return False
+        if not torch.is_autocast_enabled("cuda") or torch.get_autocast_dtype("cuda") != torch.float16:
+            return False       # fp32 evaluation has no fused kernel: the op-by-op path meets the 1e-4 bar
+        if x.dtype != torch.float32 or d.dtype != torch.float32:
+            return False
+        from . import fused
+        enc = self.encoder
+        return (fused.available() and len(self.deform_net) == 8 and self.hidden_dim_deform == 128 and self.hidden_dim == 64
+                and self.num_layers == 2 and self.geo_feat_dim == 15 and self.num_layers_color == 3 and self.hidden_dim_color == 64
+                and enc.gridtype == "tiled" and not enc.align_corners and enc.interpolation == "linear" and enc.num_levels == 16
+                and enc.level_dim == 2)
+
+    def _parameter_epoch(self):
+        ps = [self.encoder.embeddings] + [l.weight for l in self.deform_net] + [l.weight for l in self.sigma_net] + [l.weight for l in self.color_net]
+        return tuple((p.data_ptr(), p._version) for p in ps)
+
+    def _forward_fused(self, x, d, t):
+        """sigma [M] f32 (trunc_exp, density_scale NOT applied: the caller multiplies, dnerf/renderer.py:368), rgb [M,3] (the fp16 values
+        of torch.sigmoid on the half logits, held in f32), deform = None (callers of the inference branch discard it)."""
+        from . import fused
+        epoch = self._parameter_epoch()
+        cache = self.__dict__.get("_fused_cache")
+        if cache is None or cache[0] != epoch[1:]:
+            # (the fp16 table cast of grid.py:43-44 and the packed weights are made once per parameter version, not once per call)
+            field = fused.FusedField(self, t, fp16=True)
+            field.density_scale = 1.0
+            cache = (epoch[1:], field, epoch[0])
+            self.__dict__["_fused_cache"] = cache
+        elif cache[2] != epoch[0]:
+            cache[1].load_table(self.encoder.embeddings.detach())
+            cache = (cache[0], cache[1], epoch[0])
+            self.__dict__["_fused_cache"] = cache
+        field = cache[1]
+        field.set_time(t)          # by VALUE: one host read of t, where the reference's `if t == 0` reads it too (network.py:140)
+        field._buf = None          # fresh output tensors per call (caching allocator, no launch): the caller owns them, as on the op-by-op path
+        sig, rgb = field(x.contiguous(), d.contiguous())
+        return sig, rgb, None
+
     def forward(self, x, d, t):
         """x [M,3] in [-bound,bound], d [M,3] unit, t [1,1] -> sigma [M], rgb [M,3], deform [M,3]  (network.py:123-169)."""
+        if self._fused_inference_ok(x, d):
+            return self._forward_fused(x, d, t)
         deform = self._deform(x, t)
         if t == 0:  # canonical frame: no deformation (device compare => host sync, as in the reference :140)
             deform = torch.zeros_like(x)

@@ -444,11 +444,19 @@ def render_frame(model, rays_o, rays_d, time, fp16=False, dt_gamma=0.0, max_step
 def _field_eval(model, time, fp16):
     """Op-by-op field evaluation (the reference's network on the drop-in operators), fp32 outputs."""
     def run(xyzs, dirs):
-        if fp16:
-            with torch.autocast("cuda", dtype=torch.float16):
+        keep = model.__dict__.get("fused_inference")
+        model.fused_inference = False          # this IS the op-by-op path: never the fused dispatch of NeRFNetwork.forward
+        try:
+            if fp16:
+                with torch.autocast("cuda", dtype=torch.float16):
+                    sigmas, rgbs, _ = model(xyzs, dirs, time)
+            else:
                 sigmas, rgbs, _ = model(xyzs, dirs, time)
-        else:
-            sigmas, rgbs, _ = model(xyzs, dirs, time)
+        finally:
+            if keep is None:
+                del model.fused_inference
+            else:
+                model.fused_inference = keep
         return (model.density_scale * sigmas).float().contiguous(), rgbs.float().contiguous()
     return run
 
@@ -588,9 +596,18 @@ class DeviceLoop:
         (`model.iter_density` counts the updates) or `invalidate_cull_grids()` is called: a slice is rendered many times in between,
         and deriving its cull grid again is two launches at the head of every frame's latency chain (eight grids per frame group)."""
         import sdn_backend as B
-        cache = DeviceLoop._cull_cache.setdefault(id(self.model), {"epoch": None, "grids": {}})
-        if cache["epoch"] != (self.model.iter_density, self.model.density_bitfield.data_ptr()):
-            cache["epoch"], cache["grids"] = (self.model.iter_density, self.model.density_bitfield.data_ptr()), {}
+        # The kept grid carries the slice's occupancy bits themselves (the packed fine-bit image the marchers copy to LDS), so a stale
+        # entry means marching on stale OCCUPANCY: the epoch includes the bitfield's version counter -- load_state_dict, fill_bitfield
+        # and reset_extra_state rewrite the bitfield in place without a new iter_density -- and the cache lives ON the model object
+        # (an id()-keyed table would hand a new model the entry of a collected one whose id Python reused).
+        cache = self.model.__dict__.get("_sdn_cull_cache")
+        if cache is None:
+            cache = {"epoch": None, "grids": {}}
+            self.model.__dict__["_sdn_cull_cache"] = cache
+        bf = self.model.density_bitfield
+        epoch = (self.model.iter_density, bf.data_ptr(), bf._version)
+        if cache["epoch"] != epoch:
+            cache["epoch"], cache["grids"] = epoch, {}
         hit = cache["grids"].get(t_idx)
         if hit is None:
             hit = torch.empty(int(B.lib.sdn_cull_grid_bytes()), dtype=torch.uint8, device=self.model.density_bitfield.device)
@@ -598,16 +615,13 @@ class DeviceLoop:
             cache["grids"][t_idx] = hit
         return hit
 
-    _cull_cache = {}
-
     @staticmethod
     def invalidate_cull_grids(model=None):
-        """Forget kept cull grids (of `model`, or all): call after writing `density_bitfield` by any other means than
-        `update_extra_state` (e.g. `seal_mapper.fill_bitfield`, a checkpoint load)."""
-        if model is None:
-            DeviceLoop._cull_cache.clear()
-        else:
-            DeviceLoop._cull_cache.pop(id(model), None)
+        """Forget the kept cull grids of `model`: only needed after writing `density_bitfield` behind torch's back (a raw pointer, DLPack,
+        a custom kernel) -- torch-level writes (`update_extra_state`, `fill_bitfield`, `load_state_dict`, `copy_`) bump the tensor's
+        version counter and are seen by themselves."""
+        if model is not None:
+            model.__dict__.pop("_sdn_cull_cache", None)
 
     def bind(self, rays_o, rays_d, time):
         """Points the context at this frame's rays and time constants (the native driver launches near_far_from_aabb itself)."""

@@ -52,6 +52,7 @@ PROTOTYPES = {
     "sdn_seal_bbox_map": [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sdn_seal_modify_hsv": [_vp, _vp, _u32, _f32, _f32, _f32, _vp],
     "sdn_field_forward_f16": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _f32, _u32, _f32, _f32, _i32, _vp, _vp, _vp],
+    "sdn_field_build_quad_table": [_vp, _i32, _vp, _f32, _u32, _vp, _vp],
     "sdn_density_query_cells_f16": [_vp, _vp, _u32, _vp, _u32, _u32, _f32, _vp, _vp, _vp, _vp, _f32, _u32, _f32, _f32, _i32, _vp, _vp],
     "sdn_density_grid_ema": [_vp, _vp, ctypes.c_uint64, _f32, _vp, _vp],
     "sdn_density_grid_pack": [_vp, ctypes.c_uint64, _vp, _f32, _vp, _vp, _vp],
@@ -264,10 +265,33 @@ class KernelTimers:
 timers = None  # set to a KernelTimers instance to enable
 
 
+_launch_log = None  # a list while a `launch_log` context is open
+
+
+class launch_log:
+    """`with launch_log(out): ...` appends (kernel family, units) of every native launch that goes through `timed` to the list `out`
+    (tests use it to see WHICH operators a caller ran -- e.g. that a reference-shaped loop took the fused dispatch)."""
+
+    def __init__(self, out):
+        self.out = out
+
+    def __enter__(self):
+        global _launch_log
+        self.prev, _launch_log = _launch_log, self.out
+        return self.out
+
+    def __exit__(self, *exc):
+        global _launch_log
+        _launch_log = self.prev
+        return False
+
+
 class timed:
     """`with timed("grid_encode_fwd", B): launch(...)` -- no-op unless `sdn_backend.timers` is set."""
 
     def __init__(self, name, units):
+        if _launch_log is not None:
+            _launch_log.append((name, units))
         self.ev = timers.record(name, units) if timers is not None else None
 
     def __enter__(self):

@@ -74,6 +74,43 @@ def test_native_device_loop_f16_reproduces_reference_run_cuda(model_bits, case, 
     print(case, "distance to the reference fixture:", st)
 
 
+@pytest.mark.parametrize("case,kw", CASES)
+def test_reference_shaped_loop_with_the_fused_dispatch_f16(model_bits, case, kw):
+    """`model.render` -- the reference's run_cuda control flow, unchanged (dnerf/renderer.py:350-376) -- in eval mode under fp16 autocast:
+    `NeRFNetwork.forward` dispatches every iteration's field evaluation to the fused MFMA kernel.  The image is bit-identical to
+    `render_frame(..., field=FusedField)` (same operators, same kernel, same schedule) and within the -O bars of the reference fixture."""
+    from dnerf_amd.fused import FusedField
+    from dnerf_amd.renderer import render_frame
+    fx = load("infer")
+    sc = fixture_scene("cuda", model_bits=model_bits, **kw)
+    sc.model.eval()
+    launches = []
+    import sdn_backend
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        with sdn_backend.launch_log(launches):
+            a = sc.model.render(sc.rays_o[None], sc.rays_d[None], sc.time, staged=False, perturb=False, bg_color=None)
+    names = [n for n, _ in launches]
+    assert "field_forward_f16" in names and not any(n.startswith("grid_encode") for n in names), names[:12]
+    b = render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=True, field=FusedField(sc.model, sc.time))
+    assert torch.equal(a["image"][0], b["image"]) and torch.equal(torch.nan_to_num(a["depth"][0]), torch.nan_to_num(b["depth"]))
+    from tests_support import assert_dist
+    print(case, "reference-shaped -O loop vs reference run_cuda (fp32):",
+          assert_dist(a["image"][0].cpu().numpy(), fx[f"{case}_image"], "image, reference-shaped -O loop vs reference run_cuda (fp32)",
+                      max=2e-3, p999=5e-4, p99=2.5e-4, mean=1e-5, frac_above_1e3=5e-4))
+    # a parameter update is picked up (the packed weights and the fp16 table are cached per parameter version)
+    with torch.no_grad():
+        sc.model.sigma_net[1].weight.mul_(1.5)
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            c = sc.model.render(sc.rays_o[None], sc.rays_d[None], sc.time, staged=False, perturb=False, bg_color=None)
+        assert not torch.equal(c["image"], a["image"])
+        d = render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=True, field=FusedField(sc.model, sc.time))
+        assert torch.equal(c["image"][0], d["image"])
+    finally:
+        with torch.no_grad():
+            sc.model.sigma_net[1].weight.div_(1.5)
+
+
 @pytest.mark.parametrize("t", [0.0, 0.5])
 def test_field_network_reproduces_reference_forward(model_bits, t):
     from dnerf_amd.fused import FusedField

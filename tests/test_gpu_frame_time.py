@@ -185,3 +185,28 @@ def test_kept_cull_grids_change_nothing_and_follow_the_bitfield(model_bits):
         model.density_bitfield.copy_(saved)
         DeviceLoop.invalidate_cull_grids(model)
     assert torch.equal(kept.render(cams[0][0], cams[0][1], times[0])["image"], want[0])
+
+
+def test_kept_cull_grids_follow_in_place_rewrites_of_the_occupancy(model_bits):
+    """`DeviceLoop(keep_cull_grids=True)` keeps the marcher's coarse grid -- which carries the slice's packed occupancy bits -- per time
+    slice.  `load_state_dict`, `fill_bitfield` and `reset_extra_state` rewrite `density_bitfield` in place without a new `iter_density`:
+    the cache must notice (tensor version).  An emptied occupancy renders the background; restored in place, the frame is again the
+    frame of a loop that keeps nothing, bit for bit."""
+    from dnerf_amd.fused import FusedField
+    from dnerf_amd.renderer import DeviceLoop
+    model, _ = model_bits
+    sc = fixture_scene("cuda", model_bits=model_bits)
+    field = FusedField(model, sc.time)
+    kept = DeviceLoop(model, field, sc.rays_o.shape[0], "cuda", keep_cull_grids=True)
+    plain = DeviceLoop(model, field, sc.rays_o.shape[0], "cuda")
+    want = plain.render(sc.rays_o, sc.rays_d, sc.time)["image"].clone()
+    assert torch.equal(kept.render(sc.rays_o, sc.rays_d, sc.time)["image"], want) and float(want.min()) < 0.99
+    keep = model.density_bitfield.clone()
+    try:
+        model.density_bitfield.zero_()
+        blank = kept.render(sc.rays_o, sc.rays_d, sc.time)
+        assert blank["n_samples"] == 0 and bool((blank["image"] == 1).all())
+        model.density_bitfield.copy_(keep)                   # in place: iter_density unchanged
+        assert torch.equal(kept.render(sc.rays_o, sc.rays_d, sc.time)["image"], want)
+    finally:
+        model.density_bitfield.copy_(keep)

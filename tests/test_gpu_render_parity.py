@@ -153,9 +153,18 @@ def test_fused_field_f16_vs_ops_path_and_oracle(small_scene):
     f = fused.FusedField(sc.model, sc.time, fp16=True)
     s_f, c_f = f(x, d)
     s_f, c_f = s_f.clone(), c_f.clone()
-    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-        s_o, c_o, _ = sc.model(x, d, sc.time)
+    sc.model.fused_inference = False      # the op-by-op network (eval + no_grad + autocast would otherwise dispatch to the fused kernel itself)
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            s_o, c_o, deform = sc.model(x, d, sc.time)
+    finally:
+        del sc.model.fused_inference
+    assert deform is not None and c_o.dtype == torch.float16
     s_o, c_o = s_o.float(), c_o.float()
+    # ... and the dispatch: the same call with the switch at its default IS the fused kernel (density_scale left to the caller)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        s_d, c_d, none = sc.model.eval()(x, d, sc.time)
+    assert none is None and torch.equal(s_d * sc.model.density_scale, s_f) and torch.equal(c_d, c_f)
     # fp16-distance bars (the benchmarked path: -O numerics), stated as a distribution: sigma relative to max(|sigma|, 1e-3), colours
     # absolute.  Measured (MI355X, round 3): sigma vs op-by-op max 3.9e-3 / p99.9 2.0e-3 / p99 0 (isolated fp16 rounding flips of the
     # density logit, 1 ulp = 1e-3 relative after exp), 23 of 5000 above 1e-3; rgb max 4.9e-4, none above 1e-3; vs the fp16 oracle the same.
@@ -576,3 +585,42 @@ def test_one_pass_ray_batch_render_reports_a_short_sample_buffer():
         tight.render(sc.rays_o, sc.rays_d, sc.time, check=True)
     with pytest.raises(ValueError):
         tight.render(sc.rays_o[:100], sc.rays_d[:100], sc.time)
+
+
+def test_quad_table_layout_is_the_padded_layout_bit_for_bit(small_scene):
+    """The fused kernel's QUAD table (16-byte blocks of a cell's four (x, y) corners, two gathers per level) against the PADDED layout
+    (8-byte row pairs, four gathers per level): the same table values into the same arithmetic, so sigma and rgb are bit-identical; and
+    the blocks themselves are rows {r, r+1, r+s1, r+s1+1} mod the level size of the fp16-cast embeddings (get_grid_index,
+    gridencoder.cu:66-84)."""
+    from dnerf_amd import fused
+    from dnerf_amd.bench_scene import _probe_points
+    sc = small_scene
+    rng = np.random.default_rng(5)
+    pts = _probe_points(sc.bitfield, 6000, 7) + rng.uniform(-0.01, 0.01, (6000, 3)).astype(np.float32)
+    pts[:4] = [[1.0, 1.0, 1.0], [-1.0, -1.0, -1.0], [0.9999, -0.9999, 0.9999], [1.2, 0.0, 0.0]]      # the domain's corners, one point outside
+    x = torch.from_numpy(pts.astype(np.float32)).cuda()
+    d = torch.nn.functional.normalize(torch.randn(6000, 3, device="cuda"), dim=1).contiguous()
+    fq = fused.FusedField(sc.model, sc.time, table_layout="quad")
+    fp = fused.FusedField(sc.model, sc.time, table_layout="pad")
+    assert fq.table.shape[1:] == (4, 2) and fp.table.dim() == 2
+    for t in (0.5, 0.0):
+        fq.set_time(t); fp.set_time(t)
+        sq, cq = fq(x, d)
+        sp, cp = fp(x, d)
+        assert torch.equal(sq, sp) and torch.equal(cq, cp)
+    # block contents, level by level
+    enc = sc.model.encoder
+    emb = enc.embeddings.detach().half().cpu().numpy()
+    off = enc.offsets.cpu().numpy().astype(np.int64)
+    tq = fq.table.cpu().numpy()
+    S, H = np.float32(np.log2(enc.per_level_scale)), enc.base_resolution
+    for l in range(16):
+        a, b = int(off[l]), int(off[l + 1])
+        hs = b - a
+        scale = np.exp2(np.float32(l) * S, dtype=np.float32) * np.float32(H) - np.float32(1.0)
+        res = int(np.ceil(np.float64(scale))) + 1
+        s1 = res + 1 if res + 1 <= hs else 0
+        r = np.arange(hs)
+        want = np.stack([emb[a + r], emb[a + (r + 1) % hs], emb[a + (r + s1) % hs], emb[a + (r + s1 + 1) % hs]], axis=1)
+        got = tq[a + 2 * l: a + 2 * l + hs]
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), l
