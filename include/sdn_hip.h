@@ -215,6 +215,11 @@ int sdn_field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *
                           const int32_t *offsets_host, float S, uint32_t H, float bound, float density_scale,
                           int zero_deform, float *sigmas, float *rgbs, void *stream);
 
+/* Which kernel large launches of the fused field network take: 1 = the persistent two-set ("ping-pong") kernel, the default for launches
+ * of at least 4 tiles of 256 points per CU on a QUAD table; 0 = one tile per workgroup for every launch; -1 = environment SDN_FIELD_PP or
+ * the default.  Both produce the same bits: a switch for tests and A/B measurements, not a tuning knob. */
+void sdn_field_select_kernel(int persistent);
+
 /* The fused kernel's QUAD table from embeddings in the reference's layout (gridencoder/grid.py:118-140; cast to fp16 as grid.py:43-44
  * does under autocast): embeddings [ref_offsets_host[16], 2] of `dtype` (SDN_F32 / SDN_F16), ref_offsets_host [17] the reference's level
  * offsets.  out: (ref_offsets_host[16] + 32) blocks of 16 bytes; block ref_offsets_host[l] + 2 l + r holds rows {r, r+1, r+s1, r+s1+1}

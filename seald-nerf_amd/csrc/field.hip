@@ -117,6 +117,7 @@ struct FieldArgs {
     // workgroups -- start `stagger_cycles` shader cycles late, so that the two workgroups of a CU run their matrix and vector phases out
     // of step (0 = off)
     uint32_t stagger_cycles, stagger_lo, stagger_hi;
+    uint32_t n_frames;        // rows of bias0 (frames of a frame group; 1 without slot_frame)
 };
 
 // Morton code -> one coordinate (bits 0, 3, 6, ...): raymarching.cu:282-289
@@ -784,6 +785,8 @@ int fill_tiled_levels(TiledLevels &lv, const int32_t *offsets_host, float S, uin
     return 0;
 }
 
+#include "field_pp.inc"
+
 // Quad table: block (offset_q[l] + r) of level l = rows {r, r + 1, r + s1, r + s1 + 1} of the level, each mod its row count, as fp16 pairs
 // (the corners (x, y), (x+1, y), (x, y+1), (x+1, y+1) of the cell whose low corner is row r: get_grid_index adds 1 / s1 per step and
 // takes the sum mod the row count, gridencoder.cu:66-84).  T = float or __half (rounded to fp16 as grid.py:43-44's `.half()` does).
@@ -808,11 +811,13 @@ __global__ void k_build_quad_table(const T *__restrict__ emb, QuadLevels q, uint
 
 namespace sdn_int {
 
+static int g_field_pp = -1;   // 1: large launches take the persistent ping-pong kernel (default), 0: never; -1: read SDN_FIELD_PP
+
 // launch used by both the C entry point and the device-driven render loop (render.hip)
 int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count, const int32_t *state,
                       uint32_t M, const void *weights, const float *bias0, const void *table, const int32_t *offsets_host, float S,
                       uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, uint32_t expect_points,
-                      const uint8_t *slot_frame, hipStream_t st) {
+                      const uint8_t *slot_frame, uint32_t n_frames, hipStream_t st) {
     TiledLevels lv;
     int rc = fill_tiled_levels(lv, offsets_host, S, H);
     if (rc) return rc;
@@ -821,7 +826,7 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
     a.weights = (const unsigned char *)weights; a.bias0 = bias0; a.table = (const __half *)table;
     a.sigmas = sigmas; a.rgbs = rgbs; a.bound = bound; a.density_scale = density_scale; a.zero_deform = zero_deform;
     a.inv_2bound = exact_reciprocal(2 * bound);
-    a.slot_frame = slot_frame;
+    a.slot_frame = slot_frame; a.n_frames = slot_frame ? (n_frames > 16u ? 16u : n_frames) : 1u;
     a.cell_noise = nullptr; a.cell_seed = 0; a.cell_inv = a.cell_span = a.cell_half = 0;
     const uint32_t wgs = sdn_div_up(M, (uint32_t)kPointsPerWG);
     static int cus = 0;
@@ -855,6 +860,22 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
         a.stagger_cycles = (uint32_t)stag; a.stagger_lo = (uint32_t)cus; a.stagger_hi = 2u * (uint32_t)cus;
     }
     const int layout = table_layout(offsets_host);
+    // persistent ping-pong form (field_pp.inc): one 16-wave workgroup per CU walking tile pairs, for launches of at least two rounds of
+    // the CUs (SDN_FIELD_PP=0 keeps every launch on the one-tile-per-workgroup kernels: measurements only)
+    if (g_field_pp < 0) {
+        const char *e = getenv("SDN_FIELD_PP");
+        g_field_pp = e ? atoi(e) : 1;
+    }
+    static int pp_min_tiles_per_cu = -1;      // launches of at least this many 256-point tiles per CU take the persistent kernel
+    if (pp_min_tiles_per_cu < 0) {
+        const char *e = getenv("SDN_FIELD_PP_MIN_TILES");
+        pp_min_tiles_per_cu = e ? atoi(e) : 4;
+    }
+    if (g_field_pp && layout == kLayoutQuad && busy >= (uint32_t)pp_min_tiles_per_cu * (uint32_t)cus && a.n_frames <= kPPMaxFrames && M < (1u << 28)) {
+        const uint32_t pairs = sdn_div_up(sdn_div_up(M, kPPTile), 2u);
+        hipLaunchKernelGGL(k_field_pp_f16, dim3(pairs < (uint32_t)cus ? pairs : (uint32_t)cus), dim3(64 * kPPWaves), 0, st, a, lv);
+        return sdn_launch_status();
+    }
     if (layout == kLayoutQuad) {
         if (small) hipLaunchKernelGGL((k_field_f16<2, 8, false, kLayoutQuad>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
         else hipLaunchKernelGGL((k_field_f16<4, 2, false, kLayoutQuad>), dim3(wgs), dim3(64 * kWaves), 0, st, a, lv);
@@ -883,7 +904,7 @@ int field_cells_f16(const int32_t *cells, const uint32_t *cell_count, uint32_t n
     a.inv_2bound = exact_reciprocal(2 * bound);
     a.slot_frame = nullptr;
     a.cell_noise = noise; a.cell_seed = seed;
-    a.stagger_cycles = 0; a.stagger_lo = a.stagger_hi = 0;
+    a.stagger_cycles = 0; a.stagger_lo = a.stagger_hi = 0; a.n_frames = 1;
     const float half_grid = cas_bound / (float)grid_size;
     a.cell_inv = 1.0f / (float)(grid_size - 1); a.cell_span = cas_bound - half_grid; a.cell_half = half_grid;
     const uint32_t wgs = sdn_div_up(n, (uint32_t)kPointsPerWG);
@@ -904,6 +925,10 @@ int field_cells_f16(const int32_t *cells, const uint32_t *cell_count, uint32_t n
 extern "C" {
 
 uint32_t sdn_field_weight_blocks(void) { return (uint32_t)kBlkTotal; }
+
+// Kernel selection for large launches of the fused field network: 1 = persistent ping-pong kernel (the default), 0 = one tile per
+// workgroup for every launch (the two produce identical bits; tests and A/B measurements switch here), -1 = back to SDN_FIELD_PP / default.
+void sdn_field_select_kernel(int persistent) { sdn_int::g_field_pp = persistent; }
 
 // Builds the fused kernel's QUAD table (16 bytes per row, see kLayoutQuad) from embeddings in the reference layout.
 //   embeddings [ref_offsets_host[16], 2] of dtype (SDN_F32 / SDN_F16), ref_offsets_host [17] the reference's level offsets (grid.py:118-127);
@@ -930,6 +955,15 @@ int sdn_field_build_quad_table(const void *embeddings, int dtype, const int32_t 
 }
 
 #ifdef SDN_STAMPS
+// diagnostic build only: the persistent kernel's slot stamps (g_pp_stamps: 256 workgroups x 2 sets x 128 words), cleared behind the copy
+int sdn_debug_pp_stamps(unsigned long long *out) {
+    if (!out) return SDN_E_BADARG;
+    if (hipDeviceSynchronize() != hipSuccess) return sdn_launch_status();
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_stamps), sizeof(unsigned long long) * 256 * 2 * 128) != hipSuccess) return sdn_launch_status();
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_pp_stamps)) != hipSuccess) return sdn_launch_status();
+    return (int)hipMemset(p, 0, sizeof(unsigned long long) * 256 * 2 * 128);
+}
 // diagnostic build only: copies out and clears the field kernel's stamp sums (see g_field_stamps)
 // (out: sdn_debug_field_stamp_words() 64-bit words; the buffer is cleared behind the copy)
 uint32_t sdn_debug_field_stamp_words(void) { return kStampWGs * 2 * 32; }
@@ -953,7 +987,7 @@ int sdn_field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *
     if ((live_idx == nullptr) != (live_count == nullptr)) return SDN_E_BADARG;
     if (((uintptr_t)weights & 15u) != 0 || ((uintptr_t)table & 3u) != 0) return SDN_E_BADARG;
     return sdn_int::field_forward_f16(xyzs, dirs, live_idx, live_count, nullptr, M, weights, bias0, table, offsets_host, S, H, bound,
-                                      density_scale, zero_deform ? 1 : 0, sigmas, rgbs, 0u, nullptr, (hipStream_t)stream);
+                                      density_scale, zero_deform ? 1 : 0, sigmas, rgbs, 0u, nullptr, 1u, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -116,7 +116,8 @@ int sdn_render_step_f16_ev(const SdnRenderCtx *c, uint32_t bound_alive, void *ev
     if (ev_field_begin) (void)hipEventRecord((hipEvent_t)ev_field_begin, st);
     rc = sdn_int::field_forward_f16(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, (uint32_t)m_bound,
                                     c->field_weights, c->field_bias0, c->grid_table, c->grid_offsets, c->grid_S, c->grid_H, c->bound,
-                                    c->density_scale, c->zero_deform, c->sigmas, c->rgbs, 0u, c->n_group_frames > 1 ? c->slot_frame : nullptr, st);
+                                    c->density_scale, c->zero_deform, c->sigmas, c->rgbs, 0u, c->n_group_frames > 1 ? c->slot_frame : nullptr,
+                                    c->n_group_frames > 1 ? c->n_group_frames : 1u, st);
     if (ev_field_end) (void)hipEventRecord((hipEvent_t)ev_field_end, st);
     if (rc) return rc;
     rc = seal_color(c, (uint32_t)m_bound, st);
@@ -217,7 +218,7 @@ struct FrameRun {
             rc = sdn_int::field_forward_f16(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, (uint32_t)m_bound,
                                             c->field_weights, c->field_bias0, c->grid_table, c->grid_offsets, c->grid_S, c->grid_H, c->bound,
                                             c->density_scale, c->zero_deform, c->sigmas, c->rgbs, last_alive * 8u,
-                                            c->n_group_frames > 1 ? c->slot_frame : nullptr, st);
+                                            c->n_group_frames > 1 ? c->slot_frame : nullptr, c->n_group_frames > 1 ? c->n_group_frames : 1u, st);
             if (e1) (void)hipEventRecord((hipEvent_t)e1, st);
             if (!rc) rc = seal_color(c, (uint32_t)m_bound, st);
             if (!rc && m0) (void)hipEventRecord((hipEvent_t)m0, st);

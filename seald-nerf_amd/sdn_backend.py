@@ -146,6 +146,8 @@ lib = ctypes.CDLL(LIB_PATH)
 lib.sdn_version.restype = ctypes.c_char_p
 lib.sdn_host_mailbox_alloc.restype = ctypes.c_void_p
 lib.sdn_host_mailbox_alloc.argtypes = [ctypes.c_uint32]
+lib.sdn_field_select_kernel.restype = None
+lib.sdn_field_select_kernel.argtypes = [ctypes.c_int]
 for _name, _args in PROTOTYPES.items():
     _fn = getattr(lib, _name)
     _fn.argtypes = _args

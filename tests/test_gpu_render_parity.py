@@ -624,3 +624,53 @@ def test_quad_table_layout_is_the_padded_layout_bit_for_bit(small_scene):
         want = np.stack([emb[a + r], emb[a + (r + 1) % hs], emb[a + (r + s1) % hs], emb[a + (r + s1 + 1) % hs]], axis=1)
         got = tq[a + 2 * l: a + 2 * l + hs]
         assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), l
+
+
+def test_persistent_two_set_field_kernel_is_the_one_tile_kernel_bit_for_bit(small_scene):
+    """Large launches of the fused field network take the persistent two-set kernel (csrc/field_pp.inc: one 16-wave workgroup per CU, the
+    sets alternate between the wide layers and the vector-side work).  Same arithmetic in the same order: sigma and rgb are bit-identical
+    to the one-tile-per-workgroup kernel -- whole tiles, a ragged last tile, an odd tile count, a live list with the count on the device
+    (untouched slots stay untouched), and the canonical frame."""
+    import sdn_backend
+    from dnerf_amd import fused
+    from dnerf_amd.bench_scene import _probe_points
+    sc = small_scene
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    base = 4 * cus * 256                                     # the smallest launch that takes the persistent kernel
+    rng = np.random.default_rng(11)
+    sel = sdn_backend.lib.sdn_field_select_kernel
+    try:
+        for n, t in ((base, 0.5), (base + 256 * 3 + 77, 0.5), (2 * base + 256 + 1, 0.0), (3 * base - 5, 0.26)):
+            pts = _probe_points(sc.bitfield, n, 3) + rng.uniform(-0.01, 0.01, (n, 3)).astype(np.float32)
+            x = torch.from_numpy(pts.astype(np.float32)).cuda()
+            d = torch.nn.functional.normalize(torch.randn(n, 3, device="cuda"), dim=1).contiguous()
+            f = fused.FusedField(sc.model, t)
+            launches = []
+            sel(1)
+            with sdn_backend.launch_log(launches):
+                s1, c1 = f(x, d)
+            s1, c1 = s1.clone(), c1.clone()
+            sel(0)
+            s0, c0 = f(x, d)
+            assert torch.equal(s1, s0) and torch.equal(c1, c0), (n, t)
+            assert torch.isfinite(s1).all() and float(c1.min()) >= 0 and float(c1.max()) <= 1
+        # live list: every third slot, count read on the device; the other slots keep what they held
+        n = base + 1000
+        pts = _probe_points(sc.bitfield, n, 5)
+        x = torch.from_numpy(pts).cuda()
+        d = torch.nn.functional.normalize(torch.randn(n, 3, device="cuda"), dim=1).contiguous()
+        idx = torch.randperm(n, device="cuda")[: base + 300].to(torch.int32).contiguous()      # (a launch is sized by M, the list by its count)
+        cnt = torch.tensor([idx.shape[0]], dtype=torch.int32, device="cuda")
+        outs = []
+        for mode in (1, 0):
+            sel(mode)
+            f = fused.FusedField(sc.model, 0.5)
+            f._alloc(n)
+            f._buf[0].fill_(-1.0); f._buf[1].fill_(-1.0)
+            s, c = f(x, d, live_idx=idx, live_count=cnt)
+            outs.append((s.clone(), c.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        keep = torch.ones(n, dtype=torch.bool, device="cuda"); keep[idx.long()] = False
+        assert bool((outs[0][0][keep] == -1).all()) and bool((outs[0][0][~keep] >= 0).all())
+    finally:
+        sel(-1)
