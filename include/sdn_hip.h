@@ -296,7 +296,7 @@ int sdn_ffmlp_backward(const void *grad, const void *inputs, const void *weights
  * Buffer sizes: per-ray arrays N; sample arrays M_cap >= N + 128 rows; live_counts n_counters >= max_steps + 8;
  * state 16 ints; trace 2 * n_counters + 16 (ints 2 * n_counters .. +8 are a 4-deep ring of {alive rays entering the next iteration, iteration
  * number} snapshots for asynchronous read-back, the int after them a survivor-count scratch word); block_totals ceil(N / 256) + 1; n_out 1 int, zero on entry (ticket counter); cull_bits sdn_cull_grid_bytes(). */
-/* Arguments of sdn_seal_bbox_map / sdn_seal_modify_hsv as one record (host memory except `tris`), for SdnRenderCtx.seal. */
+/* Arguments of sdn_seal_bbox_map(_source) / sdn_seal_modify_hsv / sdn_seal_modify_rgb as one record (host memory except `tris`), for SdnRenderCtx.seal. */
 typedef struct SdnSealBox {
     float bounds[24];          /* n_bounds x {lo xyz, hi xyz} */
     uint32_t n_bounds, n_tris;
@@ -304,6 +304,15 @@ typedef struct SdnSealBox {
     float test_dir[3], tinv[12], rinv[9], scale[3], center[3];
     float hsv[3];              /* colour modification of the mapped samples */
     int32_t modify_hsv;        /* 0 = leave colours alone */
+    /* `rgb` / `rgbLightOffset` of the seal config (seal_utils.py:55-57, modify_rgb :761-777): tint towards a target colour, applied after
+     * the hsv modification as map_color does */
+    float rgb[3], rgb_light_offset;
+    int32_t modify_rgb;
+    /* `mapSource` (seal_utils.py:238-240,269-273): samples strictly inside source_bound {lo xyz, hi xyz} move to map_source */
+    int32_t has_map_source;
+    float source_bound[6], map_source[3];
+    uint32_t reserved_;
+    void *scratch;             /* device, 32 bytes, zeroed once by the caller: [0..15] modify_rgb's sum / count, [16..19] the mapSource flag word */
 } SdnSealBox;
 
 /* Several frames may be rendered TOGETHER by one loop ("frame group": the shards of consecutive frames of a camera path / of
@@ -428,8 +437,22 @@ int sdn_render_frames_pipelined_f16(const SdnRenderCtx *const *ctxs, uint32_t n_
 int sdn_seal_bbox_map(float *xyzs, float *dirs, uint32_t M, const float *bounds, uint32_t n_bounds, const float *tris,
                       uint32_t n_tris, const float *test_dir, const float *tinv, const float *rinv, const float *scale,
                       const float *center, uint8_t *mask, void *stream);
+/* The same with the seal config's `mapSource` option (seal_utils.py:238-240,269-273): in a call that maps at least one sample -- the
+ * reference returns early otherwise, :251-252 -- every unmapped sample strictly inside source_bound {lo xyz, hi xyz} (host) moves to
+ * map_source [3] (host).  flag: one device word owned by the caller, zeroed once (the kernels only raise it to a per-call tag).
+ * "The call's samples" are the M slots, or -- live_idx / live_count (/ state: the count is live_count[state[3]]) given -- the listed
+ * slots: the device-driven loop's sample buffers may hold stale slots of earlier iterations beyond the live ones. */
+int sdn_seal_bbox_map_source(float *xyzs, float *dirs, uint32_t M, const float *bounds, uint32_t n_bounds, const float *tris,
+                             uint32_t n_tris, const float *test_dir, const float *tinv, const float *rinv, const float *scale,
+                             const float *center, const float *source_bound, const float *map_source, uint32_t *flag, uint8_t *mask,
+                             const uint32_t *live_idx, const uint32_t *live_count, const int32_t *state, void *stream);
 /* rgbs [M,3] of the masked samples: rgb -> hsv, + (dh, ds, dv), -> rgb (color_utils.py:31-63), in place. */
 int sdn_seal_modify_hsv(float *rgbs, const uint8_t *mask, uint32_t M, float dh, float ds, float dv, void *stream);
+/* modify_rgb (seal_utils.py:761-777) on the masked samples, in place: hue and saturation of the target colour (r, g, b), brightness
+ * V(target) + (V(sample) - mean V of the masked samples of THIS call) + light_offset clamped to [0, 1].  The mean is summed in fixed
+ * point: the same for any order of the samples.  scratch16: 16 bytes of device memory, 8-byte aligned (cleared by the call). */
+int sdn_seal_modify_rgb(float *rgbs, const uint8_t *mask, uint32_t M, float r, float g, float b, float light_offset, void *scratch16,
+                        const uint32_t *live_idx, const uint32_t *live_count, const int32_t *state, void *stream);
 
 /* Read-back memory for the frame drivers: 32 bytes per ray group of coherent, device-mapped host memory.  When `host_snap`
  * comes from here the loop kernels publish every iteration's survivor count into it with one 64-bit system-scope store and

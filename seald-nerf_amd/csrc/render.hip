@@ -62,13 +62,26 @@ static int seal_map(const SdnRenderCtx *c, uint32_t m_slots, hipStream_t st) {
     const SdnSealBox *s = c->seal;
     if (!s) return 0;
     if (!c->seal_mask) return SDN_E_BADARG;
+    if (s->has_map_source) {
+        if (!s->scratch) return SDN_E_BADARG;
+        return sdn_seal_bbox_map_source(c->xyzs, c->dirs, m_slots, s->bounds, s->n_bounds, s->tris, s->n_tris, s->test_dir, s->tinv, s->rinv,
+                                        s->scale, s->center, s->source_bound, s->map_source, (uint32_t *)((char *)s->scratch + 16), c->seal_mask,
+                                        c->live_idx, (const uint32_t *)c->live_counts, c->state, st);
+    }
     return sdn_seal_bbox_map(c->xyzs, c->dirs, m_slots, s->bounds, s->n_bounds, s->tris, s->n_tris, s->test_dir, s->tinv, s->rinv, s->scale,
                              s->center, c->seal_mask, st);
 }
 static int seal_color(const SdnRenderCtx *c, uint32_t m_slots, hipStream_t st) {
     const SdnSealBox *s = c->seal;
-    if (!s || !s->modify_hsv) return 0;
-    return sdn_seal_modify_hsv(c->rgbs, c->seal_mask, m_slots, s->hsv[0], s->hsv[1], s->hsv[2], st);
+    if (!s) return 0;
+    int rc = 0;
+    if (s->modify_hsv) rc = sdn_seal_modify_hsv(c->rgbs, c->seal_mask, m_slots, s->hsv[0], s->hsv[1], s->hsv[2], st);    // map_color's order: hsv, then rgb
+    if (!rc && s->modify_rgb) {
+        if (!s->scratch) return SDN_E_BADARG;
+        rc = sdn_seal_modify_rgb(c->rgbs, c->seal_mask, m_slots, s->rgb[0], s->rgb[1], s->rgb[2], s->rgb_light_offset, s->scratch, c->live_idx,
+                                 (const uint32_t *)c->live_counts, c->state, st);
+    }
+    return rc;
 }
 
 static bool ctx_ok(const SdnRenderCtx *c) {

@@ -147,7 +147,19 @@ class NeRFNetwork(NeRFRenderer):
             cache = (cache[0], cache[1], epoch[0])
             self.__dict__["_fused_cache"] = cache
         field = cache[1]
-        field.set_time(t)          # by VALUE: one host read of t, where the reference's `if t == 0` reads it too (network.py:140)
+        # by VALUE: one host read of t per distinct tensor content, where the reference's `if t == 0` reads it on every call
+        # (network.py:140).  A loop hands the same tensor to every iteration: its value is kept while the tensor's address and version
+        # counter stand (torch-level writes bump the counter; a write behind torch's back -- raw pointer, DLPack -- needs a fresh tensor).
+        # (the tensor OBJECT, not its address: a new tensor the allocator placed at a recycled address is another object)
+        seen = self.__dict__.get("_fused_time")
+        if not isinstance(t, torch.Tensor) or seen is None or seen[0]() is not t or seen[1] != t._version:
+            value = field.time_value(t)
+            if isinstance(t, torch.Tensor):
+                import weakref
+                self.__dict__["_fused_time"] = (weakref.ref(t), t._version, value)
+        else:
+            value = seen[2]
+        field.set_time(value)
         field._buf = None          # fresh output tensors per call (caching allocator, no launch): the caller owns them, as on the op-by-op path
         sig, rgb = field(x.contiguous(), d.contiguous())
         return sig, rgb, None

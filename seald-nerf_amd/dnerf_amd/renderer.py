@@ -535,8 +535,10 @@ class DeviceLoop:
         dev = self.buf["xyzs"].device
         mapper.map_data_conversion(self.buf["xyzs"])
         a = mapper._native_args(dev)
-        if "map_source" in mapper.map_data or "rgb" in mapper.map_data:
-            raise NotImplementedError("the native loop hooks bbox mappers with an optional hsv modification (mapSource / rgb tint: use render_frame)")
+        if self.frames > 1 and ("map_source" in mapper.map_data or "rgb" in mapper.map_data):
+            # both options look at ALL samples of a loop iteration (the mean brightness of the masked ones, "does the call map anything"):
+            # in a frame group an iteration holds several frames' samples, which the reference never mixes
+            raise NotImplementedError("mapSource / rgb tint depend on the set of samples of an iteration: render such edits one frame per loop")
         box = SdnSealBox()
         for k in range(6 * a["n_bounds"]):
             box.bounds[k] = a["bounds"][k]
@@ -547,6 +549,15 @@ class DeviceLoop:
         if "hsv" in mapper.map_data:
             h = [float(v) for v in mapper.map_data["hsv"].reshape(-1).tolist()]
             box.hsv[0], box.hsv[1], box.hsv[2], box.modify_hsv = h[0], h[1], h[2], 1
+        if "rgb" in a:
+            box.rgb[0], box.rgb[1], box.rgb[2], box.rgb_light_offset, box.modify_rgb = a["rgb"][0], a["rgb"][1], a["rgb"][2], a["rgb_light_offset"], 1
+        if "map_source" in a:
+            for k in range(6):
+                box.source_bound[k] = a["source_bound"][k]
+            for k in range(3):
+                box.map_source[k] = a["map_source"][k]
+            box.has_map_source = 1
+        box.scratch = a["scratch"].data_ptr()
         mask = torch.empty(self.buf["sigmas"].shape[0], dtype=torch.uint8, device=dev)
         self._seal = (box, mask, a)      # keep the record, the mask and the triangle tensor alive
         c.seal, c.seal_mask = ctypes.addressof(box), mask.data_ptr()
@@ -859,6 +870,10 @@ class RayBatchRenderer:
     def __init__(self, model, field, N, device, max_steps=1024, T_thresh=1e-2, dt_gamma=0.0, mapper=None, samples_per_ray=96):
         import sdn_backend as B
         B.require_device()
+        if mapper is not None and ("rgb" in mapper.map_data or "map_source" in mapper.map_data):
+            # (the loop's iterations are the unit both options look at -- modify_rgb's mean brightness, map_to_origin's early return:
+            #  one pass over all samples would tint and redirect differently from the reference's loop)
+            raise NotImplementedError("mapSource / rgb tint depend on the loop's iterations: use render_frame / DeviceLoop for such edits")
         self.model, self.field, self.N, self.device, self.mapper = model, field, int(N), torch.device(device), mapper
         self.max_steps, self.T_thresh, self.dt_gamma = int(max_steps), float(T_thresh), float(dt_gamma)
         M = self.N * int(samples_per_ray)

@@ -225,7 +225,7 @@ class SealBBoxMapper(SealMapper):
     # ---- device fast path: csrc/seal.hip, one lane per sample slot, in place ---------------------------------------------
     def _native_ok(self, points, dirs):
         return (points.is_cuda and dirs is not None and points.dtype == torch.float32 and dirs.dtype == torch.float32
-                and points.is_contiguous() and dirs.is_contiguous() and "map_source" not in self.map_data)
+                and points.is_contiguous() and dirs.is_contiguous())
 
     def _native_args(self, device):
         import ctypes
@@ -243,7 +243,15 @@ class SealBBoxMapper(SealMapper):
                                 bounds=cfl(f32(bounds.reshape(-1, 6))), n_bounds=int(bounds.shape[0]),
                                 test_dir=cfl(f32(_TEST_DIR if self.map_test_dir is None else self.map_test_dir.cpu().numpy())),
                                 tinv=cfl(f32(md["transform"][:3, :4])), rinv=cfl(f32(md["rotation"])), scale=cfl(f32(md["scale"])),
-                                center=cfl(f32(md["center"])))
+                                center=cfl(f32(md["center"])),
+                                # [0..15] modify_rgb's sum / count, [16..19] the mapSource flag word (only ever raised), zeroed once
+                                scratch=torch.zeros(32, dtype=torch.uint8, device=device))
+            if "map_source" in md:
+                self._native["source_bound"] = cfl(f32(md["empty_bound"].reshape(2, 3)))
+                self._native["map_source"] = cfl(f32(md["map_source"].reshape(3)))
+            if "rgb" in md:
+                self._native["rgb"] = [float(v) for v in f32(md["rgb"].reshape(3))]
+                self._native["rgb_light_offset"] = float(np.float32(md["rgb_light_offset"]))
             self._native_key = key
         return self._native
 
@@ -254,17 +262,32 @@ class SealBBoxMapper(SealMapper):
         a = self._native_args(points.device)
         M = points.shape[0]
         mask = torch.empty(M, dtype=torch.uint8, device=points.device)
-        check(lib.sdn_seal_bbox_map(ptr(points), ptr(dirs), M, a["bounds"], a["n_bounds"], ptr(a["tris"]), a["n_tris"], a["test_dir"], a["tinv"],
-                                    a["rinv"], a["scale"], a["center"], ptr(mask), stream()), "seal_bbox_map")
+        if "map_source" in a:
+            # (`mapSource`, seal_utils.py:269-273: the call's unmapped samples inside the source box move to one point -- if the call maps
+            #  any sample at all, :251-252; every slot of the buffers is a sample of the call here)
+            check(lib.sdn_seal_bbox_map_source(ptr(points), ptr(dirs), M, a["bounds"], a["n_bounds"], ptr(a["tris"]), a["n_tris"], a["test_dir"],
+                                               a["tinv"], a["rinv"], a["scale"], a["center"], a["source_bound"], a["map_source"],
+                                               a["scratch"].data_ptr() + 16, ptr(mask), None, None, None, stream()), "seal_bbox_map_source")
+        else:
+            check(lib.sdn_seal_bbox_map(ptr(points), ptr(dirs), M, a["bounds"], a["n_bounds"], ptr(a["tris"]), a["n_tris"], a["test_dir"], a["tinv"],
+                                        a["rinv"], a["scale"], a["center"], ptr(mask), stream()), "seal_bbox_map")
         return mask.view(torch.bool)
 
     @torch.no_grad()
     def map_color_(self, rgbs, mask):
-        """In-place `map_color` of the masked samples; HIP kernel for the hsv modification, torch for the rest."""
-        if "hsv" in self.map_data and "rgb" not in self.map_data and rgbs.is_cuda and rgbs.dtype == torch.float32 and rgbs.is_contiguous():
+        """In-place `map_color` of the masked samples (seal_utils.py:48-57: the hsv modification, then the rgb tint): HIP kernels on CUDA
+        fp32 buffers, the torch restatement otherwise (and for an `image` modification, which the bbox mapper of this build does not carry)."""
+        if rgbs.is_cuda and rgbs.dtype == torch.float32 and rgbs.is_contiguous() and "image" not in self.map_data:
             from sdn_backend import lib, check, ptr, stream
-            h = [float(v) for v in self.map_data["hsv"].reshape(-1).tolist()]
-            check(lib.sdn_seal_modify_hsv(ptr(rgbs), ptr(mask.view(torch.uint8)), rgbs.shape[0], h[0], h[1], h[2], stream()), "seal_modify_hsv")
+            m8 = mask.view(torch.uint8)
+            if "hsv" in self.map_data:
+                h = [float(v) for v in self.map_data["hsv"].reshape(-1).tolist()]
+                check(lib.sdn_seal_modify_hsv(ptr(rgbs), ptr(m8), rgbs.shape[0], h[0], h[1], h[2], stream()), "seal_modify_hsv")
+            if "rgb" in self.map_data:
+                a = self._native_args(rgbs.device)
+                c = a["rgb"]
+                check(lib.sdn_seal_modify_rgb(ptr(rgbs), ptr(m8), rgbs.shape[0], c[0], c[1], c[2], a["rgb_light_offset"], ptr(a["scratch"]),
+                                              None, None, None, stream()), "seal_modify_rgb")
         elif bool(mask.any()):
             rgbs[mask] = self.map_color(None, None, rgbs[mask]).to(rgbs.dtype)
         return rgbs

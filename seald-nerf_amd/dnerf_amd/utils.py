@@ -6,6 +6,7 @@ in torch followed by the same per-pixel arithmetic.
 """
 import torch
 
+import sdn_backend as _sdn
 from sdn_backend import lib as _lib, check as _check, ptr as _ptr, stream as _stream
 
 
@@ -25,7 +26,8 @@ def get_rays(poses, intrinsics, H, W, N=-1, error_map=None, patch_size=1):
         rays_d = torch.empty(B, H * W, 3, dtype=torch.float32, device=device)
         p = poses.detach().to(torch.float32).contiguous()
         for b in range(B):
-            _check(_lib.sdn_get_rays(_ptr(p[b]), fx, fy, cx, cy, int(H), int(W), _ptr(rays_o[b]), _ptr(rays_d[b]), _stream()), "get_rays")
+            with _sdn.timed("get_rays", H * W):
+                _check(_lib.sdn_get_rays(_ptr(p[b]), fx, fy, cx, cy, int(H), int(W), _ptr(rays_o[b]), _ptr(rays_d[b]), _stream()), "get_rays")
         results["rays_o"], results["rays_d"] = rays_o, rays_d
         return results
 

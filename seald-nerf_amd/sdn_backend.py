@@ -51,6 +51,8 @@ PROTOTYPES = {
     "sdn_host_mailbox_free": [_vp],
     "sdn_seal_bbox_map": [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sdn_seal_modify_hsv": [_vp, _vp, _u32, _f32, _f32, _f32, _vp],
+    "sdn_seal_bbox_map_source": [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sdn_seal_modify_rgb": [_vp, _vp, _u32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "sdn_field_forward_f16": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _f32, _u32, _f32, _f32, _i32, _vp, _vp, _vp],
     "sdn_field_build_quad_table": [_vp, _i32, _vp, _f32, _u32, _vp, _vp],
     "sdn_density_query_cells_f16": [_vp, _vp, _u32, _vp, _u32, _u32, _f32, _vp, _vp, _vp, _vp, _f32, _u32, _f32, _f32, _i32, _vp, _vp],
@@ -86,7 +88,9 @@ class SdnRenderCtx(ctypes.Structure):
 class SdnSealBox(ctypes.Structure):
     """Mirror of `SdnSealBox` in include/sdn_hip.h."""
     _fields_ = [("bounds", _f32 * 24), ("n_bounds", _u32), ("n_tris", _u32), ("tris", _vp), ("test_dir", _f32 * 3), ("tinv", _f32 * 12),
-                ("rinv", _f32 * 9), ("scale", _f32 * 3), ("center", _f32 * 3), ("hsv", _f32 * 3), ("modify_hsv", ctypes.c_int32)]
+                ("rinv", _f32 * 9), ("scale", _f32 * 3), ("center", _f32 * 3), ("hsv", _f32 * 3), ("modify_hsv", ctypes.c_int32),
+                ("rgb", _f32 * 3), ("rgb_light_offset", _f32), ("modify_rgb", ctypes.c_int32), ("has_map_source", ctypes.c_int32),
+                ("source_bound", _f32 * 6), ("map_source", _f32 * 3), ("reserved_", _u32), ("scratch", _vp)]
 
 
 TRAIN_N_PARAMS = 14   # SDN_TRAIN_N_PARAMS

@@ -455,14 +455,45 @@ def gen_get_rays(out):
     out["get_rays"] = g
 
 
+SEAL_CONFIG_RGB_MOVE = dict(type="bbox", boundType="to", scale=[1.0, 1.0, 1.0], rgb=[0.9, 0.2, 0.1], rgbLightOffset=0.05, mapSource=[0.9, 0.9, 0.9],
+                            raw=SEAL_CONFIG["raw"], transform=SEAL_CONFIG["transform"])
+
+
+def gen_seald_rgb(out):
+    """The teacher with a bbox mapper that MOVES the head (mapSource: samples in the source box are sent to an empty corner, seal_utils.py
+    :269-273) and tints the copy towards a colour (`rgb` + rgbLightOffset: modify_rgb, :761-777, with the mean brightness of the masked
+    samples OF EACH LOOP ITERATION) -- the two map_data options the hsv fixture above does not touch.  Same reference code path:
+    SealDNeRF/renderer.py:250-276 calling SealBBoxMapper.map_to_origin / SealMapper.map_color."""
+    import SealDNeRF.network as seald_network
+    import SealNeRF.seal_utils as SU
+    model, bits = build_reference_model(seald_network.NeRFNetwork)
+    ro, rd, _ = camera_rays(64, 64)
+    s = {}
+    mapper = reference_bbox_mapper(SU, SEAL_CONFIG_RGB_MOVE)
+    filled = fill_bitfield_np(bits, mapper.map_data["force_fill_bound"].numpy())
+    model.density_bitfield.copy_(torch.from_numpy(filled))
+    plain = run_infer(model, ro, rd, 0.5)                     # (filled occupancy, no mapper: what the edit is compared with)
+    model.seal_mapper = mapper
+    r = run_infer(model, ro, rd, 0.5)
+    for k, v in r.items():
+        s[f"mapped_{k}"] = v
+    s["plain_image"] = plain["image"]
+    s["filled_bitfield_sha"] = np.array(sha(filled[32]))
+    print(f"[seald_rgb] mapped iterations {len(s['mapped_trace'])}, pixels changed by the edit "
+          f"{(np.abs(s['mapped_image'] - s['plain_image']).max(1) > 1e-3).sum()}")
+    out["seald_rgb"] = s
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 def main():
-    which = set(sys.argv[1:]) or {"dnerf", "seald", "get_rays", "bound2", "bg"}
+    which = set(sys.argv[1:]) or {"dnerf", "seald", "seald_rgb", "get_rays", "bound2", "bg"}
     out = {}
     if "dnerf" in which:
         gen_dnerf(out)
     if "seald" in which:
         gen_seald(out)
+    if "seald_rgb" in which:
+        gen_seald_rgb(out)
     if "get_rays" in which:
         gen_get_rays(out)
     if "bound2" in which:

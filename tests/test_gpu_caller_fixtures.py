@@ -316,3 +316,102 @@ def test_background_sphere_model_reproduces_reference():
     fast = DeviceLoop(sc.model, FusedField(sc.model, sc.time), sc.rays_o.shape[0], "cuda").render(sc.rays_o, sc.rays_d, sc.time)
     torch.cuda.synchronize()
     assert np.abs(fast["image"].cpu().numpy() - fx["infer_image"]).max() < 2e-2
+
+
+def test_hip_get_rays_kernel_reproduces_the_reference_fixture():
+    """`sdn_get_rays` (through dnerf_amd.utils.get_rays on CUDA poses) against what the reference's nerf/utils.get_rays produced
+    (caller_get_rays.npz): all pixels of two poses; the sampled variants gather from the kernel's full frame with the fixture's
+    own indices (the draws are torch CPU-generator draws, checked by the CPU test)."""
+    from dnerf_amd.utils import get_rays
+    fx = load("get_rays")
+    poses, intr = torch.from_numpy(fx["poses"]).cuda(), fx["intrinsics"]
+    launches = []
+    import sdn_backend
+    with sdn_backend.launch_log(launches):
+        r = get_rays(poses, intr, 40, 56, -1)
+    assert any(n == "get_rays" for n, _ in launches), launches          # the HIP kernel ran, not the torch expression
+    np.testing.assert_allclose(r["rays_o"].cpu().numpy(), fx["all_rays_o"], rtol=0, atol=0)
+    np.testing.assert_allclose(r["rays_d"].cpu().numpy(), fx["all_rays_d"], rtol=0, atol=2e-6)      # (norm / matmul summation order)
+    for name, b in (("rand", slice(None)), ("patch", slice(0, 1)), ("err", slice(0, 1))):
+        inds = torch.from_numpy(fx[f"{name}_inds"]).cuda().long()
+        picked = torch.gather(r["rays_d"][b], 1, inds[..., None].expand(-1, -1, 3))
+        np.testing.assert_allclose(picked.cpu().numpy(), fx[f"{name}_rays_d"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["to", "both_rot", "from_src"])
+def test_hip_seal_kernels_reproduce_the_reference_fixture(name):
+    """csrc/seal.hip (`sdn_seal_bbox_map(_source)`, `sdn_seal_modify_hsv`, `sdn_seal_modify_rgb`) against what the reference's
+    SealBBoxMapper.map_to_origin / map_color produced on the fixture's points (caller_seal_helpers.npz): masks equal except within
+    rounding of a box face (dot products are accumulated x, y, z in fp32 where torch's einsum order is library-defined: at most 3 of
+    6 000 points may flip), mapped points and directions 2e-6 -- `from_src`: including the samples the mapSource option sends to its
+    point --, hsv-modified colours 2e-6, rgb-tinted colours 5e-6 (the mean brightness is summed in fixed point here, by torch.mean
+    there)."""
+    from dnerf_amd.seal_mapper import SealBBoxMapper
+    from test_caller_fixtures_cpu import SEAL_CONFIGS
+    fx = load("seal_helpers")
+    cfg = SEAL_CONFIGS[name]
+    m = SealBBoxMapper(cfg)
+    pts, dirs = torch.from_numpy(fx["pts"]).cuda(), torch.from_numpy(fx["dirs"]).cuda()
+    launches = []
+    import sdn_backend
+    with sdn_backend.launch_log(launches):
+        p2, d2 = pts.clone(), dirs.clone()
+        mask = m.map_to_origin_(p2, d2)
+    want = torch.from_numpy(fx[f"{name}_mask"])
+    flips = int((mask.cpu() != want).sum())
+    assert flips <= 3 and bool(mask.any()), flips
+    both = (mask.cpu() & want).numpy()
+    np.testing.assert_allclose(p2.cpu().numpy()[both], fx[f"{name}_points"][both], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(d2.cpu().numpy()[both], fx[f"{name}_dirs"][both], rtol=0, atol=2e-6)
+    out = ~(mask.cpu() | want)
+    # unmapped samples: untouched, or -- mapSource -- moved to the configured point exactly where the reference moved them
+    np.testing.assert_allclose(p2.cpu().numpy()[out.numpy()], fx[f"{name}_points"][out.numpy()], rtol=0, atol=0)
+    if name == "from_src":
+        moved = (fx[f"{name}_points"] != fx["pts"]).any(1) & ~fx[f"{name}_mask"]
+        assert moved.sum() >= 0 and np.array_equal(fx[f"{name}_points"][moved], np.broadcast_to(np.float32([0.5, 0.5, 0.5]), (int(moved.sum()), 3)))
+    cols_in = torch.zeros(pts.shape[0], 3, device="cuda")
+    cols_in[want.cuda()] = torch.from_numpy(fx[f"{name}_colors_in"]).cuda()
+    got = m.map_color_(cols_in.clone(), want.cuda())
+    np.testing.assert_allclose(got.cpu().numpy()[want.numpy()], fx[f"{name}_colors_out"], rtol=0, atol=5e-6 if "rgb" in cfg else 2e-6)
+    assert torch.equal(got[~want.cuda()], cols_in[~want.cuda()])
+
+
+def test_seald_teacher_rgb_tint_and_map_source_in_the_native_loops(model_bits):
+    """caller_seald_rgb.npz -- the reference's teacher with a mapper that MOVES the head (`mapSource`) and tints the copy (`rgb` +
+    rgbLightOffset; the mean brightness of each iteration's masked samples enters every colour): the host-stepped loop on the fp32
+    operators reproduces the fixture (trace exact, image 1e-4); the device-driven loop and the host-stepped loop with the fused -O
+    field run the same kernels on the same samples -- the mean is summed order-independently -- and agree bit for bit; -O bars
+    against the reference's fp32 render."""
+    from dnerf_amd.fused import FusedField
+    from dnerf_amd.renderer import DeviceLoop, render_frame
+    from dnerf_amd.seal_mapper import SealBBoxMapper
+    from test_caller_fixtures_cpu import SEAL_CONFIG_RGB_MOVE
+    from tests_support import assert_dist
+    fx = load("seald_rgb")
+    model, bits = model_bits
+    sc = fixture_scene("cuda", model_bits=model_bits)
+    keep = model.density_bitfield.clone()
+    try:
+        mapper = SealBBoxMapper(SEAL_CONFIG_RGB_MOVE)
+        filled = fill_bitfield_host(bits, mapper.map_data["force_fill_bound"].cpu().numpy())
+        model.density_bitfield.copy_(torch.from_numpy(filled))
+        out = render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=False, T_thresh=1e-4, mapper=mapper)
+        assert fx["mapped_trace"].tolist() == [list(r) for r in out["trace"]]
+        np.testing.assert_allclose(out["image"].cpu().numpy(), fx["mapped_image"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(out["weights_sum"].cpu().numpy(), fx["mapped_weights_sum"], rtol=0, atol=1e-4)
+        assert (np.abs(out["image"].cpu().numpy() - fx["plain_image"]).max(1) > 1e-3).sum() > 100
+        field = FusedField(sc.model, sc.time)
+        host = render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=True, field=field, T_thresh=1e-4, mapper=mapper)
+        loop = DeviceLoop(sc.model, field, sc.rays_o.shape[0], "cuda", T_thresh=1e-4, mapper=mapper)
+        fast = loop.render(sc.rays_o, sc.rays_d, sc.time)
+        torch.cuda.synchronize()
+        assert torch.equal(host["image"], fast["image"]) and host["n_samples"] == fast["n_samples"]
+        again = loop.render(sc.rays_o, sc.rays_d, sc.time)
+        assert torch.equal(again["image"], fast["image"])
+        print("seald rgb + mapSource frame, -O device loop vs reference teacher (fp32):",
+              assert_dist(fast["image"].cpu().numpy(), fx["mapped_image"], "mapped image (rgb tint + mapSource), -O device loop vs SealDNeRF teacher run_cuda (fp32)",
+                          max=4e-3, p999=1e-3, mean=2e-5, frac_above_1e3=2e-3))
+        with pytest.raises(NotImplementedError):
+            DeviceLoop(sc.model, field, 2 * sc.rays_o.shape[0], "cuda", T_thresh=1e-4, mapper=mapper, frames=2)
+    finally:
+        model.density_bitfield.copy_(keep)

@@ -79,8 +79,11 @@ def test_morton_roundtrip_and_packbits_bit_exact():
     assert np.array_equal(pre.cpu().numpy(), O.packbits(grid, 0.5))
 
 
+@pytest.mark.parametrize("plain", [False, True])
 @pytest.mark.parametrize("n_step,dt_gamma", [(1, 0.0), (4, 0.0), (8, 0.0), (3, 1.0 / 128)])
-def test_march_rays_bit_exact(cam, n_step, dt_gamma):
+def test_march_rays_bit_exact(cam, n_step, dt_gamma, plain):
+    """The operator with the reference's signature.  An 8-byte aligned 128^3 slice takes the exact cull grid inside the op (kept per
+    slice content); `plain`: a slice at a 4-byte offset takes the plain marcher -- the same bits either way."""
     import raymarching
     N = cam["N"]
     alive = np.arange(N, dtype=np.int32)[::-1].copy()[: N - 7]  # not the identity, ragged count
@@ -88,8 +91,26 @@ def test_march_rays_bit_exact(cam, n_step, dt_gamma):
     rays_t = cam["nears"].copy()
     ref = O.march_rays(n_alive, n_step, alive, rays_t, cam["ro"], cam["rd"], 1.0, cam["bf"], 1, 128, cam["nears"], cam["fars"],
                        align=128, dt_gamma=dt_gamma)
-    out = raymarching.march_rays(n_alive, n_step, _dev(alive), _dev(rays_t), _dev(cam["ro"]), _dev(cam["rd"]), 1.0, _dev(cam["bf"]), 1, 128,
+    bf = _dev(cam["bf"])
+    if plain:
+        store = torch.empty(bf.numel() + 8, dtype=torch.uint8, device="cuda")
+        bf = store[4:4 + bf.numel()].copy_(bf)
+        assert bf.data_ptr() % 8 == 4 and raymarching._cull_grid_of(bf, 1, 128) is None
+    else:
+        assert raymarching._cull_grid_of(bf, 1, 128) is not None
+    out = raymarching.march_rays(n_alive, n_step, _dev(alive), _dev(rays_t), _dev(cam["ro"]), _dev(cam["rd"]), 1.0, bf, 1, 128,
                                  _dev(cam["nears"]), _dev(cam["fars"]), 128, False, dt_gamma, 1024)
+    if not plain:
+        # an in-place rewrite of the slice is seen (tensor version): emptied occupancy -> no sample; restored -> the samples again
+        keep = bf.clone()
+        bf.zero_()
+        none = raymarching.march_rays(n_alive, n_step, _dev(alive), _dev(rays_t), _dev(cam["ro"]), _dev(cam["rd"]), 1.0, bf, 1, 128,
+                                      _dev(cam["nears"]), _dev(cam["fars"]), 128, False, dt_gamma, 1024)
+        assert float(none[2].abs().max()) == 0.0
+        bf.copy_(keep)
+        again = raymarching.march_rays(n_alive, n_step, _dev(alive), _dev(rays_t), _dev(cam["ro"]), _dev(cam["rd"]), 1.0, bf, 1, 128,
+                                       _dev(cam["nears"]), _dev(cam["fars"]), 128, False, dt_gamma, 1024)
+        assert all(torch.equal(a, b) for a, b in zip(again, out))
     for o, r, name in zip(out, ref, ("xyzs", "dirs", "deltas")):
         assert o.shape == r.shape, name  # includes the "+128 when already aligned" padding rule
         assert np.array_equal(o.cpu().numpy().view(np.uint32), r.view(np.uint32)), name
