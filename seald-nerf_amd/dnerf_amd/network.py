@@ -160,6 +160,8 @@ class NeRFNetwork(NeRFRenderer):
         else:
             value = seen[2]
         field.set_time(value)
+        # (Evaluating only the slots that hold a sample -- a list built from the zero direction vectors of a marcher's empty slots --
+        #  was measured and dropped: the list kernel and the zero fills cost more than the skipped slots save, 2.73 -> 3.08 ms per frame.)
         field._buf = None          # fresh output tensors per call (caching allocator, no launch): the caller owns them, as on the op-by-op path
         sig, rgb = field(x.contiguous(), d.contiguous())
         return sig, rgb, None
