@@ -173,6 +173,13 @@ int sdn_grid_encode_backward(const void *grad, const float *inputs, const int32_
                              void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                              uint32_t H, const void *dy_dx, void *grad_inputs, uint32_t gridtype,
                              int align_corners, uint32_t interp, int dtype, void *stream);
+/* Deterministic form (a mode for bit-exact tests): det_scratch = offsets_host[L] * C 64-bit words of device memory,
+ * 8-byte aligned, cleared by the call.  Every corner contribution is added to a fixed-point accumulator (2^-24 units for the fp16 table,
+ * 2^-40 for fp32) with an integer atomic -- independent of the order the hardware executes them in -- and the sums are added to
+ * grad_embeddings with one rounding per element; NULL = sdn_grid_encode_backward. */
+int sdn_grid_encode_backward_det(const void *grad, const float *inputs, const int32_t *offsets_host, void *grad_embeddings, uint32_t B,
+                                 uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const void *dy_dx, void *grad_inputs,
+                                 uint32_t gridtype, int align_corners, uint32_t interp, int dtype, void *det_scratch, void *stream);
 
 /* ---------------------------------------------------------------------------
  * shencoder  (reference: shencoder/src/shencoder.h:9-10)   fp32 only, D == 3, 1 <= C <= 8
@@ -546,6 +553,9 @@ typedef struct SdnTrainStep {
      * table_done before its first access to the table.  A caller that touches the table, its moments or its EMA shadow itself must
      * wait for table_done first (hipStreamWaitEvent / sdn_train_flush).  All three NULL: everything on `stream`, as before. */
     void *table_stream, *table_ready, *table_done;
+    /* optional deterministic mode: grid_offsets[16] * 2 64-bit words of device memory for the table gradient's order-independent
+     * accumulation (sdn_grid_encode_backward_det); NULL = the plain half atomics */
+    void *det_scratch;
 } SdnTrainStep;
 
 /* Byte offsets into the workspace of what a caller or a test may want to look at.  fp16 "flat" networks are laid out as the fused

@@ -221,10 +221,18 @@ __device__ __forceinline__ void atomic_add_h1(__half *p, float a) {
     } while (old != assumed);
 }
 
-template <typename T, uint32_t D, uint32_t C, uint32_t N_C>
+// DET (deterministic mode, sdn_grid_encode_backward_det): every contribution w * grad is added to a 64-bit FIXED-POINT accumulator
+// (det_all, one per table element, 2^-kDetFrac units) with an integer atomic -- integer addition is associative, so the sum does not
+// depend on the order in which the hardware executes the atomics, which the float / half atomics' rounding does.  k_grid_det_finish adds
+// the sums to the gradient table, one rounding per element.
+template <typename T> struct DetScale;
+template <> struct DetScale<__half> { static constexpr double value = 16777216.0; };          // 2^24: fp16's subnormal step is 2^-24; +-5e11 of range
+template <> struct DetScale<float> { static constexpr double value = 1099511627776.0; };       // 2^40: 9e-13 of resolution, +-8e6 of range
+
+template <typename T, uint32_t D, uint32_t C, uint32_t N_C, bool DET>
 __global__ void __launch_bounds__(256) k_grid_bwd(const T *__restrict__ grad, const float *__restrict__ inputs, T *__restrict__ grad_grid_all,
                                                   uint32_t B, uint32_t L, LevelParams lp, uint32_t gridtype, bool align_corners,
-                                                  uint32_t interp) {
+                                                  uint32_t interp, long long *__restrict__ det_all) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t b = tid * N_C / C;
     const uint32_t level = blockIdx.y;
@@ -262,6 +270,15 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const T *__restrict__ grad, co
             else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
         }
         const uint32_t index = grid_index<D, C>(gridtype, align_corners, hashmap_size, resolution, pgl) + ch;
+        if constexpr (DET) {
+            if (active) {
+                long long *det = det_all + (size_t)lp.offset[level] * C + index;
+                #pragma unroll
+                for (uint32_t c = 0; c < N_C; c++)
+                    atomicAdd((unsigned long long *)(det + c), (unsigned long long)__double2ll_rn((double)(w * grad_cur[c]) * DetScale<T>::value));
+            }
+            continue;
+        }
         // Consecutive lanes are consecutive samples -- in training, neighbours along a ray, a fraction of a coarse cell apart -- so on
         // the coarse levels whole runs of lanes update the SAME row, and a wave's same-address atomics are executed one after the
         // other by the L2 (the 9 000-sample training batch spent 176 us here, nearly all of it in the few hundred hot rows of levels
@@ -295,6 +312,16 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const T *__restrict__ grad, co
             for (uint32_t c = 0; c < N_C; c++) atomic_add_f32((float *)grad_grid + index + c, acc[c]);
         }
     }
+}
+
+// deterministic mode, second pass: gradient element += its fixed-point sum (one rounding)
+template <typename T>
+__global__ void __launch_bounds__(256) k_grid_det_finish(T *__restrict__ grad_grid, const long long *__restrict__ det, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long v = det[i];
+    if (v == 0) return;
+    Num<T>::st(grad_grid + i, (float)((double)Num<T>::ld(grad_grid + i) + (double)v / DetScale<T>::value));
 }
 
 // gridencoder.cu:343-369    grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]
@@ -356,20 +383,27 @@ int dispatch_fwd(uint32_t D, uint32_t C, const float *inputs, const T *emb, T *o
 
 template <typename T, uint32_t D, uint32_t C, uint32_t N_C>
 void launch_bwd(const T *grad, const float *inputs, T *gg, uint32_t B, uint32_t L, const LevelParams &lp, const T *dy_dx, T *gi,
-                uint32_t gridtype, bool ac, uint32_t interp, hipStream_t st) {
+                uint32_t gridtype, bool ac, uint32_t interp, hipStream_t st, long long *det) {
     const dim3 grid(sdn_div_up(B * C / N_C, 256u), L, 1);
-    hipLaunchKernelGGL((k_grid_bwd<T, D, C, N_C>), grid, dim3(256), 0, st, grad, inputs, gg, B, L, lp, gridtype, ac, interp);
+    if (det) {
+        const uint64_t n = (uint64_t)lp.offset[L] * C;
+        (void)hipMemsetAsync(det, 0, n * sizeof(long long), st);
+        hipLaunchKernelGGL((k_grid_bwd<T, D, C, N_C, true>), grid, dim3(256), 0, st, grad, inputs, gg, B, L, lp, gridtype, ac, interp, det);
+        hipLaunchKernelGGL((k_grid_det_finish<T>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, gg, (const long long *)det, n);
+    } else {
+        hipLaunchKernelGGL((k_grid_bwd<T, D, C, N_C, false>), grid, dim3(256), 0, st, grad, inputs, gg, B, L, lp, gridtype, ac, interp, (long long *)nullptr);
+    }
     if (dy_dx && gi) hipLaunchKernelGGL((k_grid_input_bwd<T, D, C>), dim3(sdn_div_up(B * D, 256u)), dim3(256), 0, st, grad, dy_dx, gi, B, L);
 }
 
 template <typename T, uint32_t D>
 int dispatch_bwd_c(uint32_t C, const T *grad, const float *inputs, T *gg, uint32_t B, uint32_t L, const LevelParams &lp, const T *dy_dx, T *gi,
-                   uint32_t gridtype, bool ac, uint32_t interp, hipStream_t st) {
+                   uint32_t gridtype, bool ac, uint32_t interp, hipStream_t st, long long *det) {
     switch (C) {
-        case 1: launch_bwd<T, D, 1, 1>(grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st); break;
-        case 2: launch_bwd<T, D, 2, 2>(grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st); break;
-        case 4: launch_bwd<T, D, 4, 2>(grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st); break;
-        case 8: launch_bwd<T, D, 8, 2>(grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st); break;
+        case 1: launch_bwd<T, D, 1, 1>(grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st, det); break;
+        case 2: launch_bwd<T, D, 2, 2>(grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st, det); break;
+        case 4: launch_bwd<T, D, 4, 2>(grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st, det); break;
+        case 8: launch_bwd<T, D, 8, 2>(grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st, det); break;
         default: return SDN_E_UNSUPPORTED;
     }
     return 0;
@@ -377,12 +411,12 @@ int dispatch_bwd_c(uint32_t C, const T *grad, const float *inputs, T *gg, uint32
 
 template <typename T>
 int dispatch_bwd(uint32_t D, uint32_t C, const T *grad, const float *inputs, T *gg, uint32_t B, uint32_t L, const LevelParams &lp,
-                 const T *dy_dx, T *gi, uint32_t gridtype, bool ac, uint32_t interp, hipStream_t st) {
+                 const T *dy_dx, T *gi, uint32_t gridtype, bool ac, uint32_t interp, hipStream_t st, long long *det) {
     switch (D) {
-        case 2: return dispatch_bwd_c<T, 2>(C, grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st);
-        case 3: return dispatch_bwd_c<T, 3>(C, grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st);
-        case 4: return dispatch_bwd_c<T, 4>(C, grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st);
-        case 5: return dispatch_bwd_c<T, 5>(C, grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st);
+        case 2: return dispatch_bwd_c<T, 2>(C, grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st, det);
+        case 3: return dispatch_bwd_c<T, 3>(C, grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st, det);
+        case 4: return dispatch_bwd_c<T, 4>(C, grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st, det);
+        case 5: return dispatch_bwd_c<T, 5>(C, grad, inputs, gg, B, L, lp, dy_dx, gi, gridtype, ac, interp, st, det);
         default: return SDN_E_UNSUPPORTED;
     }
 }
@@ -415,6 +449,15 @@ int sdn_grid_encode_forward(const float *inputs, const void *embeddings, const i
 int sdn_grid_encode_backward(const void *grad, const float *inputs, const int32_t *offsets_host, void *grad_embeddings, uint32_t B,
                              uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const void *dy_dx, void *grad_inputs,
                              uint32_t gridtype, int align_corners, uint32_t interp, int dtype, void *stream) {
+    return sdn_grid_encode_backward_det(grad, inputs, offsets_host, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners,
+                                        interp, dtype, nullptr, stream);
+}
+
+// The same with an order-independent table gradient: det_scratch = offsets_host[L] * C 64-bit words of device memory (cleared by the
+// call), or NULL = the plain atomics.  Two runs on the same inputs then give the same bits (tests; resumed training).
+int sdn_grid_encode_backward_det(const void *grad, const float *inputs, const int32_t *offsets_host, void *grad_embeddings, uint32_t B,
+                                 uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const void *dy_dx, void *grad_inputs,
+                                 uint32_t gridtype, int align_corners, uint32_t interp, int dtype, void *det_scratch, void *stream) {
     if (B == 0) return 0;
     if (!grad || !inputs || !offsets_host || !grad_embeddings) return SDN_E_BADARG;
     if (gridtype > 1 || interp > 1) return SDN_E_UNSUPPORTED;
@@ -424,10 +467,10 @@ int sdn_grid_encode_backward(const void *grad, const float *inputs, const int32_
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SDN_F32)
         rc = dispatch_bwd<float>(D, C, (const float *)grad, inputs, (float *)grad_embeddings, B, L, lp, (const float *)dy_dx,
-                                 (float *)grad_inputs, gridtype, align_corners != 0, interp, st);
+                                 (float *)grad_inputs, gridtype, align_corners != 0, interp, st, (long long *)det_scratch);
     else if (dtype == SDN_F16)
         rc = dispatch_bwd<__half>(D, C, (const __half *)grad, inputs, (__half *)grad_embeddings, B, L, lp, (const __half *)dy_dx,
-                                  (__half *)grad_inputs, gridtype, align_corners != 0, interp, st);
+                                  (__half *)grad_inputs, gridtype, align_corners != 0, interp, st, (long long *)det_scratch);
     else
         return SDN_E_UNSUPPORTED;
     return rc ? rc : sdn_launch_status();

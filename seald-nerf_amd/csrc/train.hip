@@ -856,8 +856,9 @@ int sdn_train_step_f16(const SdnTrainStep *s, void *stream) {
     SDN_TRY(sdn_ffh::backward_packed(H(L.dcol_out), ws + L.pk_col_b, H(L.col_hidden), M, kColIn, kColW, kColL, ACT_RELU, 1, H(L.col_bwd), H(L.dcol_in), st));
     const SigmaBwd sb{H(L.dh0), H(L.dcol_in), H(L.h1), H(L.w_sigma0), H(L.w_sigma1), H(L.dh), H(L.dh1), H(L.denc), M};
     hipLaunchKernelGGL(k_train_sigma_bwd, dim3(sdn_div_up(M, 32u)), dim3(64), 0, st, sb);
-    SDN_TRY(sdn_grid_encode_backward(ws + L.denc, F(L.xdef), s->grid_offsets, ws + L.g_table, M, 3, 2, kLevels, s->grid_S, s->grid_H,
-                                     no_deform_grad ? nullptr : ws + L.dy_dx, no_deform_grad ? nullptr : ws + L.dx16, 1, 0, 0, SDN_F16, st));
+    SDN_TRY(sdn_grid_encode_backward_det(ws + L.denc, F(L.xdef), s->grid_offsets, ws + L.g_table, M, 3, 2, kLevels, s->grid_S, s->grid_H,
+                                         no_deform_grad ? nullptr : ws + L.dy_dx, no_deform_grad ? nullptr : ws + L.dx16, 1, 0, 0, SDN_F16,
+                                         s->det_scratch, st));
     sdn_ffh::DwJob jobs[16];
     uint32_t nj = 0;
     dw_job_list(L, ws, M, jobs, nj);

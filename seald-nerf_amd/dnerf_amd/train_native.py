@@ -23,6 +23,13 @@ _PARAM_NAMES = (["encoder.embeddings"] + [f"deform_net.{i}.weight" for i in rang
                 + [f"color_net.{i}.weight" for i in range(3)])
 
 
+def deterministic_mode():
+    """SDN_DETERMINISTIC=1 in the environment, or torch.use_deterministic_algorithms(True): order-independent accumulations where the
+    default path uses float / half atomics (the grid encoder's table gradient)."""
+    import os
+    return os.environ.get("SDN_DETERMINISTIC", "0") == "1" or torch.are_deterministic_algorithms_enabled()
+
+
 def _budget(mean_count, align=128):
     """raymarching.py:200-203, including the `+ align` of an already aligned count."""
     return mean_count + (align - mean_count % align)
@@ -30,7 +37,7 @@ def _budget(mean_count, align=128):
 
 class NativeTrainStep:
     def __init__(self, model, optimizer, scaler, n_rays, device, ema_decay=None, perturb=True, bg_color=1, dt_gamma=0.0, max_steps=1024,
-                 T_thresh=1e-4, seed=0, grad_sync=None, train_deform=True, overlap_table_update=False):
+                 T_thresh=1e-4, seed=0, grad_sync=None, train_deform=True, overlap_table_update=False, deterministic=None):
         """optimizer: a torch.optim.Adam over `model.get_params(lr, lr_net)` (or merged groups); scaler: torch.amp.GradScaler.
         ema_decay: None, or the decay of a torch_ema-style shadow kept in `self.ema_shadow` (nerf/utils.py:906).
         train_deform=False: the deformation MLP is evaluated but not trained (SealD-NeRF's edit training, SealDNeRF/utils.py:692-694;
@@ -111,6 +118,10 @@ class NativeTrainStep:
             self._table_side = (torch.cuda.Stream(device=self.device), torch.cuda.Event(), torch.cuda.Event())
             for e in self._table_side[1:]:
                 e.record()                                # materialises the hipEvent_t handles; the native step re-records them
+        # deterministic mode: the one order-dependent sum of a step -- the table gradient's half atomics -- is taken
+        # in fixed point with integer atomics instead; two runs from the same state then give the same bits.  Default: SDN_DETERMINISTIC=1
+        # in the environment, or torch.use_deterministic_algorithms(True).
+        self.deterministic = deterministic_mode() if deterministic is None else bool(deterministic)
         self.noises = None          # optional [n_rays] f32 device tensor: the per-ray offsets of the next steps (instead of the generator)
         self._time_cache = (None, None, None)       # (tensor, _version, value) of the last `time` tensor read back
         self._lr_of = {}
@@ -157,6 +168,10 @@ class NativeTrainStep:
         r.loss_out, r.image_out, r.workspace = self.loss.data_ptr(), self.image.data_ptr(), self._ws_ptr
         if self._table_side is not None:
             r.table_stream, r.table_ready, r.table_done = (self._table_side[0].cuda_stream, self._table_side[1].cuda_event, self._table_side[2].cuda_event)
+        if self.deterministic:
+            # order-independent table gradient (sdn_grid_encode_backward_det): one 64-bit fixed-point accumulator per table element
+            self._det = torch.empty(int(self._offsets[16]) * 2, dtype=torch.int64, device=self.device)
+            r.det_scratch = self._det.data_ptr()
         if self._rec is not None:
             self.flush()                                  # the old record's table pass may still be in flight: order this stream behind it
         self._rec, self._M = r, M

@@ -32,6 +32,11 @@ def _host_offsets(offsets):
 _SORT_MIN_BATCH = 1 << 20   # backward: batches at least this large are scattered in Morton order (see _grid_encode.backward)
 
 
+def _deterministic():
+    import os
+    return os.environ.get("SDN_DETERMINISTIC", "0") == "1" or torch.are_deterministic_algorithms_enabled()
+
+
 class _grid_encode(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
@@ -100,10 +105,13 @@ class _grid_encode(Function):
         grad_embeddings = torch.zeros_like(embeddings)
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
         _, off_ptr = _host_offsets(offsets)
+        # deterministic mode (SDN_DETERMINISTIC=1 / torch.use_deterministic_algorithms(True)): the table gradient is summed in 64-bit
+        # fixed point with integer atomics -- the same bits whatever order the hardware executes them in
+        det = torch.empty(embeddings.numel(), dtype=torch.int64, device=embeddings.device) if _deterministic() else None
         with _sdn.timed("grid_encode_bwd_f16" if embeddings.dtype == torch.float16 else "grid_encode_bwd_f32", B):
-            _check(_lib.sdn_grid_encode_backward(_ptr(grad), _ptr(inputs), off_ptr, _ptr(grad_embeddings), B, D, C, L, S, H, _ptr(dy_dx),
-                                                 _ptr(grad_inputs), int(gridtype), int(bool(ctx.align_corners)), int(interpolation),
-                                                 _dtype_id(embeddings.dtype), _stream()), "grid_encode_backward")
+            _check(_lib.sdn_grid_encode_backward_det(_ptr(grad), _ptr(inputs), off_ptr, _ptr(grad_embeddings), B, D, C, L, S, H, _ptr(dy_dx),
+                                                     _ptr(grad_inputs), int(gridtype), int(bool(ctx.align_corners)), int(interpolation),
+                                                     _dtype_id(embeddings.dtype), _ptr(det), _stream()), "grid_encode_backward")
         if dy_dx is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
             if perm is not None:

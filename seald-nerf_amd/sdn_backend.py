@@ -37,6 +37,7 @@ PROTOTYPES = {
     "sdn_compact_alive": [_vp, _u32, _vp, _vp, _vp, _vp],
     "sdn_grid_encode_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _i32, _u32, _i32, _vp],
     "sdn_grid_encode_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _vp],
+    "sdn_grid_encode_backward_det": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _vp, _vp],
     "sdn_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp],
     "sdn_sh_encode_backward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp],
     "sdn_freq_encode_forward": [_vp, _u32, _u32, _u32, _u32, _vp, _vp],
@@ -114,7 +115,7 @@ class SdnTrainStep(ctypes.Structure):
                 + [("adam_steps", _vp), ("loss_scale", _vp), ("growth_tracker", _vp), ("growth_factor", _f32), ("backoff_factor", _f32),
                    ("growth_interval", _u32), ("ema_decay", _f32), ("loss_out", _vp), ("image_out", _vp), ("workspace", _vp),
                    ("mode", ctypes.c_int32), ("keep_deform", ctypes.c_int32), ("grad_divisor", _f32), ("deform_frozen", ctypes.c_int32), ("phase", ctypes.c_int32), ("sample_set", ctypes.c_int32),
-                   ("table_stream", _vp), ("table_ready", _vp), ("table_done", _vp)])
+                   ("table_stream", _vp), ("table_ready", _vp), ("table_done", _vp), ("det_scratch", _vp)])
 
 
 class SdnTrainLayout(ctypes.Structure):

@@ -520,6 +520,57 @@ def test_checkpoint_round_trip_through_the_optimizer_and_scaler_state():
     assert float(step2.adam_steps[0]) == 6 and int(scaler2._growth_tracker) == 6
 
 
+def test_deterministic_mode_makes_runs_and_a_resumed_run_bit_identical():
+    """`NativeTrainStep(deterministic=True)` (SDN_DETERMINISTIC=1): the table gradient -- the one order-dependent sum of a step -- is
+    accumulated in 64-bit fixed point with integer atomics.  Two six-step runs from the same state are then bit-identical in EVERY
+    parameter, and so is a run that is checkpointed after three steps and resumed in fresh objects (the statistical bound of the test
+    above is only needed in the default mode)."""
+    from dnerf_amd.network import NeRFNetwork
+    from dnerf_amd.train_native import NativeTrainStep
+
+    def run(n, stop_at=None):
+        sc, model, opt, scaler, target = _setup()
+        step = NativeTrainStep(model, opt, scaler, N_RAYS, "cuda", perturb=True, seed=5, deterministic=True)
+        saved, losses = None, []
+        for k in range(n):
+            losses.append(float(step(sc.rays_o, sc.rays_d, target, sc.time)))
+            if k + 1 == stop_at:
+                torch.cuda.synchronize()
+                step.sync_optimizer_state()
+                saved = {"model": copy.deepcopy(model.state_dict()), "opt": copy.deepcopy(opt.state_dict()), "scaler": scaler.state_dict(),
+                         "mean_count": model.mean_count, "local_step": model.local_step, "step_count": step.step_count}
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in model.named_parameters()}, saved, (sc, target), losses
+
+    A, saved, (sc, target), la = run(6, stop_at=3)
+    B, _, _, lb = run(6)
+    assert la == lb and all(torch.equal(A[k], B[k]) for k in A), [k for k in A if not torch.equal(A[k], B[k])]
+    model2 = NeRFNetwork(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1).cuda().train()
+    model2.load_state_dict(saved["model"])
+    model2.mean_count, model2.local_step = saved["mean_count"], saved["local_step"]
+    opt2 = torch.optim.Adam(model2.get_params(1e-2, 1e-3), betas=(0.9, 0.99), eps=1e-15)
+    scaler2 = torch.amp.GradScaler("cuda")
+    step2 = NativeTrainStep(model2, opt2, scaler2, N_RAYS, "cuda", perturb=True, seed=5, deterministic=True)
+    opt2.load_state_dict(saved["opt"])
+    scaler2.load_state_dict(saved["scaler"])
+    step2.refresh(optimizer_state=True)
+    step2.step_count = saved["step_count"]               # (the per-step noise stream continues where the first run stopped)
+    l2 = [float(step2(sc.rays_o, sc.rays_d, target, sc.time)) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert l2 == la[3:], (l2, la[3:])
+    diff = [k for k, v in model2.named_parameters() if not torch.equal(v.detach(), A[k])]
+    assert not diff, diff
+    # ... and the mode computes the same gradient as the default path up to the half atomics' rounding: one step from the same state
+    sc, model, opt, scaler, target = _setup()
+    g = []
+    for det in (False, True):
+        st = NativeTrainStep(model, opt, scaler, N_RAYS, "cuda", perturb=False, deterministic=det)
+        st(sc.rays_o, sc.rays_d, target, sc.time, grads_only=True)
+        rows = model.encoder.embeddings.shape[0]
+        g.append(st.view("g_table", torch.float16, (rows, 2)).float().clone())
+    assert float((g[0] - g[1]).norm()) <= 2e-3 * float(g[0].norm()) and float(g[0].norm()) > 0
+
+
 def test_frozen_deformation_leaves_the_optimizer_serialisable():
     """SealD-NeRF's edit training (SealDNeRF/utils.py:692-694): the optimizer holds only the non-deformation parameters.  The native
     step must not plant state entries for parameters outside the optimizer's groups (torch then raises KeyError in

@@ -12,7 +12,7 @@ import sys
 
 def main():
     pmc, bench, loops, out = json.load(open(sys.argv[1])), json.loads(open(sys.argv[2]).read().strip().splitlines()[-1]), int(sys.argv[3]), sys.argv[4]
-    k = pmc["kernels"]["k_field_f16"]
+    k = pmc["kernels"].get("k_field") or pmc["kernels"]["k_field_f16"]      # "k_field": k_field_f16 and k_field_pp_f16 dispatches together
     c, d = k["counters"], k["derived"]
     frames_per_loop = int(bench["config"]["frames_per_loop"])
     points = bench["config"]["sampled_points_per_frame"] * frames_per_loop * loops
@@ -20,7 +20,7 @@ def main():
     waves = c["SQ_WAVES"]["sum"] / c["SQ_WAVES"]["dispatches"] * c["SQ_INSTS_MFMA"]["dispatches"]      # waves over the MFMA pass's dispatches
     busy_waves = c["SQ_INSTS_MFMA"]["sum"] / 240.0                                                        # waves that did a tile (240 MFMAs each)
     res = {"note": ("rocprofv3 --pmc passes (SQ sets, GRBM, FETCH_SIZE, WRITE_SIZE: each its own pass with --kernel-trace, tools/pmc_passes.py) over `"
-                    + pmc["command"] + f"`: {loops} loops of {frames_per_loop} copies of the static 800x800 frame, one loop at a time; every k_field_f16 dispatch "
+                    + pmc["command"] + f"`: {loops} loops of {frames_per_loop} copies of the static 800x800 frame, one loop at a time; every fused-field dispatch (k_field_f16 / k_field_pp_f16) "
                     "summed.  The kernel's algorithmic bytes are 552 B per point (512 B of table gathers + 24 in + 16 out): either traffic figure is BELOW them -- "
                     "table and weights are served by L2 / Infinity Cache."),
            "field_forward_f16": {

@@ -87,9 +87,11 @@ def main():
     ap.add_argument("--kernel", action="append", default=[])
     ap.add_argument("--note", default="")
     ap.add_argument("--timeout", type=int, default=600)
+    ap.add_argument("--summarize-only", action="store_true", help="no GPU step: build the summary from the pass folders OUTDIR/pmc_* already there "
+                    "(a collection that ran out of time leaves its finished passes behind)")
     args = ap.parse_args(argv[:cut])
     os.makedirs(args.outdir, exist_ok=True)
-    names = available()
+    names = None if args.summarize_only else available()
     env = dict(os.environ, TMPDIR="/tmp")
     passes, dropped = [], []
     for spec in args.sets:
@@ -100,6 +102,10 @@ def main():
         if not have:
             continue
         folder = os.path.join(args.outdir, "pmc_" + tag)
+        if args.summarize_only:
+            if glob.glob(os.path.join(folder, "**", "*counter_collection.csv"), recursive=True):
+                passes.append((tag, folder, have))
+            continue
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", *have, "--output-format", "csv", "-d", folder, "-o", "p", "--", *prog]
         print("[pmc_passes]", " ".join(cmd), flush=True)
         with open(os.path.join(args.outdir, f"pmc_{tag}.out"), "w") as so, open(os.path.join(args.outdir, f"pmc_{tag}.err"), "w") as se:
