@@ -386,8 +386,8 @@ void launch_bwd(const T *grad, const float *inputs, T *gg, uint32_t B, uint32_t 
                 uint32_t gridtype, bool ac, uint32_t interp, hipStream_t st, long long *det) {
     const dim3 grid(sdn_div_up(B * C / N_C, 256u), L, 1);
     if (det) {
-        const uint64_t n = (uint64_t)lp.offset[L] * C;
-        (void)hipMemsetAsync(det, 0, n * sizeof(long long), st);
+        const uint64_t n = ((uint64_t)lp.offset[L - 1] + lp.hashmap_size[L - 1]) * C;      // elements of the whole table
+        if (hipMemsetAsync(det, 0, n * sizeof(long long), st) != hipSuccess) return;      // (reported by the caller's sdn_launch_status)
         hipLaunchKernelGGL((k_grid_bwd<T, D, C, N_C, true>), grid, dim3(256), 0, st, grad, inputs, gg, B, L, lp, gridtype, ac, interp, det);
         hipLaunchKernelGGL((k_grid_det_finish<T>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, gg, (const long long *)det, n);
     } else {
