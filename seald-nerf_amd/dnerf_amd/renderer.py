@@ -703,13 +703,25 @@ def _context_streams(k, device):
     0.52 with 7, 8 or 16, 0.49 with 3-4 from the pool; own streams: 0.435-0.439 for 5..9 queues -- profiles/r03_hw_queues.txt).  The
     process still needs GPU_MAX_HW_QUEUES >= contexts + 1 (set before the HIP runtime starts; bench.py does).
     SDN_CTX_PRIORITIES="p0,p1,..." (HIP priorities, -1 high / 0 normal / 1 low, used in turn; measured: no effect);
-    SDN_CTX_STREAMS=torch falls back to the pool."""
+    SDN_CTX_STREAMS=torch falls back to the pool.
+    One set of streams per (device, k, priorities) is created and REUSED by every later loop object of the process: raw HIP streams are
+    never destroyed by torch's ExternalStream wrapper, and each leaked set would shift the queue assignment of the next -- the very
+    sensitivity this function removes.  (Under rocprofv3 the profiler's preloaded library starts the HIP runtime before bench.py can set
+    GPU_MAX_HW_QUEUES: export it in the environment of such a run.)"""
     import os
     if os.environ.get("SDN_CTX_STREAMS", "") == "torch":
         return [torch.cuda.Stream(device=device) for _ in range(k)]
     import ctypes
     spec = os.environ.get("SDN_CTX_PRIORITIES", "").strip() or "0"
-    prios = [int(x) for x in spec.split(",")]
+    try:
+        prios = [int(x) for x in spec.split(",")]
+    except ValueError:
+        raise ValueError(f"SDN_CTX_PRIORITIES={spec!r}: expected comma-separated integers (HIP stream priorities, e.g. '-1,0,0,0')") from None
+    if any(p < -1 or p > 1 for p in prios):
+        raise ValueError(f"SDN_CTX_PRIORITIES={spec!r}: HIP stream priorities are -1 (high), 0, 1 (low)")
+    key = (str(torch.device(device)), int(k), tuple(prios))
+    if key in _CONTEXT_STREAMS:
+        return _CONTEXT_STREAMS[key]
     try:
         hip = ctypes.CDLL("libamdhip64.so")
     except OSError:
@@ -722,7 +734,11 @@ def _context_streams(k, device):
             if rc != 0:
                 raise RuntimeError(f"hipStreamCreateWithPriority failed ({rc})")
             out.append(torch.cuda.ExternalStream(h.value, device=device))
+    _CONTEXT_STREAMS[key] = out
     return out
+
+
+_CONTEXT_STREAMS = {}
 
 
 class PipelinedDeviceLoop:

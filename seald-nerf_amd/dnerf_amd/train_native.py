@@ -118,6 +118,8 @@ class NativeTrainStep:
             self._table_side = (torch.cuda.Stream(device=self.device), torch.cuda.Event(), torch.cuda.Event())
             for e in self._table_side[1:]:
                 e.record()                                # materialises the hipEvent_t handles; the native step re-records them
+            # `model.state_dict()` (a checkpoint, an EMA copy for evaluation) reads the table: order the reader's stream behind the pass
+            self._sd_hook = model.register_state_dict_pre_hook(lambda module, prefix, keep_vars: self.flush())
         # deterministic mode: the one order-dependent sum of a step -- the table gradient's half atomics -- is taken
         # in fixed point with integer atomics instead; two runs from the same state then give the same bits.  Default: SDN_DETERMINISTIC=1
         # in the environment, or torch.use_deterministic_algorithms(True).
@@ -325,7 +327,12 @@ class NativeTrainStep:
         self._pending = {"set": q, "event": done, "time": tv, "local_step": m.local_step, "step_count": self.step_count, "rays": (ro, rd)}
 
     def __call__(self, rays_o=None, rays_d=None, target=None, time=None, bg_color=None, grads_only=False):
-        """One training step on the loaded batch (arguments, if given, are copied into the step's input buffers; `time` by value).
+        """One training step on the loaded batch.  Arguments, if given: `time` is taken by value; fp32 contiguous tensors on this device
+        are READ IN PLACE by the step's kernels (`_adopt`: no device-to-device copy) -- stream order makes later writes on the SAME
+        stream safe, but a loader that refills its ray / target buffers on ANOTHER stream must order that stream behind the step (an
+        event recorded after this call) -- anything else (other dtype / device / layout) is copied into the step's own buffers.
+        `step.rays_o / rays_d` therefore may alias the caller's tensors, and `step.target` is the step's own buffer only in the copied case.
+        A device `time` tensor is read back once per (tensor object, version): change it through torch operations, or pass a number.
         Returns the loss tensor (device, overwritten by the next step).  grads_only: forward + backward only -- gradients stay in the
         workspace (`view("g_deform", ...)`), nothing is updated."""
         if rays_o is not None:

@@ -649,6 +649,10 @@ def test_table_pass_on_a_second_stream_changes_nothing_but_the_schedule():
         sc, model, opt, scaler, target = _setup()
         step = NativeTrainStep(model, opt, scaler, N_RAYS, "cuda", perturb=True, seed=3, overlap_table_update=overlap)
         losses = [step(sc.rays_o, sc.rays_d, target, t).clone() for t in (0.5, 0.25, 0.0, 0.75, 0.5)]
+        if overlap:                                                  # state_dict() orders the reading stream behind the pass by itself (pre-hook)
+            snap = {k: v.clone() for k, v in model.state_dict().items() if k == "encoder.embeddings"}
+            torch.cuda.synchronize()
+            assert torch.equal(snap["encoder.embeddings"], model.encoder.embeddings.detach())
         step.flush()
         early = model.encoder.embeddings.detach().clone()          # stream-ordered read, no device-wide synchronisation before it
         torch.cuda.synchronize()
