@@ -226,6 +226,9 @@ int sdn_field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *
  * of at least 4 tiles of 256 points per CU on a QUAD table; 0 = one tile per workgroup for every launch; -1 = environment SDN_FIELD_PP or
  * the default.  Both produce the same bits: a switch for tests and A/B measurements, not a tuning knob. */
 void sdn_field_select_kernel(int persistent);
+/* Workgroups of a persistent launch: 0 = one per CU (default); a driver that keeps several frames in flight passes fewer (7 / 8 of
+ * the CUs) so that the other frames' small kernels find a free CU while a persistent launch runs. */
+void sdn_field_persistent_workgroups(int n);
 
 /* The fused kernel's QUAD table from embeddings in the reference's layout (gridencoder/grid.py:118-140; cast to fp16 as grid.py:43-44
  * does under autocast): embeddings [ref_offsets_host[16], 2] of `dtype` (SDN_F32 / SDN_F16), ref_offsets_host [17] the reference's level

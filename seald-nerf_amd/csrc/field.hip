@@ -812,6 +812,7 @@ __global__ void k_build_quad_table(const T *__restrict__ emb, QuadLevels q, uint
 namespace sdn_int {
 
 static int g_field_pp = -1;   // 1: large launches take the persistent ping-pong kernel (default), 0: never; -1: read SDN_FIELD_PP
+static int g_field_pp_wgs = 0;   // workgroups of a persistent launch; 0 = one per CU
 
 // launch used by both the C entry point and the device-driven render loop (render.hip)
 int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count, const int32_t *state,
@@ -873,7 +874,16 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
     }
     if (g_field_pp && layout == kLayoutQuad && busy >= (uint32_t)pp_min_tiles_per_cu * (uint32_t)cus && a.n_frames <= kPPMaxFrames && M < (1u << 28)) {
         const uint32_t pairs = sdn_div_up(sdn_div_up(M, kPPTile), 2u);
-        hipLaunchKernelGGL(k_field_pp_f16, dim3(pairs < (uint32_t)cus ? pairs : (uint32_t)cus), dim3(64 * kPPWaves), 0, st, a, lv);
+        // (SDN_FIELD_PP_CUS: workgroups of the persistent launch, default one per CU -- fewer leave CUs to the other frames' small kernels
+        //  of a pipelined stream, which cannot share a CU with a 16-wave, 156-KiB workgroup: a measurement knob)
+        static int env_cus = -1;
+        if (env_cus < 0) {
+            const char *e = getenv("SDN_FIELD_PP_CUS");
+            env_cus = e ? atoi(e) : 0;
+        }
+        int pp_cus = env_cus > 0 ? env_cus : (g_field_pp_wgs > 0 ? g_field_pp_wgs : cus);
+        if (pp_cus > cus) pp_cus = cus;
+        hipLaunchKernelGGL(k_field_pp_f16, dim3(pairs < (uint32_t)pp_cus ? pairs : (uint32_t)pp_cus), dim3(64 * kPPWaves), 0, st, a, lv);
         return sdn_launch_status();
     }
     if (layout == kLayoutQuad) {
@@ -929,6 +939,10 @@ uint32_t sdn_field_weight_blocks(void) { return (uint32_t)kBlkTotal; }
 // Kernel selection for large launches of the fused field network: 1 = persistent ping-pong kernel (the default), 0 = one tile per
 // workgroup for every launch (the two produce identical bits; tests and A/B measurements switch here), -1 = back to SDN_FIELD_PP / default.
 void sdn_field_select_kernel(int persistent) { sdn_int::g_field_pp = persistent; }
+// Workgroups of a persistent launch (0 = one per CU, the default).  A stream of frames in several loop contexts leaves an eighth of the
+// CUs to the other frames' marchers and compositors -- which cannot share a CU with a 16-wave, 156-KiB workgroup and otherwise wait
+// for a whole persistent launch to end: 0.410 -> 0.398 ms per frame with 224 of 256 (profiles/r04_field_pp_kernel.txt).
+void sdn_field_persistent_workgroups(int n) { sdn_int::g_field_pp_wgs = n > 0 ? n : 0; }
 
 // Builds the fused kernel's QUAD table (16 bytes per row, see kLayoutQuad) from embeddings in the reference layout.
 //   embeddings [ref_offsets_host[16], 2] of dtype (SDN_F32 / SDN_F16), ref_offsets_host [17] the reference's level offsets (grid.py:118-127);

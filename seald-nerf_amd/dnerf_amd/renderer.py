@@ -754,6 +754,10 @@ class PipelinedDeviceLoop:
         self.N, self.device, self.overlap_div, self.K = N, device, int(overlap_div), int(contexts)
         self.loops = [DeviceLoop(model, field, N, device, mailbox=mailbox, **kw) for _ in range(self.K)]
         self.streams = _context_streams(self.K, device)
+        if self.K > 1:
+            # several frames in flight: the persistent field launches leave an eighth of the CUs to the other frames' small kernels
+            import sdn_backend as B
+            B.lib.sdn_field_persistent_workgroups(int(torch.cuda.get_device_properties(device).multi_processor_count) * 7 // 8)
         # mailbox=False: ordinary pinned memory -> the driver's event + side-stream copy read-back (see DeviceLoop)
         self.host_state = HostMailbox(self.K) if mailbox else torch.zeros(self.K, 8, dtype=torch.int32).pin_memory()
         self._ctxs = (ctypes.POINTER(SdnRenderCtx) * self.K)(*[ctypes.pointer(lp.ctx) for lp in self.loops])

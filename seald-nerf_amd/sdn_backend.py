@@ -153,6 +153,8 @@ lib.sdn_host_mailbox_alloc.restype = ctypes.c_void_p
 lib.sdn_host_mailbox_alloc.argtypes = [ctypes.c_uint32]
 lib.sdn_field_select_kernel.restype = None
 lib.sdn_field_select_kernel.argtypes = [ctypes.c_int]
+lib.sdn_field_persistent_workgroups.restype = None
+lib.sdn_field_persistent_workgroups.argtypes = [ctypes.c_int]
 for _name, _args in PROTOTYPES.items():
     _fn = getattr(lib, _name)
     _fn.argtypes = _args

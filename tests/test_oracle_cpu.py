@@ -241,7 +241,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert not missing, missing
     import sdn_backend
     declared = (set(sdn_backend.PROTOTYPES) | set(sdn_backend.PROTOTYPES_U64) | set(sdn_backend.PROTOTYPES_U32)
-                | {"sdn_version", "sdn_host_mailbox_alloc", "sdn_field_select_kernel"})
+                | {"sdn_version", "sdn_host_mailbox_alloc", "sdn_field_select_kernel", "sdn_field_persistent_workgroups"})
     assert set(names) == declared, sorted(set(names) ^ declared)
 
 
