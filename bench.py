@@ -29,7 +29,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA
 GRID_BYTES_PER_POINT = {"f16": 588.0, "f32": 1164.0}  # gathers + 12 B in + outputs
 FIELD_FLOP_PER_POINT = 235520.0                          # 117 760 MAC
-PMC_SUMMARY = "r03_field_pmc_summary.json"               # rocprofv3 --pmc summary the static `traffic` figure comes from
+PMC_SUMMARY = "r04_field_pmc_summary.json"               # rocprofv3 --pmc summary the static `traffic` figure comes from
 
 
 def parse():
