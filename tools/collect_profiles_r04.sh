@@ -61,6 +61,7 @@ echo "cpu 800 done"
 fi
 if want modes; then
 python3 bench.py --mode train --steps 300 --warmup 10 > $OUT/bench_train.json 2>/dev/null || exit 1
+SDN_DETERMINISTIC=1 python3 bench.py --mode train --steps 300 --warmup 10 > $OUT/bench_train_deterministic.json 2>/dev/null || exit 1
 python3 bench.py --mode seald --steps 20 > $OUT/bench_seald.json 2>/dev/null || exit 1
 python3 bench.py --mode seald-train --steps 50 > $OUT/bench_seald_train.json 2>/dev/null || exit 1
 python3 bench.py --mode density --steps 8 > $OUT/bench_density.json 2>/dev/null || exit 1
