@@ -118,6 +118,7 @@ struct FieldArgs {
     // of step (0 = off)
     uint32_t stagger_cycles, stagger_lo, stagger_hi;
     uint32_t n_frames;        // rows of bias0 (frames of a frame group; 1 without slot_frame)
+    uint32_t pp_soft;         // persistent kernel: the workgroup count to stay within unless more workgroups save a whole round (0 = gridDim.x)
 };
 
 // Morton code -> one coordinate (bits 0, 3, 6, ...): raymarching.cu:282-289
@@ -851,7 +852,7 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
         if (pin == 1) small = false;
         if (pin == 2) small = true;
     }
-    a.stagger_cycles = 0; a.stagger_lo = a.stagger_hi = 0;
+    a.stagger_cycles = 0; a.stagger_lo = a.stagger_hi = 0; a.pp_soft = 0;
     if (!small) {
         static int stag = -1;
         if (stag < 0) {
@@ -883,7 +884,17 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
         }
         int pp_cus = env_cus > 0 ? env_cus : (g_field_pp_wgs > 0 ? g_field_pp_wgs : cus);
         if (pp_cus > cus) pp_cus = cus;
-        hipLaunchKernelGGL(k_field_pp_f16, dim3(pairs < (uint32_t)pp_cus ? pairs : (uint32_t)pp_cus), dim3(64 * kPPWaves), 0, st, a, lv);
+        // The launch covers every CU; the kernel, which knows the live count, keeps G of the workgroups (the others leave at once):
+        // the fewest that finish in as many rounds as `pp_cus` would need -- or, when one workgroup per CU saves a whole round over
+        // `pp_cus`, the fewest that finish in that many (SDN_FIELD_PP_BALANCE=0: exactly pp_cus, as before)
+        static int balance = -1;
+        if (balance < 0) {
+            const char *e = getenv("SDN_FIELD_PP_BALANCE");
+            balance = e ? atoi(e) : 1;
+        }
+        const uint32_t grid = balance ? (uint32_t)cus : (uint32_t)pp_cus;
+        a.pp_soft = (uint32_t)pp_cus | (balance ? 0u : 0x80000000u);
+        hipLaunchKernelGGL(k_field_pp_f16, dim3(pairs < grid ? pairs : grid), dim3(64 * kPPWaves), 0, st, a, lv);
         return sdn_launch_status();
     }
     if (layout == kLayoutQuad) {
@@ -914,7 +925,7 @@ int field_cells_f16(const int32_t *cells, const uint32_t *cell_count, uint32_t n
     a.inv_2bound = exact_reciprocal(2 * bound);
     a.slot_frame = nullptr;
     a.cell_noise = noise; a.cell_seed = seed;
-    a.stagger_cycles = 0; a.stagger_lo = a.stagger_hi = 0; a.n_frames = 1;
+    a.stagger_cycles = 0; a.stagger_lo = a.stagger_hi = 0; a.n_frames = 1; a.pp_soft = 0;
     const float half_grid = cas_bound / (float)grid_size;
     a.cell_inv = 1.0f / (float)(grid_size - 1); a.cell_span = cas_bound - half_grid; a.cell_half = half_grid;
     const uint32_t wgs = sdn_div_up(n, (uint32_t)kPointsPerWG);
