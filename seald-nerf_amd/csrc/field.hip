@@ -886,14 +886,14 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
         if (pp_cus > cus) pp_cus = cus;
         // The launch covers every CU; the kernel, which knows the live count, keeps G of the workgroups (the others leave at once):
         // the fewest that finish in as many rounds as `pp_cus` would need -- or, when one workgroup per CU saves a whole round over
-        // `pp_cus`, the fewest that finish in that many (SDN_FIELD_PP_BALANCE=0: exactly pp_cus, as before)
+        // `pp_cus`, the fewest that finish in that many (SDN_FIELD_PP_BALANCE=0: exactly pp_cus, as before; 2: never more than pp_cus)
         static int balance = -1;
         if (balance < 0) {
             const char *e = getenv("SDN_FIELD_PP_BALANCE");
-            balance = e ? atoi(e) : 1;
+            balance = e ? atoi(e) : 0;
         }
-        const uint32_t grid = balance ? (uint32_t)cus : (uint32_t)pp_cus;
-        a.pp_soft = (uint32_t)pp_cus | (balance ? 0u : 0x80000000u);
+        const uint32_t grid = balance == 1 ? (uint32_t)cus : (uint32_t)pp_cus;
+        a.pp_soft = (uint32_t)pp_cus | (balance == 0 ? 0x80000000u : (balance == 2 ? 0x40000000u : 0u));
         hipLaunchKernelGGL(k_field_pp_f16, dim3(pairs < grid ? pairs : grid), dim3(64 * kPPWaves), 0, st, a, lv);
         return sdn_launch_status();
     }

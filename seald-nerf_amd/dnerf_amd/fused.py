@@ -218,10 +218,14 @@ class FusedField:
         if self._buf is None or self._buf[0].shape[0] < M:
             self._alloc(M)
         sigmas, rgbs = self._buf[0][:M], self._buf[1][:M]
+        c = self.__dict__.get("_const")
+        if c is None or c[0] is not self.weights or c[1] is not self.table or c[2] is not self.offsets_host:
+            # (validated addresses of what does not change between calls: the reference-shaped loops are bound by host time)
+            c = self._const = (self.weights, self.table, self.offsets_host, ptr(self.weights), ptr(self.table), self.offsets_host.ctypes.data)
         with sdn_backend.timed("field_forward_f16", M):
             check(sdn_backend.lib.sdn_field_forward_f16(ptr(xyzs, torch.float32, "xyzs"), ptr(dirs, torch.float32, "dirs"),
-                                                        ptr(live_idx), ptr(live_count), M, ptr(self.weights), ptr(self.bias0),
-                                                        ptr(self.table), self.offsets_host.ctypes.data, self.S, self.H, self.bound,
+                                                        ptr(live_idx), ptr(live_count), M, c[3], ptr(self.bias0),
+                                                        c[4], c[5], self.S, self.H, self.bound,
                                                         self.density_scale, self.zero_deform, ptr(sigmas), ptr(rgbs), stream()),
                   "field_forward_f16")
         return sigmas, rgbs

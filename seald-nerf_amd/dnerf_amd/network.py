@@ -113,30 +113,39 @@ class NeRFNetwork(NeRFRenderer):
     fused_inference = True       # class default; set False on a model to keep `forward` on the op-by-op path in every mode
 
     def _fused_inference_ok(self, x, d):
+        # (cheapest tests first: this runs on every forward call, and the reference-shaped render loop is bound by host time)
         if not self.fused_inference or self.training or torch.is_grad_enabled() or not x.is_cuda or x.dim() != 2 or x.shape[0] == 0:
             return False
         if not torch.is_autocast_enabled("cuda") or torch.get_autocast_dtype("cuda") != torch.float16:
             return False       # fp32 evaluation has no fused kernel: the op-by-op path meets the 1e-4 bar
         if x.dtype != torch.float32 or d.dtype != torch.float32:
             return False
-        from . import fused
-        enc = self.encoder
-        return (fused.available() and len(self.deform_net) == 8 and self.hidden_dim_deform == 128 and self.hidden_dim == 64
-                and self.num_layers == 2 and self.geo_feat_dim == 15 and self.num_layers_color == 3 and self.hidden_dim_color == 64
-                and enc.gridtype == "tiled" and not enc.align_corners and enc.interpolation == "linear" and enc.num_levels == 16
-                and enc.level_dim == 2)
+        ok = self.__dict__.get("_fused_arch_ok")
+        if ok is None:         # the architecture does not change after construction
+            from . import fused
+            enc = self.encoder
+            ok = bool(fused.available() and len(self.deform_net) == 8 and self.hidden_dim_deform == 128 and self.hidden_dim == 64
+                      and self.num_layers == 2 and self.geo_feat_dim == 15 and self.num_layers_color == 3 and self.hidden_dim_color == 64
+                      and enc.gridtype == "tiled" and not enc.align_corners and enc.interpolation == "linear" and enc.num_levels == 16
+                      and enc.level_dim == 2)
+            self.__dict__["_fused_arch_ok"] = ok
+        return ok
 
     def _parameter_epoch(self):
-        ps = [self.encoder.embeddings] + [l.weight for l in self.deform_net] + [l.weight for l in self.sigma_net] + [l.weight for l in self.color_net]
-        return tuple((p.data_ptr(), p._version) for p in ps)
+        ps = self.__dict__.get("_fused_params")
+        if ps is None:         # the Parameter OBJECTS (load_state_dict, .to(), optimizer steps keep them; their address / version move)
+            ps = tuple([self.encoder.embeddings] + [l.weight for l in self.deform_net] + [l.weight for l in self.sigma_net]
+                       + [l.weight for l in self.color_net])
+            self.__dict__["_fused_params"] = ps
+        return tuple([(p.data_ptr(), p._version) for p in ps])
 
     def _forward_fused(self, x, d, t):
         """sigma [M] f32 (trunc_exp, density_scale NOT applied: the caller multiplies, dnerf/renderer.py:368), rgb [M,3] (the fp16 values
         of torch.sigmoid on the half logits, held in f32), deform = None (callers of the inference branch discard it)."""
-        from . import fused
         epoch = self._parameter_epoch()
         cache = self.__dict__.get("_fused_cache")
         if cache is None or cache[0] != epoch[1:]:
+            from . import fused
             # (the fp16 table cast of grid.py:43-44 and the packed weights are made once per parameter version, not once per call)
             field = fused.FusedField(self, t, fp16=True)
             field.density_scale = 1.0
@@ -159,7 +168,9 @@ class NeRFNetwork(NeRFRenderer):
                 self.__dict__["_fused_time"] = (weakref.ref(t), t._version, value)
         else:
             value = seen[2]
-        field.set_time(value)
+        if cache[1].__dict__.get("_time_set") != value:
+            field.set_time(value)
+            field._time_set = value
         # (Evaluating only the slots that hold a sample -- a list built from the zero direction vectors of a marcher's empty slots --
         #  was measured and dropped: the list kernel and the zero fills cost more than the skipped slots save, 2.73 -> 3.08 ms per frame.)
         field._buf = None          # fresh output tensors per call (caching allocator, no launch): the caller owns them, as on the op-by-op path

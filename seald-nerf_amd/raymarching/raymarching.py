@@ -225,62 +225,73 @@ def _cull_grid_of(bitfield, C, H):
     return grid
 
 
+def _to_f32(t):
+    return t if t.dtype == _f32 else t.float()
+
+
 class _march_rays(Function):
+    """The reference wraps the inference marcher in an autograd Function only for `custom_fwd(cast_inputs=float32)`; it has no
+    backward (raymarching.py:300-346).  Here `march_rays` / `composite_rays` are plain functions that do the same cast themselves:
+    `Function.apply` + the autocast bookkeeping cost ~10 us of host time per call, and the reference-shaped render loop is bound by
+    exactly that (profiles/r04_reference_shaped_host_time.txt).  The classes stay for callers that name them."""
+
     @staticmethod
-    @custom_fwd(device_type="cuda", cast_inputs=_f32)
-    def forward(ctx, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far, align=-1,
-                perturb=False, dt_gamma=0, max_steps=1024):
-        """raymarching.py:300-346.  -> xyzs [Mp,3], dirs [Mp,3], deltas [Mp,2], Mp = n_alive*n_step padded
-        with `M += align - M % align` (a full `align` when already aligned, as in the reference :331-332)."""
-        rays_o, rays_d = _rays(rays_o, rays_d)
-        dev = rays_o.device
-        M0 = n_alive * n_step
-        M = M0
-        if align > 0:
-            M += align - (M % align)
-        xyzs = torch.empty(M, 3, dtype=_f32, device=dev)
-        dirs = torch.empty(M, 3, dtype=_f32, device=dev)
-        deltas = torch.empty(M, 2, dtype=_f32, device=dev)
-        noises = torch.rand(n_alive, dtype=_f32, device=dev) if perturb else None
-        cull = _cull_grid_of(density_bitfield, C, H)
-        if cull is not None:
-            # the exact cull grid (sdn_build_cull_grid, kept per occupancy slice and tensor version): rays whose remaining segment stays
-            # clear of every occupied voxel retire at once instead of probing hundreds of empty voxels -- the same samples, bit for bit
-            # (tests/test_gpu_ops_parity.py), 122 -> ~25 us per call in the reference-shaped loop of an 800x800 frame; the kernel also
-            # clears the padded tail itself
-            _check(_lib.sdn_march_rays_ex(int(n_alive), int(n_step), _ptr(rays_alive, _i32, "rays_alive"), _ptr(rays_t, _f32, "rays_t"),
-                                          _ptr(rays_o, _f32, "rays_o"), _ptr(rays_d, _f32, "rays_d"), float(bound), float(dt_gamma),
-                                          int(max_steps), int(C), int(H), _ptr(density_bitfield, torch.uint8, "density_bitfield"),
-                                          _ptr(far, _f32, "far"), _ptr(xyzs), _ptr(dirs), _ptr(deltas), _ptr(noises), int(M), _ptr(cull),
-                                          None, None, _stream()), "march_rays_ex")
-            return xyzs, dirs, deltas
-        if M > M0:  # the kernel writes every slot below n_alive*n_step; only the tail needs clearing
-            xyzs[M0:].zero_(); dirs[M0:].zero_(); deltas[M0:].zero_()
-        _check(_lib.sdn_march_rays(int(n_alive), int(n_step), _ptr(rays_alive, _i32, "rays_alive"), _ptr(rays_t, _f32, "rays_t"),
-                                   _ptr(rays_o, _f32, "rays_o"), _ptr(rays_d, _f32, "rays_d"), float(bound), float(dt_gamma),
-                                   int(max_steps), int(C), int(H), _ptr(density_bitfield, torch.uint8, "density_bitfield"),
-                                   _ptr(near, _f32, "near"), _ptr(far, _f32, "far"), _ptr(xyzs), _ptr(dirs), _ptr(deltas),
-                                   _ptr(noises), _stream()), "march_rays")
+    def forward(ctx, *args):
+        return march_rays(*args)
+
+
+def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far, align=-1,
+               perturb=False, dt_gamma=0, max_steps=1024):
+    """raymarching.py:300-346.  -> xyzs [Mp,3], dirs [Mp,3], deltas [Mp,2], Mp = n_alive*n_step padded
+    with `M += align - M % align` (a full `align` when already aligned, as in the reference :331-332)."""
+    rays_o, rays_d = _rays(_to_f32(rays_o), _to_f32(rays_d))
+    rays_t, near, far = _to_f32(rays_t), _to_f32(near), _to_f32(far)
+    dev = rays_o.device
+    M0 = n_alive * n_step
+    M = M0
+    if align > 0:
+        M += align - (M % align)
+    xyzs = torch.empty(M, 3, dtype=_f32, device=dev)
+    dirs = torch.empty(M, 3, dtype=_f32, device=dev)
+    deltas = torch.empty(M, 2, dtype=_f32, device=dev)
+    noises = torch.rand(n_alive, dtype=_f32, device=dev) if perturb else None
+    cull = _cull_grid_of(density_bitfield, C, H)
+    if cull is not None:
+        # the exact cull grid (sdn_build_cull_grid, kept per occupancy slice and tensor version): rays whose remaining segment stays
+        # clear of every occupied voxel retire at once instead of probing hundreds of empty voxels -- the same samples, bit for bit
+        # (tests/test_gpu_ops_parity.py), 122 -> ~25 us per call in the reference-shaped loop of an 800x800 frame; the kernel also
+        # clears the padded tail itself
+        _check(_lib.sdn_march_rays_ex(int(n_alive), int(n_step), _ptr(rays_alive, _i32, "rays_alive"), _ptr(rays_t, _f32, "rays_t"),
+                                      _ptr(rays_o, _f32, "rays_o"), _ptr(rays_d, _f32, "rays_d"), float(bound), float(dt_gamma),
+                                      int(max_steps), int(C), int(H), _ptr(density_bitfield, torch.uint8, "density_bitfield"),
+                                      _ptr(far, _f32, "far"), _ptr(xyzs), _ptr(dirs), _ptr(deltas), _ptr(noises), int(M), _ptr(cull),
+                                      None, None, _stream()), "march_rays_ex")
         return xyzs, dirs, deltas
-
-
-march_rays = _march_rays.apply
+    if M > M0:  # the kernel writes every slot below n_alive*n_step; only the tail needs clearing
+        xyzs[M0:].zero_(); dirs[M0:].zero_(); deltas[M0:].zero_()
+    _check(_lib.sdn_march_rays(int(n_alive), int(n_step), _ptr(rays_alive, _i32, "rays_alive"), _ptr(rays_t, _f32, "rays_t"),
+                               _ptr(rays_o, _f32, "rays_o"), _ptr(rays_d, _f32, "rays_d"), float(bound), float(dt_gamma),
+                               int(max_steps), int(C), int(H), _ptr(density_bitfield, torch.uint8, "density_bitfield"),
+                               _ptr(near, _f32, "near"), _ptr(far, _f32, "far"), _ptr(xyzs), _ptr(dirs), _ptr(deltas),
+                               _ptr(noises), _stream()), "march_rays")
+    return xyzs, dirs, deltas
 
 
 class _composite_rays(Function):
     @staticmethod
-    @custom_fwd(device_type="cuda", cast_inputs=_f32)  # sigmas / rgbs arrive as fp16 under autocast
-    def forward(ctx, n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh=1e-2):
-        """raymarching.py:354-370.  Mutates rays_alive (-1 = terminated), rays_t, weights_sum, depth, image."""
-        _check(_lib.sdn_composite_rays(int(n_alive), int(n_step), float(T_thresh), _ptr(rays_alive, _i32, "rays_alive"),
-                                       _ptr(rays_t, _f32, "rays_t"), _ptr(sigmas.contiguous(), _f32, "sigmas"),
-                                       _ptr(rgbs.contiguous(), _f32, "rgbs"), _ptr(deltas.contiguous(), _f32, "deltas"),
-                                       _ptr(weights_sum, _f32, "weights_sum"), _ptr(depth, _f32, "depth"), _ptr(image, _f32, "image"),
-                                       _stream()), "composite_rays")
-        return tuple()
+    def forward(ctx, *args):
+        return composite_rays(*args)
 
 
-composite_rays = _composite_rays.apply
+def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh=1e-2):
+    """raymarching.py:354-370.  Mutates rays_alive (-1 = terminated), rays_t, weights_sum, depth, image."""
+    sigmas, rgbs, deltas = _to_f32(sigmas), _to_f32(rgbs), _to_f32(deltas)   # sigmas / rgbs arrive as fp16 under autocast (op-by-op network)
+    _check(_lib.sdn_composite_rays(int(n_alive), int(n_step), float(T_thresh), _ptr(rays_alive, _i32, "rays_alive"),
+                                   _ptr(rays_t, _f32, "rays_t"), _ptr(sigmas.contiguous(), _f32, "sigmas"),
+                                   _ptr(rgbs.contiguous(), _f32, "rgbs"), _ptr(deltas.contiguous(), _f32, "deltas"),
+                                   _ptr(weights_sum, _f32, "weights_sum"), _ptr(depth, _f32, "depth"), _ptr(image, _f32, "image"),
+                                   _stream()), "composite_rays")
+    return tuple()
 
 
 def compact_alive(rays_alive, out=None, count=None, scratch=None):

@@ -199,10 +199,17 @@ class HostMailbox:
             pass
 
 
+_device_seen = False
+
+
 def require_device():
+    global _device_seen
+    if _device_seen:
+        return
     if not torch.cuda.is_available():
         raise SdnError("SealD-NeRF HIP operators need a ROCm device (torch.cuda.is_available() is False); "
                        "there is no CPU fallback")
+    _device_seen = True
 
 
 def to_device(t):
@@ -224,7 +231,14 @@ def ptr(t, dtype=None, name="tensor"):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device (the raw getter skips building a torch.cuda.Stream object: the
+    wrappers call this once per launch, and the reference-shaped loops are bound by exactly this kind of host work)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

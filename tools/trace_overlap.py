@@ -25,7 +25,7 @@ def union(iv):
 
 
 def kind(n):
-    return "F" if "k_field_f16" in n else ("M" if ("k_composite_march" in n or "k_march_rays" in n) else "o")
+    return "F" if "k_field" in n else ("M" if ("k_composite_march" in n or "k_march_rays" in n) else "o")
 
 
 def per_queue(rows, t0):
@@ -69,16 +69,29 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
     ap.add_argument("--window-ms", type=float, default=150.0, help="analyse the LAST this-many ms of the trace (the timed stream)")
+    ap.add_argument("--densest", action="store_true", help="analyse the window with the most launches instead of the last one")
     args = ap.parse_args()
     rows = []
     for r in csv.DictReader(open(args.trace)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0")))
     t_end = max(r[1] for r in rows)
     t0 = t_end - int(args.window_ms * 1e6)
+    if args.densest:   # the window of that length holding the most kernel launches: the pipelined stream, wherever it sits in the trace
+        starts = sorted(r[0] for r in rows)
+        w, best, j = int(args.window_ms * 1e6), (0, starts[0]), 0
+        for i, s in enumerate(starts):
+            while starts[j] < s - w:
+                j += 1
+            if i - j + 1 > best[0]:
+                best = (i - j + 1, s)
+        t_end = best[1]
+        t0 = t_end - w
+        rows = [r for r in rows if r[0] < t_end]
+        rows = [(s, min(e, t_end), n, q) for s, e, n, q in rows]
     per_queue(rows, t0)
     rows = [(max(s, t0), e, n) for s, e, n, _ in rows if e > t0]
     wall = t_end - t0
-    field = [(s, e) for s, e, n in rows if "k_field_f16" in n]
+    field = [(s, e) for s, e, n in rows if "k_field" in n]
     march = [(s, e) for s, e, n in rows if "k_composite_march" in n or "k_march_rays" in n]
     allk = [(s, e) for s, e, _ in rows]
     u_all, u_field, u_march = union(allk), union(field), union(march)
