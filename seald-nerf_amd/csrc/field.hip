@@ -874,7 +874,7 @@ int field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *live
         pp_min_tiles_per_cu = e ? atoi(e) : 4;
     }
     if (g_field_pp && layout == kLayoutQuad && busy >= (uint32_t)pp_min_tiles_per_cu * (uint32_t)cus && a.n_frames <= kPPMaxFrames && M < (1u << 28)) {
-        const uint32_t pairs = sdn_div_up(sdn_div_up(M, kPPTile), 2u);
+        const uint32_t pairs = sdn_div_up(M, kPPTile);     // (tiles: the unit the kernel deals out)
         // (SDN_FIELD_PP_CUS: workgroups of the persistent launch, default one per CU -- fewer leave CUs to the other frames' small kernels
         //  of a pipelined stream, which cannot share a CU with a 16-wave, 156-KiB workgroup: a measurement knob)
         static int env_cus = -1;
