@@ -285,11 +285,20 @@ struct FrameRun {
                 uint64_t v;
                 uint32_t spins = 0;
                 auto t0 = std::chrono::steady_clock::now();
+                auto t_query = t0;
                 while (((v = __atomic_load_n(word, __ATOMIC_ACQUIRE)) >> 32) != want) {
-                    if ((++spins & 0xFFFFu) == 0) {
-                        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(kDriverTimeoutSeconds)) return SDN_E_TIMEOUT;
-                        hipError_t q = hipStreamQuery(st);             // a faulted kernel never publishes: surface the error
-                        if (q != hipSuccess && q != hipErrorNotReady) return (int)q;
+                    if ((++spins & 0x3FFFu) == 0) {
+                        // A faulted kernel never publishes: surface the error -- but only after 5 ms without news, and then every 5 ms.
+                        // hipStreamQuery puts a marker packet into the stream; asked every 65 536 spins (the cached mailbox word spins at
+                        // ~1 ns: once per iteration of a lone frame) it cost 5.9 us in front of the next iteration's first kernel, 58 us of
+                        // a 1.04 ms frame (rocprofv3 trace, profiles/r04_lone_frame_timeline.txt)
+                        const auto now = std::chrono::steady_clock::now();
+                        if (now - t0 > std::chrono::seconds(kDriverTimeoutSeconds)) return SDN_E_TIMEOUT;
+                        if (now - t_query > std::chrono::milliseconds(5)) {
+                            t_query = now;
+                            hipError_t q = hipStreamQuery(st);
+                            if (q != hipSuccess && q != hipErrorNotReady) return (int)q;
+                        }
                     }
                 }
                 n_prev = (int32_t)(uint32_t)v;
@@ -426,6 +435,7 @@ int sdn_render_frames_pipelined_f16(const SdnRenderCtx *const *ctxs, uint32_t n_
     auto t_last = stats ? now() : 0.0;
     uint32_t idle_spins = 0;
     auto t_progress = std::chrono::steady_clock::now();
+    auto t_query = t_progress;
     while (finished < n_frames) {
         n_loops++;
         bool progress = false;
@@ -462,12 +472,17 @@ int sdn_render_frames_pipelined_f16(const SdnRenderCtx *const *ctxs, uint32_t n_
         if (!progress) {
             rc = launch_next();
             if (rc) return fail(rc);
-            if ((++idle_spins & 0xFFFFu) == 0) {
-                // nothing has arrived for a while: surface a device error, and give up after 20 s without any iteration completing
-                // (a hung kernel never publishes its mailbox word and hipStreamQuery keeps answering "not ready")
-                for (uint32_t c = 0; c < n_ctx; c++)
-                    if (frame_of[c] >= 0) { hipError_t q = hipStreamQuery((hipStream_t)streams[c]); if (q != hipSuccess && q != hipErrorNotReady) return fail((int)q); }
-                if (std::chrono::steady_clock::now() - t_progress > std::chrono::seconds(kDriverTimeoutSeconds)) return SDN_E_TIMEOUT;
+            if ((++idle_spins & 0x3FFFu) == 0) {
+                // nothing has arrived for 5 ms (and every 5 ms from then on): surface a device error, and give up after 20 s without any
+                // iteration completing (a hung kernel never publishes its mailbox word and hipStreamQuery keeps answering "not ready").
+                // Time-based, not spin-count-based: every hipStreamQuery is a marker packet in that loop's stream (see FrameRun::settle)
+                const auto now_c = std::chrono::steady_clock::now();
+                if (now_c - t_progress > std::chrono::milliseconds(5) && now_c - t_query > std::chrono::milliseconds(5)) {
+                    t_query = now_c;
+                    for (uint32_t c = 0; c < n_ctx; c++)
+                        if (frame_of[c] >= 0) { hipError_t q = hipStreamQuery((hipStream_t)streams[c]); if (q != hipSuccess && q != hipErrorNotReady) return fail((int)q); }
+                }
+                if (now_c - t_progress > std::chrono::seconds(kDriverTimeoutSeconds)) return SDN_E_TIMEOUT;
             }
         } else {
             idle_spins = 0;
