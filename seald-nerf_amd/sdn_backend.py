@@ -55,6 +55,7 @@ PROTOTYPES = {
     "sdn_seal_bbox_map_source": [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sdn_seal_modify_rgb": [_vp, _vp, _u32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "sdn_field_forward_f16": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _f32, _u32, _f32, _f32, _i32, _vp, _vp, _vp],
+    "sdn_field_forward_f32": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _f32, _u32, _f32, _f32, _i32, _vp, _vp, _vp],
     "sdn_field_build_quad_table": [_vp, _i32, _vp, _f32, _u32, _vp, _vp],
     "sdn_density_query_cells_f16": [_vp, _vp, _u32, _vp, _u32, _u32, _f32, _vp, _vp, _vp, _vp, _f32, _u32, _f32, _f32, _i32, _vp, _vp],
     "sdn_density_grid_ema": [_vp, _vp, ctypes.c_uint64, _f32, _vp, _vp],
@@ -134,6 +135,7 @@ PROTOTYPES.update({
 
 PROTOTYPES_U32 = {
     "sdn_field_weight_blocks": [],
+    "sdn_field_weight_floats_f32": [],
     "sdn_cull_grid_bytes": [],
 }
 PROTOTYPES_U64 = {

@@ -1,0 +1,87 @@
+"""The fp32 fused field kernel (csrc/field_f32.hip, `dnerf_amd.fused_f32.FusedFieldF32`): the reference network WITHOUT `-O`
+(dnerf/network.py:123-169 in float32) in one launch.  Bars are the fp32 ones of the north star: 1e-4 against the float64-accumulated
+oracle and against the op-by-op fp32 network, for the field's outputs and for a rendered frame; sample counts and traces exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import render as orender  # noqa: E402
+from oracle.field import FieldOracle  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def small_scene():
+    from dnerf_amd.bench_scene import build_scene
+    return build_scene(H=64, W=64, device="cuda", seed=0)
+
+
+@pytest.mark.parametrize("t", [0.5, 0.0, 0.93])
+def test_fp32_fused_field_vs_oracle_and_op_by_op_network(small_scene, t):
+    """sigma / rgb of 10 000 points (inside the figure, near it, outside the box: the grid's out-of-range rule; a ragged last tile) at
+    three time stamps incl. the canonical one (t == 0: no deformation)."""
+    from dnerf_amd.fused_f32 import FusedFieldF32
+    from dnerf_amd.bench_scene import _probe_points
+    sc = small_scene
+    rng = np.random.default_rng(5)
+    n = 10000 + 37
+    pts = np.concatenate([_probe_points(sc.bitfield, 6000, 3), rng.uniform(-1.2, 1.2, (n - 6000, 3)).astype(np.float32)]).astype(np.float32)
+    x = torch.from_numpy(pts).cuda()
+    d = torch.nn.functional.normalize(torch.randn(n, 3, device="cuda"), dim=1).contiguous()
+    tt = torch.tensor([[t]], dtype=torch.float32, device="cuda")
+    f = FusedFieldF32(sc.model, tt)
+    f.density_scale = 1.0
+    s, c = f(x, d)
+    torch.cuda.synchronize()
+    assert torch.isfinite(s).all() and torch.isfinite(c).all()
+    with torch.no_grad():
+        keep = sc.model.fused_inference
+        sc.model.fused_inference = False
+        try:
+            s_ops, c_ops, _ = sc.model(x, d, tt)
+        finally:
+            sc.model.fused_inference = keep
+    o = FieldOracle(orender.state_of(sc.model), mode="fp32")
+    s_ref, c_ref, _ = o.forward(pts, d.cpu().numpy(), t)
+    np.testing.assert_allclose(s.cpu().numpy(), s_ref, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(c.cpu().numpy(), c_ref, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(s.cpu().numpy(), s_ops.float().cpu().numpy(), rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(c.cpu().numpy(), c_ops.float().cpu().numpy(), rtol=2e-4, atol=1e-6)
+    assert float(s.max()) > 1.0 and 0.0 < float(c.min()) and float(c.max()) < 1.0
+
+
+def test_fp32_fused_field_live_list_leaves_other_slots_alone(small_scene):
+    from dnerf_amd.fused_f32 import FusedFieldF32
+    from dnerf_amd.bench_scene import _probe_points
+    sc = small_scene
+    n = 3000
+    x = torch.from_numpy(_probe_points(sc.bitfield, n, 9)).cuda()
+    d = torch.nn.functional.normalize(torch.randn(n, 3, device="cuda"), dim=1).contiguous()
+    f = FusedFieldF32(sc.model, 0.4)
+    s_all, c_all = f(x, d)
+    s_all, c_all = s_all.clone(), c_all.clone()
+    idx = torch.randperm(n, device="cuda")[:1111].to(torch.int32).contiguous()
+    cnt = torch.tensor([idx.shape[0]], dtype=torch.int32, device="cuda")
+    f._alloc(n)
+    f._buf[0].fill_(-1.0); f._buf[1].fill_(-1.0)
+    s, c = f(x, d, live_idx=idx, live_count=cnt)
+    keep = torch.ones(n, dtype=torch.bool, device="cuda"); keep[idx.long()] = False
+    assert bool((s[keep] == -1).all()) and bool((c[keep] == -1).all())
+    assert torch.equal(s[~keep], s_all[~keep]) and torch.equal(c[~keep], c_all[~keep])      # a point's result does not depend on its tile
+
+
+def test_render_frame_fp32_through_the_fused_field_vs_oracle(small_scene):
+    """The host-stepped loop over the drop-in operators with the fp32 fused field in place of the op-by-op network: trace and sample
+    count exact, image / depth / weights within 1e-4 of the oracle's fp32 render -- the bar the fp16 kernel cannot meet."""
+    from dnerf_amd.fused_f32 import FusedFieldF32
+    from dnerf_amd.renderer import render_frame
+    sc = small_scene
+    f = FusedFieldF32(sc.model, sc.time)
+    out = render_frame(sc.model, sc.rays_o, sc.rays_d, sc.time, fp16=False, field=f)
+    ref = orender.render_frame_oracle(sc, mode="fp32")
+    assert out["n_samples"] == ref["n_samples"] > 1000
+    assert [tuple(t) for t in out["trace"]] == [tuple(t) for t in ref["trace"]]
+    np.testing.assert_allclose(out["image"].cpu().numpy(), ref["image"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(np.nan_to_num(out["depth"].cpu().numpy()), np.nan_to_num(ref["depth"]), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(out["weights_sum"].cpu().numpy(), ref["weights_sum"], rtol=1e-4, atol=1e-4)
