@@ -27,6 +27,7 @@ import torch  # noqa: E402
 METRIC = "rendered rays/sec + sampled-points/sec, 800×800 D-NeRF jumpingjacks"
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA
+MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32: the fp32 vector rate (MI355X_MICROARCH.md)
 GRID_BYTES_PER_POINT = {"f16": 588.0, "f32": 1164.0}  # gathers + 12 B in + outputs
 FIELD_FLOP_PER_POINT = 235520.0                          # 117 760 MAC
 PMC_SUMMARY = "r04_field_pmc_summary.json"               # rocprofv3 --pmc summary the static `traffic` figure comes from
@@ -500,7 +501,12 @@ def main():
     field_kind = args.field
     if field_kind == "auto":
         field_kind = "fused" if fused.available() else "ops"
-    field = fused.FusedField(sc.model, sc.time, fp16=fp16) if field_kind == "fused" else None
+    if field_kind == "fused" and not fp16:       # --fp32: the reference without -O through the fp32 fused kernel (csrc/field_f32.hip)
+        from dnerf_amd.fused_f32 import FusedFieldF32
+        field = FusedFieldF32(sc.model, sc.time)
+        args.no_secondary = True                 # (the secondary figures describe the -O path)
+    else:
+        field = fused.FusedField(sc.model, sc.time, fp16=fp16) if field_kind == "fused" else None
     import sdn_backend
     timers = sdn_backend.KernelTimers()
     loop_kind = args.loop
@@ -772,7 +778,7 @@ def main():
                 + (f"; {n_excl} of them (the last" + (" and the quarter points" if n_excl > 2 else (" and the midpoint" if n_excl == 2 else "")) + ") rendered with nothing else in flight -- their launches give achieved / frac -- and "
                    f"{n_instrumented - n_excl} overlapped like the uninstrumented ones (the `overlapped` entry)" if ploop is not None else ""))
             # field FLOPs of the whole timed region over its wall time: a lower bound of the kernel's rate that no overlap can inflate
-            result["roofline"]["whole_job_mfma_frac"] = FIELD_FLOP_PER_POINT * n_samples / elapsed / 1e12 / MFMA_F16_PEAK_TFLOPS
+            result["roofline"]["whole_job_mfma_frac"] = FIELD_FLOP_PER_POINT * n_samples / elapsed / 1e12 / (MFMA_F16_PEAK_TFLOPS if fp16 else MFMA_F32_PEAK_TFLOPS)
         if world == 1 and dloop is not None and not args.no_secondary and args.emulate_rank_of <= 1:
             result["roofline_secondary"] = marcher_roofline(dloop, grp_o, grp_d, grp_t, n_groups, distinct, frame_cam, F)
             result["grid_gather_rate"] = grid_gather_rate(sc, dev)
@@ -970,11 +976,12 @@ def roofline(timers, fp16, points_exclusive, points_overlapped=0):
                 "avg_launch_ms": s["avg_ms"], "avg_points_per_launch": s["avg_units"]}
     else:
         achieved = FIELD_FLOP_PER_POINT * s["avg_units"] / (s["avg_ms"] * 1e-3) / 1e12
-        roof = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": None, "flop_per_point": FIELD_FLOP_PER_POINT,
+        peak = MFMA_F16_PEAK_TFLOPS if fp16 else MFMA_F32_PEAK_TFLOPS
+        roof = {"kernel": name if fp16 else "field_forward_f32", "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak, "traffic": None, "flop_per_point": FIELD_FLOP_PER_POINT,
                 "avg_launch_ms": s["avg_ms"], "avg_points_per_launch": s["avg_units"]}
         pmc = os.path.join(ROOT, "profiles", PMC_SUMMARY)
-        if os.path.exists(pmc):  # HBM bytes per point from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE), NOT measured in this run
+        if fp16 and os.path.exists(pmc):  # HBM bytes per point from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE), NOT measured in this run
             f = json.load(open(pmc))["field_forward_f16"]
             roof["traffic"] = f["hbm_bytes_per_point"] * s["avg_units"]
             roof["traffic_static"] = True
@@ -990,7 +997,7 @@ def roofline(timers, fp16, points_exclusive, points_overlapped=0):
             units = points_overlapped / over["launches"]
             ach = FIELD_FLOP_PER_POINT * units / (over["avg_ms"] * 1e-3) / 1e12
             roof["overlapped"] = {"avg_launch_ms": over["avg_ms"], "launches": over["launches"], "achieved": ach,
-                                  "frac": ach / MFMA_F16_PEAK_TFLOPS,
+                                  "frac": ach / peak,
                                   "note": "loops in flight share the CUs: this is the figure rocprofv3 --stats of the default command averages towards"}
             summ["field_forward_f16_overlapped"] = over
     return roof, summ

@@ -41,6 +41,7 @@ constexpr int kTail = kD1 + 6 * kStageFloats;
 constexpr int kT_D7 = 0, kT_S0 = kT_D7 + 64 * 64, kT_S1 = kT_S0 + 16 * 64 * 2, kT_C0 = kT_S1 + 32 * 64, kT_C1 = kT_C0 + 16 * 64 * 2,
               kT_C2 = kT_C1 + 32 * 64 * 2, kTailFloats = kT_C2 + 32 * 64;
 static_assert(kTailFloats == kStageFloats, "the tail stage is one LDS buffer");
+static_assert(kTail == kD1 + 6 * kStageFloats, "the tail stage follows D6: the hidden-layer loop prefetches it as 'D7'");
 constexpr int kTotalFloats = kTail + kTailFloats;
 
 struct F32Args {
@@ -92,13 +93,27 @@ __global__ void __launch_bounds__(64 * kWaves, 1) k_field_f32(F32Args P, LevelPa
         x[0] = P.xyzs[(size_t)slot * 3]; x[1] = P.xyzs[(size_t)slot * 3 + 1]; x[2] = P.xyzs[(size_t)slot * 3 + 2];
         d[0] = P.dirs[(size_t)slot * 3]; d[1] = P.dirs[(size_t)slot * 3 + 1]; d[2] = P.dirs[(size_t)slot * 3 + 2];
     }
-    auto stage = [&](const float *src, int floats) {       // all 512 threads: global -> LDS, 16 bytes at a time
+    // Weight stages: the NEXT stage's 16-byte pieces are fetched into registers before a layer's MFMAs start (8 per thread for 64 KiB) and
+    // written to LDS when every wave is through with the current stage -- the global latency runs under the layer instead of in front of it
+    float4 pre[8];
+    auto prefetch = [&](const float *src, int floats) {
+        #pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int k = (q * 64 * kWaves + (int)threadIdx.x) * 4;
+            if (k < floats) pre[q] = *reinterpret_cast<const float4 *>(src + k);
+        }
+    };
+    auto commit = [&](int floats) {
         __syncthreads();                                   // every wave has finished reading the previous stage
-        for (int k = threadIdx.x * 4; k < floats; k += 64 * kWaves * 4)
-            *reinterpret_cast<float4 *>(s_w + k) = *reinterpret_cast<const float4 *>(src + k);
-        if (src == P.weights && threadIdx.x < 128) s_bias[threadIdx.x] = P.bias0[threadIdx.x];
+        #pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int k = (q * 64 * kWaves + (int)threadIdx.x) * 4;
+            if (k < floats) *reinterpret_cast<float4 *>(s_w + k) = pre[q];
+        }
         __syncthreads();
     };
+    prefetch(P.weights + kD0, kD0Floats);
+    if (threadIdx.x < 128) s_bias[threadIdx.x] = P.bias0[threadIdx.x];
 
     // ---- deformation network: freq(x, 10) (time part folded into bias0) -> 128 x 7 -> 3 ----
     float bin[64];
@@ -110,7 +125,8 @@ __global__ void __launch_bounds__(64 * kWaves, 1) k_field_f32(F32Args P, LevelPa
         bin[31] = h ? 0.0f : x[2];
     }
     float16_t acc[4];
-    stage(P.weights + kD0, kD0Floats);
+    commit(kD0Floats);
+    prefetch(P.weights + kD1, kStageFloats);
     #pragma unroll
     for (int mt = 0; mt < 4; mt++)
         #pragma unroll
@@ -124,7 +140,8 @@ __global__ void __launch_bounds__(64 * kWaves, 1) k_field_f32(F32Args P, LevelPa
     #pragma unroll 1
     for (int l = 0; l < 6; l++) {
         relu_into<4>(acc, bin);
-        stage(P.weights + kD1 + (size_t)l * kStageFloats, kStageFloats);
+        commit(kStageFloats);                                                          // D(l+1), fetched under the previous layer
+        prefetch(P.weights + kD1 + (size_t)(l + 1) * kStageFloats, kStageFloats);      // D(l+2); after D6 the tail stage (kTail follows D6)
         #pragma unroll
         for (int mt = 0; mt < 4; mt++)
             #pragma unroll
@@ -132,7 +149,7 @@ __global__ void __launch_bounds__(64 * kWaves, 1) k_field_f32(F32Args P, LevelPa
         layer<64, 4>(s_w, bin, acc, lane);
     }
     relu_into<4>(acc, bin);
-    stage(P.weights + kTail, kTailFloats);
+    commit(kTailFloats);
     float16_t a1[1];
     #pragma unroll
     for (int v = 0; v < 16; v++) a1[0][v] = 0.0f;

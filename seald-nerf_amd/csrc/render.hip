@@ -84,11 +84,24 @@ static int seal_color(const SdnRenderCtx *c, uint32_t m_slots, hipStream_t st) {
     return rc;
 }
 
+// the fused field network on this iteration's samples (live list, count on the device): the `-O` kernel, or the fp32 one (ctx->field_f32)
+static int launch_field(const SdnRenderCtx *c, uint32_t m_bound, uint32_t expect_points, hipStream_t st) {
+    if (c->field_f32)
+        return sdn_int::field_forward_f32(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, m_bound,
+                                          (const float *)c->field_weights, c->field_bias0, (const float *)c->grid_table, c->grid_offsets, c->grid_S,
+                                          c->grid_H, c->bound, c->density_scale, c->zero_deform, c->sigmas, c->rgbs, st);
+    return sdn_int::field_forward_f16(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, m_bound, c->field_weights,
+                                      c->field_bias0, c->grid_table, c->grid_offsets, c->grid_S, c->grid_H, c->bound, c->density_scale,
+                                      c->zero_deform, c->sigmas, c->rgbs, expect_points, c->n_group_frames > 1 ? c->slot_frame : nullptr,
+                                      c->n_group_frames > 1 ? c->n_group_frames : 1u, st);
+}
+
 static bool ctx_ok(const SdnRenderCtx *c) {
     if (!(c && c->rays_o && c->rays_d && c->nears && c->fars && c->alive_a && c->alive_b && c->rays_t && c->weights_sum &&
           c->depth && c->image && c->state && c->live_counts && c->cull_bits))
         return false;
     if (c->n_group_frames > 1) {   // frame group: one occupancy slice per frame, rays split evenly, the per-slot frame scratch
+        if (c->field_f32) return false;                       // (the fp32 field kernel evaluates one frame's constants per launch)
         if (c->n_group_frames > SDN_MAX_GROUP_FRAMES || !c->slot_frame || c->rays_per_frame == 0 ||
             (uint64_t)c->n_group_frames * c->rays_per_frame != c->N)
             return false;
@@ -127,10 +140,7 @@ int sdn_render_step_f16_ev(const SdnRenderCtx *c, uint32_t bound_alive, void *ev
     rc = seal_map(c, (uint32_t)m_bound, st);
     if (rc) return rc;
     if (ev_field_begin) (void)hipEventRecord((hipEvent_t)ev_field_begin, st);
-    rc = sdn_int::field_forward_f16(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, (uint32_t)m_bound,
-                                    c->field_weights, c->field_bias0, c->grid_table, c->grid_offsets, c->grid_S, c->grid_H, c->bound,
-                                    c->density_scale, c->zero_deform, c->sigmas, c->rgbs, 0u, c->n_group_frames > 1 ? c->slot_frame : nullptr,
-                                    c->n_group_frames > 1 ? c->n_group_frames : 1u, st);
+    rc = launch_field(c, (uint32_t)m_bound, 0u, st);
     if (ev_field_end) (void)hipEventRecord((hipEvent_t)ev_field_end, st);
     if (rc) return rc;
     rc = seal_color(c, (uint32_t)m_bound, st);
@@ -228,10 +238,7 @@ struct FrameRun {
             void *m0 = time_march ? e0 : nullptr, *m1 = time_march ? e1 : nullptr;
             if (time_march) e0 = e1 = nullptr;
             if (e0) (void)hipEventRecord((hipEvent_t)e0, st);
-            rc = sdn_int::field_forward_f16(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, (uint32_t)m_bound,
-                                            c->field_weights, c->field_bias0, c->grid_table, c->grid_offsets, c->grid_S, c->grid_H, c->bound,
-                                            c->density_scale, c->zero_deform, c->sigmas, c->rgbs, last_alive * 8u,
-                                            c->n_group_frames > 1 ? c->slot_frame : nullptr, c->n_group_frames > 1 ? c->n_group_frames : 1u, st);
+            rc = launch_field(c, (uint32_t)m_bound, last_alive * 8u, st);
             if (e1) (void)hipEventRecord((hipEvent_t)e1, st);
             if (!rc) rc = seal_color(c, (uint32_t)m_bound, st);
             if (!rc && m0) (void)hipEventRecord((hipEvent_t)m0, st);

@@ -126,6 +126,14 @@ class FusedFieldF32:
     def set_time(self, time):
         self.bias0, self.zero_deform, self.t_idx = self.time_constants(time)
 
+    def group_constants(self, times):
+        """(bias0 [1,128], zero_deform bit, [slice index]) in the shape `renderer.DeviceLoop.frame_time` asks for; the fp32 kernel
+        evaluates ONE frame's constants per launch, so a group has one frame."""
+        if len(times) != 1:
+            raise NotImplementedError("the fp32 fused field renders one frame per loop (frame groups are a feature of the -O path)")
+        bias0, zero, t_idx = self.time_constants(times[0])
+        return bias0.reshape(1, 128), zero, [t_idx]
+
     def refresh(self):
         """Re-pack after the weights changed (the table is read in place)."""
         self.weights.copy_(torch.from_numpy(pack_weights_f32(self.model)))

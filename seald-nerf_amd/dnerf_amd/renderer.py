@@ -518,6 +518,11 @@ class DeviceLoop:
         c.N, c.M_cap, c.n_counters, c.max_steps, c.C, c.H = N, M, n_counters, int(max_steps), int(model.cascade), int(model.grid_size)
         c.bound, c.dt_gamma, c.T_thresh, c.density_scale = float(model.bound), float(dt_gamma), float(T_thresh), float(model.density_scale)
         c.n_group_frames, c.rays_per_frame = (self.frames, N // self.frames) if self.frames > 1 else (0, 0)
+        # the fp32 fused field (dnerf_amd.fused_f32.FusedFieldF32: the reference without -O) in the same loop: its packed floats, the
+        # model's fp32 table in place, the reference's offsets
+        c.field_f32 = 1 if type(field).__name__ == "FusedFieldF32" else 0
+        if c.field_f32 and self.frames > 1:
+            raise NotImplementedError("the fp32 fused field renders one frame per loop")
         self.ctx = c
         self.max_steps = int(max_steps)
         self.set_mapper(mapper)

@@ -84,7 +84,7 @@ class SdnRenderCtx(ctypes.Structure):
                 + [(n, _f32) for n in ("bound", "dt_gamma", "T_thresh", "density_scale")]
                 + [("zero_deform", ctypes.c_int32), ("aabb", _vp), ("min_near", _f32), ("reserved_", ctypes.c_int32), ("rays_tend", _vp), ("seal", _vp), ("seal_mask", _vp),
                    ("n_group_frames", _u32), ("rays_per_frame", _u32), ("frame_bitfield", _vp * MAX_GROUP_FRAMES), ("slot_frame", _vp),
-                   ("frame_cull", _vp * MAX_GROUP_FRAMES)])
+                   ("frame_cull", _vp * MAX_GROUP_FRAMES), ("field_f32", _i32), ("reserved2_", _i32)])
 
 
 class SdnSealBox(ctypes.Structure):

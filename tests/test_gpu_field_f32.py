@@ -85,3 +85,34 @@ def test_render_frame_fp32_through_the_fused_field_vs_oracle(small_scene):
     np.testing.assert_allclose(out["image"].cpu().numpy(), ref["image"], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(np.nan_to_num(out["depth"].cpu().numpy()), np.nan_to_num(ref["depth"]), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(out["weights_sum"].cpu().numpy(), ref["weights_sum"], rtol=1e-4, atol=1e-4)
+
+
+def test_native_loops_with_the_fp32_field_equal_the_host_stepped_loop(small_scene):
+    """`SdnRenderCtx.field_f32`: the device-driven loop and a stream of frames through the pipelined driver call the fp32 kernel where the
+    `-O` loops call the fp16 one -- image, depth, weights, trace and sample count bit for bit those of the host-stepped loop with the
+    same field (same samples into the same kernel; a point's result does not depend on its tile)."""
+    from dnerf_amd.fused_f32 import FusedFieldF32
+    from dnerf_amd.renderer import render_frame, DeviceLoop, PipelinedDeviceLoop
+    sc = small_scene
+    N, dev = sc.rays_o.shape[0], sc.rays_o.device
+    f = FusedFieldF32(sc.model, sc.time)
+    for t in (0.5, 0.0):
+        tt = torch.tensor([[t]], dtype=torch.float32, device=dev)
+        host = render_frame(sc.model, sc.rays_o, sc.rays_d, tt, fp16=False, field=FusedFieldF32(sc.model, tt))
+        a = DeviceLoop(sc.model, f, N, dev).render(sc.rays_o, sc.rays_d, t)
+        torch.cuda.synchronize()
+        assert torch.equal(a["image"], host["image"]) and torch.equal(a["weights_sum"], host["weights_sum"])
+        assert torch.equal(torch.nan_to_num(a["depth"]), torch.nan_to_num(host["depth"]))
+        assert [tuple(x) for x in a["trace"]] == [tuple(x) for x in host["trace"]] and a["n_samples"] == host["n_samples"] > 1000
+    pl = PipelinedDeviceLoop(sc.model, f, N, dev, contexts=2)
+    times = [0.5, 0.0, 0.25]
+    outs = [(torch.empty(N, 3, device=dev), torch.empty(N, device=dev)) for _ in times]
+    pl.render_frames([sc.rays_o] * 3, [sc.rays_d] * 3, times, outputs=outs)
+    torch.cuda.synchronize()
+    one = DeviceLoop(sc.model, f, N, dev)
+    for k, t in enumerate(times):
+        b = one.render(sc.rays_o, sc.rays_d, t)
+        torch.cuda.synchronize()
+        assert torch.equal(b["image"], outs[k][0]), k
+    with pytest.raises(NotImplementedError):
+        DeviceLoop(sc.model, f, 2 * N, dev, frames=2)
