@@ -31,7 +31,11 @@ namespace {
 using sdn_grid::LevelParams;
 typedef float float16_t __attribute__((ext_vector_type(16)));
 
-constexpr int kWaves = 8;
+#ifndef SDN_F32_WAVES
+#define SDN_F32_WAVES 8
+#endif
+constexpr int kWaves = SDN_F32_WAVES;          // waves per workgroup (8: one workgroup per CU; 4: two, out of step with each other)
+constexpr int kPieces = 16384 / (64 * kWaves * 4);   // 16-byte pieces per thread of a 64-KiB stage
 constexpr int kPointsPerWG = 32 * kWaves;
 constexpr int kStageFloats = 16384;   // 64 KiB: one 128 x 128 layer
 
@@ -79,7 +83,7 @@ __device__ __forceinline__ void relu_into(const float16_t (&acc)[MT], float (&b)
         for (int v = 0; v < 16; v++) b[mt * 16 + v] = fmaxf(acc[mt][v], 0.0f);
 }
 
-__global__ void __launch_bounds__(64 * kWaves, 1) k_field_f32(F32Args P, LevelParams lp) {
+__global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) k_field_f32(F32Args P, LevelParams lp) {
     __shared__ __attribute__((aligned(16))) float s_w[kStageFloats];
     __shared__ float s_bias[128];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -96,7 +100,7 @@ __global__ void __launch_bounds__(64 * kWaves, 1) k_field_f32(F32Args P, LevelPa
     }
     // Weight stages: the NEXT stage's 16-byte pieces are fetched into registers before a layer's MFMAs start (8 per thread for 64 KiB) and
     // written to LDS when every wave is through with the current stage -- the global latency runs under the layer instead of in front of it
-    struct Pre { float4 v[8]; };
+    struct Pre { float4 v[kPieces]; };
     // (stage sizes are multiples of one piece per thread, 2 048 floats: the guard is a compile-time one -- a lane-dependent guard made
     //  every piece a predicated merge that waited for its load on the spot)
     auto prefetch = [&](const float *src, auto floats_c) -> Pre {
@@ -104,7 +108,7 @@ __global__ void __launch_bounds__(64 * kWaves, 1) k_field_f32(F32Args P, LevelPa
         static_assert(floats % (64 * kWaves * 4) == 0, "whole pieces");
         Pre r;
         #pragma unroll
-        for (int q = 0; q < 8; q++)
+        for (int q = 0; q < kPieces; q++)
             r.v[q] = (q * 64 * kWaves * 4 < floats) ? *reinterpret_cast<const float4 *>(src + (q * 64 * kWaves + (int)threadIdx.x) * 4)
                                                     : make_float4(0, 0, 0, 0);
         // (left alone the scheduler sinks these loads to the end of the layer, where nothing hides them)
@@ -123,7 +127,7 @@ __global__ void __launch_bounds__(64 * kWaves, 1) k_field_f32(F32Args P, LevelPa
         constexpr int floats = decltype(floats_c)::value;
         wg_barrier();                                      // every wave has finished reading the previous stage
         #pragma unroll
-        for (int q = 0; q < 8; q++)
+        for (int q = 0; q < kPieces; q++)
             if (q * 64 * kWaves * 4 < floats) *reinterpret_cast<float4 *>(s_w + (q * 64 * kWaves + (int)threadIdx.x) * 4) = r.v[q];
         wg_barrier();
     };
