@@ -225,12 +225,13 @@ int sdn_field_forward_f16(const float *xyzs, const float *dirs, const uint32_t *
 /* The same network in fp32 (the reference without `-O`; csrc/field_f32.hip: v_mfma_f32_32x32x2_f32, fp32 encoders): weights =
  * sdn_field_weight_floats_f32() floats in the order of dnerf_amd/fused_f32.py:pack_weights_f32, bias0 [128] = W0[:,63:76] . freq(t, 6)
  * in fp32, table = the model's fp32 embeddings [offsets_host[16], 2] in the reference's layout (read in place), offsets_host [17] the
- * reference's level offsets.  Everything else as sdn_field_forward_f16. */
+ * reference's level offsets.  deform: NULL, or [M,3] receiving the deformation network's output (zeros when zero_deform: network.py:139-141).
+ * Everything else as sdn_field_forward_f16. */
 uint32_t sdn_field_weight_floats_f32(void);
 int sdn_field_forward_f32(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count,
                           uint32_t M, const float *weights, const float *bias0, const float *table,
                           const int32_t *offsets_host, float S, uint32_t H, float bound, float density_scale,
-                          int zero_deform, float *sigmas, float *rgbs, void *stream);
+                          int zero_deform, float *sigmas, float *rgbs, float *deform, void *stream);
 
 /* Which kernel large launches of the fused field network take: 1 = the persistent two-set ("ping-pong") kernel, the default for launches
  * of at least 4 tiles of 256 points per CU on a QUAD table; 0 = one tile per workgroup for every launch; -1 = environment SDN_FIELD_PP or

@@ -4,9 +4,10 @@
 // encoders are the fp32 operators' own expressions (freqencoder.cu:30-58 with its phase-shifted sine, gridencoder.cu:87-245,
 // shencoder.cu:49-121 through sh_eval.h).
 //
-// Mapping.  A workgroup is 8 waves, a wave owns 32 points (N of the MFMA) from its encodings to its outputs and never talks to another
+// Mapping.  A workgroup is 4 waves (two workgroups per CU, out of step with each other: one encodes while the other multiplies; 8 waves
+// in one workgroup measured 3 % slower), a wave owns 32 points (N of the MFMA) from its encodings to its outputs and never talks to another
 // wave; the workgroup shares the WEIGHTS: each layer's A operands are staged once in LDS (64 KiB for a 128 x 128 layer) and read by
-// all eight waves.  v_mfma_f32_32x32x2_f32 takes A[m = lane % 32][k = lane / 32] and B[k = lane / 32][n = lane % 32] -- one register
+// all its waves.  v_mfma_f32_32x32x2_f32 takes A[m = lane % 32][k = lane / 32] and B[k = lane / 32][n = lane % 32] -- one register
 // each -- and leaves C[row = 8 (v / 4) + 4 (lane / 32) + v % 4][n = lane % 32] in accumulator register v.  So accumulator register v
 // of output tile mt IS the B operand of the next layer for the k-pair (row, row + 4), row = 32 mt + 8 (v / 4) + v % 4: activations never
 // leave the register file and are never permuted; the k-order that makes this true is baked into the weight packing
@@ -32,7 +33,7 @@ using sdn_grid::LevelParams;
 typedef float float16_t __attribute__((ext_vector_type(16)));
 
 #ifndef SDN_F32_WAVES
-#define SDN_F32_WAVES 8
+#define SDN_F32_WAVES 4
 #endif
 constexpr int kWaves = SDN_F32_WAVES;          // waves per workgroup (8: one workgroup per CU; 4: two, out of step with each other)
 constexpr int kPieces = 16384 / (64 * kWaves * 4);   // 16-byte pieces per thread of a 64-KiB stage
@@ -55,7 +56,7 @@ struct F32Args {
     const int32_t *state;
     uint32_t M;
     const float *weights, *bias0, *table;
-    float *sigmas, *rgbs;
+    float *sigmas, *rgbs, *deform;      // deform: optional [M,3], the deformation network's output (zeros on the canonical frame)
     float bound, density_scale;
     int zero_deform;
 };
@@ -176,6 +177,10 @@ __global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) k_field_f32(F32Args P
     for (int v = 0; v < 16; v++) a1[0][v] = 0.0f;
     layer<64, 1>(s_w + kT_D7, bin, a1, lane);
     // rows 0..2 of the output live in registers 0..2 of the lower lane half; the upper half evaluates the same point
+    if (P.deform && valid && h == 0) {      // dnerf/network.py:139-141: `deform = zeros` on the canonical frame
+        #pragma unroll
+        for (int k = 0; k < 3; k++) P.deform[(size_t)slot * 3 + k] = P.zero_deform ? 0.0f : a1[0][k];
+    }
     if (!P.zero_deform) {
         #pragma unroll
         for (int k = 0; k < 3; k++) x[k] = x[k] + __shfl(a1[0][k], (int)n, 64);
@@ -275,13 +280,13 @@ __global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) k_field_f32(F32Args P
 namespace sdn_int {
 int field_forward_f32(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count, const int32_t *state,
                       uint32_t M, const float *weights, const float *bias0, const float *table, const int32_t *offsets_host, float S,
-                      uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, hipStream_t st) {
+                      uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, float *deform, hipStream_t st) {
     LevelParams lp;
     int rc = sdn_grid::fill_levels(lp, offsets_host, 16u, S, H);
     if (rc) return rc;
     F32Args a;
     a.xyzs = xyzs; a.dirs = dirs; a.live_idx = live_idx; a.live_count = live_count; a.state = state; a.M = M;
-    a.weights = weights; a.bias0 = bias0; a.table = table; a.sigmas = sigmas; a.rgbs = rgbs;
+    a.weights = weights; a.bias0 = bias0; a.table = table; a.sigmas = sigmas; a.rgbs = rgbs; a.deform = deform;
     a.bound = bound; a.density_scale = density_scale; a.zero_deform = zero_deform;
     hipLaunchKernelGGL(k_field_f32, dim3(sdn_div_up(M, (uint32_t)kPointsPerWG)), dim3(64 * kWaves), 0, st, a, lp);
     return sdn_launch_status();
@@ -294,13 +299,13 @@ uint32_t sdn_field_weight_floats_f32(void) { return (uint32_t)kTotalFloats; }
 
 int sdn_field_forward_f32(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count, uint32_t M,
                           const float *weights, const float *bias0, const float *table, const int32_t *offsets_host, float S, uint32_t H,
-                          float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, void *stream) {
+                          float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, float *deform, void *stream) {
     if (M == 0) return 0;
     if (!xyzs || !dirs || !weights || !bias0 || !table || !offsets_host || !sigmas || !rgbs) return SDN_E_BADARG;
     if ((live_idx == nullptr) != (live_count == nullptr)) return SDN_E_BADARG;
     if (((uintptr_t)weights & 15u) != 0 || ((uintptr_t)table & 3u) != 0) return SDN_E_BADARG;
     return sdn_int::field_forward_f32(xyzs, dirs, live_idx, live_count, nullptr, M, weights, bias0, table, offsets_host, S, H, bound,
-                                      density_scale, zero_deform ? 1 : 0, sigmas, rgbs, (hipStream_t)stream);
+                                      density_scale, zero_deform ? 1 : 0, sigmas, rgbs, deform, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -89,7 +89,7 @@ static int launch_field(const SdnRenderCtx *c, uint32_t m_bound, uint32_t expect
     if (c->field_f32)
         return sdn_int::field_forward_f32(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, m_bound,
                                           (const float *)c->field_weights, c->field_bias0, (const float *)c->grid_table, c->grid_offsets, c->grid_S,
-                                          c->grid_H, c->bound, c->density_scale, c->zero_deform, c->sigmas, c->rgbs, st);
+                                          c->grid_H, c->bound, c->density_scale, c->zero_deform, c->sigmas, c->rgbs, nullptr, st);
     return sdn_int::field_forward_f16(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, m_bound, c->field_weights,
                                       c->field_bias0, c->grid_table, c->grid_offsets, c->grid_S, c->grid_H, c->bound, c->density_scale,
                                       c->zero_deform, c->sigmas, c->rgbs, expect_points, c->n_group_frames > 1 ? c->slot_frame : nullptr,

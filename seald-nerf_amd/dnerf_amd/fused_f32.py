@@ -144,7 +144,8 @@ class FusedFieldF32:
         dev = self.weights.device
         self._buf = (torch.empty(M, dtype=torch.float32, device=dev), torch.empty(M, 3, dtype=torch.float32, device=dev))
 
-    def __call__(self, xyzs, dirs, live_idx=None, live_count=None):
+    def __call__(self, xyzs, dirs, live_idx=None, live_count=None, deform=None):
+        """deform: optional [M,3] f32 tensor that receives the deformation network's output (the third value of NeRFNetwork.forward)."""
         M = xyzs.shape[0]
         if self._buf is None or self._buf[0].shape[0] < M:
             self._alloc(M)
@@ -154,5 +155,5 @@ class FusedFieldF32:
                                                         ptr(live_idx), ptr(live_count), M, ptr(self.weights), ptr(self.bias0),
                                                         ptr(self.table, torch.float32, "embeddings"), self.offsets_host.ctypes.data,
                                                         self.S, self.H, self.bound, self.density_scale, self.zero_deform, ptr(sigmas),
-                                                        ptr(rgbs), stream()), "field_forward_f32")
+                                                        ptr(rgbs), ptr(deform, torch.float32, "deform"), stream()), "field_forward_f32")
         return sigmas, rgbs

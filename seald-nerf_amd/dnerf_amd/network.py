@@ -12,7 +12,8 @@ Two evaluation paths:
     the default geometry the whole network is ONE launch of the fused MFMA kernel (csrc/field.hip, `sdn_field_forward_f16`), so the
     reference-shaped loop of `run_cuda` (dnerf/renderer.py:350-376; SealDNeRF/renderer.py:250-276 with the mapper hooks) costs
     march + one field launch + composite per iteration.  Same numbers as the native loops' field (`FusedField`), fp16 distance
-    from the op-by-op path; `model.fused_inference = False` switches it off.
+    from the op-by-op path; `model.fused_inference = False` switches it off.  Without autocast (no `-O`) the same dispatch goes to
+    the fp32 fused kernel (csrc/field_f32.hip, 1e-4 from the op-by-op fp32 network) when `model.fused_inference_f32 = True`.
 """
 import torch
 import torch.nn as nn
@@ -111,14 +112,21 @@ class NeRFNetwork(NeRFRenderer):
 
     # -- fused inference dispatch -----------------------------------------------------------------
     fused_inference = True       # class default; set False on a model to keep `forward` on the op-by-op path in every mode
+    fused_inference_f32 = False  # opt-in: without autocast (the reference without -O) dispatch to the fp32 fused kernel as well
 
     def _fused_inference_ok(self, x, d):
         # (cheapest tests first: this runs on every forward call, and the reference-shaped render loop is bound by host time)
         if not self.fused_inference or self.training or torch.is_grad_enabled() or not x.is_cuda or x.dim() != 2 or x.shape[0] == 0:
             return False
-        if not torch.is_autocast_enabled("cuda") or torch.get_autocast_dtype("cuda") != torch.float16:
-            return False       # fp32 evaluation has no fused kernel: the op-by-op path meets the 1e-4 bar
         if x.dtype != torch.float32 or d.dtype != torch.float32:
+            return False
+        if not torch.is_autocast_enabled("cuda"):
+            if not self.fused_inference_f32:
+                return False   # the default without -O stays the op-by-op network: hipBLASLt fp32 GEMMs, what the fp32 fixtures pin
+            mode = 32          # opt-in: the fp32 fused kernel (csrc/field_f32.hip), 1e-4 from the op-by-op network, 3 x faster
+        elif torch.get_autocast_dtype("cuda") == torch.float16:
+            mode = 16          # -O: the fp16 fused kernel with autocast's roundings
+        else:
             return False
         ok = self.__dict__.get("_fused_arch_ok")
         if ok is None:         # the architecture does not change after construction
@@ -129,7 +137,17 @@ class NeRFNetwork(NeRFRenderer):
                       and enc.gridtype == "tiled" and not enc.align_corners and enc.interpolation == "linear" and enc.num_levels == 16
                       and enc.level_dim == 2)
             self.__dict__["_fused_arch_ok"] = ok
-        return ok
+        if not ok:
+            return False
+        if mode == 32:
+            ok32 = self.__dict__.get("_fused_f32_ok")
+            if ok32 is None:
+                from . import fused_f32
+                ok32 = bool(fused_f32.available())
+                self.__dict__["_fused_f32_ok"] = ok32
+            if not ok32 or self.encoder.embeddings.dtype != torch.float32 or self.deform_net[0].weight.dtype != torch.float32:
+                return False
+        return mode
 
     def _parameter_epoch(self):
         ps = self.__dict__.get("_fused_params")
@@ -138,6 +156,35 @@ class NeRFNetwork(NeRFRenderer):
                        + [l.weight for l in self.color_net])
             self.__dict__["_fused_params"] = ps
         return tuple([(p.data_ptr(), p._version) for p in ps])
+
+    def _forward_fused32(self, x, d, t):
+        """The fp32 network in one launch: sigma [M], rgb [M,3], deform [M,3] (zeros on the canonical frame), all float32, within 1e-4 of
+        the op-by-op evaluation (tests/test_gpu_field_f32.py)."""
+        epoch = self._parameter_epoch()
+        cache = self.__dict__.get("_fused_cache32")
+        if cache is None or cache[0] != epoch[1:] or cache[2][0] != epoch[0][0]:
+            from . import fused_f32
+            # (weights packed once per parameter version; the embedding table is read where it is, so its in-place updates need nothing)
+            field = fused_f32.FusedFieldF32(self, t)
+            field.density_scale = 1.0
+            cache = (epoch[1:], field, epoch[0])
+            self.__dict__["_fused_cache32"] = cache
+        field = cache[1]
+        seen = self.__dict__.get("_fused_time")
+        if not isinstance(t, torch.Tensor) or seen is None or seen[0]() is not t or seen[1] != t._version:
+            value = field.time_value(t)
+            if isinstance(t, torch.Tensor):
+                import weakref
+                self.__dict__["_fused_time"] = (weakref.ref(t), t._version, value)
+        else:
+            value = seen[2]
+        if field.__dict__.get("_time_set") != value:
+            field.set_time(value)
+            field._time_set = value
+        field._buf = None
+        deform = torch.empty(x.shape[0], 3, dtype=torch.float32, device=x.device)
+        sig, rgb = field(x.contiguous(), d.contiguous(), deform=deform)
+        return sig, rgb, deform
 
     def _forward_fused(self, x, d, t):
         """sigma [M] f32 (trunc_exp, density_scale NOT applied: the caller multiplies, dnerf/renderer.py:368), rgb [M,3] (the fp16 values
@@ -179,8 +226,9 @@ class NeRFNetwork(NeRFRenderer):
 
     def forward(self, x, d, t):
         """x [M,3] in [-bound,bound], d [M,3] unit, t [1,1] -> sigma [M], rgb [M,3], deform [M,3]  (network.py:123-169)."""
-        if self._fused_inference_ok(x, d):
-            return self._forward_fused(x, d, t)
+        mode = self._fused_inference_ok(x, d)
+        if mode:
+            return self._forward_fused(x, d, t) if mode == 16 else self._forward_fused32(x, d, t)
         deform = self._deform(x, t)
         if t == 0:  # canonical frame: no deformation (device compare => host sync, as in the reference :140)
             deform = torch.zeros_like(x)

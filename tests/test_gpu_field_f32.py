@@ -116,3 +116,35 @@ def test_native_loops_with_the_fp32_field_equal_the_host_stepped_loop(small_scen
         assert torch.equal(b["image"], outs[k][0]), k
     with pytest.raises(NotImplementedError):
         DeviceLoop(sc.model, f, 2 * N, dev, frames=2)
+
+
+def test_forward_dispatches_to_the_fp32_kernel_when_asked(small_scene):
+    """`model.fused_inference_f32 = True`: eval + no_grad WITHOUT autocast sends NeRFNetwork.forward to the fp32 fused kernel -- sigma,
+    rgb AND the deformation (zeros on the canonical frame, dnerf/network.py:139-141) within 1e-4 of the op-by-op network; the
+    reference-shaped render (`model.render` -> run_cuda) then agrees with the op-by-op render within the fp32 bar.  Off by default."""
+    import copy
+    from dnerf_amd.bench_scene import _probe_points
+    sc = small_scene
+    model = copy.deepcopy(sc.model).eval()
+    n = 5000
+    x = torch.from_numpy(_probe_points(sc.bitfield, n, 4)).cuda()
+    d = torch.nn.functional.normalize(torch.randn(n, 3, device="cuda"), dim=1).contiguous()
+    for t in (0.5, 0.0):
+        tt = torch.tensor([[t]], dtype=torch.float32, device="cuda")
+        with torch.no_grad():
+            assert not model._fused_inference_ok(x, d)
+            s0, c0, d0 = model(x, d, tt)
+            model.fused_inference_f32 = True
+            assert model._fused_inference_ok(x, d) == 32
+            s1, c1, d1 = model(x, d, tt)
+            model.fused_inference_f32 = False
+        np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(c1.cpu().numpy(), c0.cpu().numpy(), rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(d1.cpu().numpy(), d0.float().cpu().numpy(), rtol=2e-4, atol=2e-6)
+        if t == 0.0:
+            assert float(d1.abs().max()) == 0.0
+    with torch.no_grad():
+        a = model.render(sc.rays_o[None], sc.rays_d[None], sc.time, staged=True, perturb=False, bg_color=1, max_steps=1024)
+        model.fused_inference_f32 = True
+        b = model.render(sc.rays_o[None], sc.rays_d[None], sc.time, staged=True, perturb=False, bg_color=1, max_steps=1024)
+    np.testing.assert_allclose(b["image"].cpu().numpy(), a["image"].cpu().numpy(), rtol=1e-4, atol=1e-4)

@@ -19,6 +19,7 @@ python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2>$
 python3 bench.py > $OUT/bench_default.json 2>/dev/null || exit 1; echo "bench default done"
 python3 bench.py --steps 20 --pipeline 0 --group-frames 1 --no-cpu-baseline > $OUT/bench_sequential.json 2>/dev/null || exit 1
 python3 bench.py --steps 20 --warmup 5 --pipeline 0 --no-cpu-baseline --no-secondary > $OUT/bench_one_loop_at_a_time.json 2>/dev/null || exit 1
+python3 bench.py --fp32 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_fp32.json 2>/dev/null || exit 1
 echo "bench lines done"
 fi
 if want stats; then
