@@ -148,3 +148,26 @@ def test_forward_dispatches_to_the_fp32_kernel_when_asked(small_scene):
         model.fused_inference_f32 = True
         b = model.render(sc.rays_o[None], sc.rays_d[None], sc.time, staged=True, perturb=False, bg_color=1, max_steps=1024)
     np.testing.assert_allclose(b["image"].cpu().numpy(), a["image"].cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_fp32_fused_field_in_a_larger_box():
+    """bound = 2 (cascade 2): the grid's input normalisation (x + bound) / (2 bound) and its out-of-range rule with another box."""
+    from dnerf_amd.bench_scene import build_scene
+    from dnerf_amd.fused_f32 import FusedFieldF32
+    sc = build_scene(H=32, W=32, device="cuda", seed=0, bound=2)
+    rng = np.random.default_rng(2)
+    n = 4096 + 5
+    x = torch.from_numpy(rng.uniform(-2.3, 2.3, (n, 3)).astype(np.float32)).cuda()
+    d = torch.nn.functional.normalize(torch.randn(n, 3, device="cuda"), dim=1).contiguous()
+    tt = torch.tensor([[0.3]], dtype=torch.float32, device="cuda")
+    f = FusedFieldF32(sc.model, tt)
+    f.density_scale = 1.0
+    s, c = f(x, d)
+    with torch.no_grad():
+        sc.model.fused_inference = False
+        try:
+            s_ops, c_ops, _ = sc.model(x, d, tt)
+        finally:
+            del sc.model.fused_inference
+    np.testing.assert_allclose(s.cpu().numpy(), s_ops.float().cpu().numpy(), rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(c.cpu().numpy(), c_ops.float().cpu().numpy(), rtol=2e-4, atol=1e-6)

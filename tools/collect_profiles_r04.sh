@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects round 4's measurement artefacts on the GPU box into gpurun_out/profiles_r04/ (the summaries are copied into profiles/
 # afterwards).  rocprofv3: the profiled program comes right after `--`; counters in their own passes (with --kernel-trace only).
-#   bash tools/collect_profiles_r04.sh [bench|stats|pmc|grid|cpu800|modes|all]
+#   bash tools/collect_profiles_r04.sh [bench|stats|pmc|grid|fp32|cpu800|modes|all]
 set -o pipefail
 OUT=gpurun_out/profiles_r04
 mkdir -p $OUT
@@ -55,6 +55,11 @@ timeout -k 10 900 python3 tools/pmc_passes.py $OUT/pmc_grid $OUT/pmc_grid_raw.js
   --kernel k_grid_fwd --kernel k_grid_bwd \
   --note "tools/grid_bwd_speed.py: forward + backward of the stand-alone grid op, 9 000 / 262 144 ray-ordered and 2 097 152 uniform points, fp16 and fp32" -- python3 tools/grid_bwd_speed.py || exit 1
 echo "grid pmc done"
+fi
+if want fp32; then
+stats fp32 --fp32 --steps 20 --warmup 5 --no-cpu-baseline || exit 1
+python3 tools/field_f32_speed.py > $OUT/field_f32_speed.txt 2>/dev/null || exit 1
+echo "fp32 done"
 fi
 if want cpu800; then
 python3 bench.py --steps 20 --warmup 5 --no-secondary --cpu-baseline-side 800 > $OUT/bench_cpu_baseline_800.json 2>/dev/null || exit 1
