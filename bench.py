@@ -921,12 +921,24 @@ def grid_gather_rate(sc, dev, n_points=196352, launches=20):
     _, ms_r = timed(xr)
     if name is None:
         return None
+    # (since round 4 an inference forward under -O reads the QUAD copy of the table from its second call on -- two 16-byte gathers per
+    #  point and level instead of four 8-byte ones, gridencoder/grid.py; the plain kernel on the same points for comparison)
+    from gridencoder import grid as _grid_mod
+    _grid_mod.quad_forward = False
+    try:
+        _, ms_plain = timed(x)
+        _, ms_plain_r = timed(xr)
+    finally:
+        _grid_mod.quad_forward = True
     achieved = GRID_BYTES_PER_POINT["f16"] * n_points / (ms * 1e-3) / 1e9
     out = {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "bytes_per_point_algorithmic": GRID_BYTES_PER_POINT["f16"], "points_per_launch": n_points, "avg_launch_ms": ms, "launches": launches,
            "uniformly_random_points": {"avg_launch_ms": ms_r, "achieved": GRID_BYTES_PER_POINT["f16"] * n_points / (ms_r * 1e-3) / 1e9,
                                        "frac": GRID_BYTES_PER_POINT["f16"] * n_points / (ms_r * 1e-3) / 1e9 / HBM_PEAK_GBS},
-           "note": "algorithmic gather rate of the stand-alone op on a frame's own samples, clean run; counter bytes are static (separate rocprofv3 --pmc passes)"}
+           "plain_kernel": {"avg_launch_ms": ms_plain, "frac": GRID_BYTES_PER_POINT["f16"] * n_points / (ms_plain * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "uniformly_random_points_ms": ms_plain_r,
+                            "note": "k_grid_fwd on the .half() table (four 8-byte gathers per point and level): the kernel of rounds 1-3"},
+           "note": "algorithmic gather rate of the stand-alone op (inference: k_grid_fwd_quad on the QUAD copy of the table, bit-identical outputs) on a frame's own samples, clean run; counter bytes are static (separate rocprofv3 --pmc passes)"}
     pmc = os.path.join(ROOT, "profiles", "r02_grid_pmc_summary.json")
     if os.path.exists(pmc):
         try:

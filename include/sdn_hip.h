@@ -160,6 +160,12 @@ int sdn_compact_alive(const int32_t *in, uint32_t n, int32_t *out, int32_t *n_ou
  * gridtype 0 = hash, 1 = tiled; interp 0 = linear, 1 = smoothstep.
  * offsets_host: the same L+1 offsets in host memory (the reference re-reads them on the device;
  * passing them by value keeps every per-level constant in scalar registers). */
+/* The forward for D = 3, C = 2, 16 tiled levels, fp16 (no align_corners, linear interpolation: the dnerf configuration under `-O`) on the
+ * QUAD copy of the table (sdn_field_build_quad_table; ref_offsets_host = the reference's level offsets): two 16-byte gathers per
+ * (point, level) instead of four 8-byte ones, outputs [16, B, 2] fp16 bit-identical to sdn_grid_encode_forward's.  For inference on a
+ * table that does not change between calls; gridencoder/grid.py keeps the copy per table version. */
+int sdn_grid_encode_forward_quad_f16(const float *inputs, const void *quad_table, const int32_t *ref_offsets_host, void *outputs,
+                                     uint32_t B, float S, uint32_t H, void *stream);
 int sdn_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets_host,
                             void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                             void *dy_dx, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,

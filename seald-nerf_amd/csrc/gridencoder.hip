@@ -421,9 +421,124 @@ int dispatch_bwd(uint32_t D, uint32_t C, const T *grad, const float *inputs, T *
     }
 }
 
+// ---------------------------------------------------------------------------
+// forward on a QUAD copy of an fp16 table (sdn_field_build_quad_table: block r of a level = rows {r, r+1, r+s1, r+s1+1} mod the level's
+// row count -- the four (x, y) corners of a cell): TWO 16-byte gathers per (point, level) instead of four 8-byte ones.  The operator is
+// bound by the rate at which a CU takes lane-divergent gather addresses (DESIGN.md "The address-rate roof"), so halving the
+// addresses is what counts.  Same values into the same arithmetic as k_grid_fwd<__half, 3, 2> (tiled grid, no align_corners, linear
+// interpolation): bit-identical outputs.  For inference on a table that does not change between calls (gridencoder/grid.py keeps the
+// copy per table version).
+// ---------------------------------------------------------------------------
+struct QuadFwdLevels {
+    uint32_t offset_q[16], hsize[16], s1[16], s2[16];
+    float scale[16];
+};
+// LV levels per lane (blockIdx.y = level group): the inputs are read once per group and the 2 LV gathers of a lane are in flight together
+// -- the launch is short of waves, not of addresses, when every lane waits for two loads (one level per lane: 25 us per 196 352 points,
+// like the plain kernel; profiles/r04_grid_quad_forward.txt)
+template <int LV>
+__global__ void __launch_bounds__(256) k_grid_fwd_quad(const float *__restrict__ inputs, const uint4 *__restrict__ quad, __half *__restrict__ outputs,
+                                                       uint32_t B, QuadFwdLevels q) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level0 = blockIdx.y * LV;
+    float in[3];
+    bool oob = false;
+    #pragma unroll
+    for (uint32_t d = 0; d < 3; d++) {
+        in[d] = inputs[(size_t)b * 3 + d];
+        if (in[d] < 0 || in[d] > 1) oob = true;
+    }
+    if (oob) {
+        #pragma unroll
+        for (int k = 0; k < LV; k++) {
+            __half *out = outputs + ((size_t)(level0 + k) * B + b) * 2;
+            Num<__half>::st(out, 0.0f); Num<__half>::st(out + 1, 0.0f);
+        }
+        return;
+    }
+    float pos[LV][3];
+    uint4 lo[LV], hi[LV];
+    #pragma unroll
+    for (int k = 0; k < LV; k++) {
+        const uint32_t level = level0 + k;
+        const uint32_t hs = q.hsize[level], s1 = q.s1[level], s2 = q.s2[level];
+        const float scale = q.scale[level];
+        uint32_t pg[3];
+        #pragma unroll
+        for (uint32_t d = 0; d < 3; d++) {
+            pos[k][d] = in[d] * scale + 0.5f;
+            pg[d] = (uint32_t)floorf(pos[k][d]);
+            pos[k][d] -= (float)pg[d];
+        }
+        // get_grid_index (gridencoder.cu:66-84) of the cell's low corner and of the corner one step up in z; a dropped dimension has stride 0
+        const uint32_t lin = pg[0] + pg[1] * s1 + pg[2] * s2;
+        auto reduce = [&](uint32_t i) { return ((hs & (hs - 1u)) == 0u) ? (i & (hs - 1u)) : (i >= hs ? i % hs : i); };
+        lo[k] = quad[(size_t)q.offset_q[level] + reduce(lin)];
+        hi[k] = quad[(size_t)q.offset_q[level] + reduce(lin + s2)];
+    }
+    #pragma unroll
+    for (int k = 0; k < LV; k++) {
+        float ws[8];
+        #pragma unroll
+        for (uint32_t idx = 0; idx < 8; idx++) {
+            float w = 1;
+            #pragma unroll
+            for (uint32_t d = 0; d < 3; d++) w *= (idx & (1u << d)) ? pos[k][d] : 1 - pos[k][d];
+            ws[idx] = w;
+        }
+        const uint32_t raw[8] = {lo[k].x, lo[k].y, lo[k].z, lo[k].w, hi[k].x, hi[k].y, hi[k].z, hi[k].w};
+        float r0 = 0, r1 = 0;
+        #pragma unroll
+        for (uint32_t idx = 0; idx < 8; idx++) {
+            const __half2 v = __builtin_bit_cast(__half2, raw[idx]);
+            r0 = Num<__half>::rnd(r0 + Num<__half>::rnd(ws[idx] * __low2float(v)));
+            r1 = Num<__half>::rnd(r1 + Num<__half>::rnd(ws[idx] * __high2float(v)));
+        }
+        __half *out = outputs + ((size_t)(level0 + k) * B + b) * 2;
+        Num<__half>::st(out, r0); Num<__half>::st(out + 1, r1);
+    }
+}
+
 }  // namespace
 
 extern "C" {
+// grid_encode forward for D = 3, C = 2, 16 tiled levels, fp16, on the QUAD copy of the table (sdn_field_build_quad_table; ref_offsets_host
+// = the reference's 17 level offsets, the copy's level l starts at block ref_offsets_host[l] + 2 l): outputs [16, B, 2] fp16,
+// bit-identical to sdn_grid_encode_forward on the fp16 table.
+int sdn_grid_encode_forward_quad_f16(const float *inputs, const void *quad_table, const int32_t *ref_offsets_host, void *outputs, uint32_t B,
+                                     float S, uint32_t H, void *stream) {
+    if (B == 0) return 0;
+    if (!inputs || !quad_table || !ref_offsets_host || !outputs || ((uintptr_t)quad_table & 15u) != 0) return SDN_E_BADARG;
+    QuadFwdLevels q;
+    for (uint32_t l = 0; l < 16; l++) {
+        const uint32_t hs = (uint32_t)(ref_offsets_host[l + 1] - ref_offsets_host[l]);
+        if (hs == 0) return SDN_E_BADARG;
+        const float scale = exp2f((float)l * S) * (float)H - 1.0f;      // gridencoder.cu:138-139
+        const uint32_t res = (uint32_t)ceil((double)scale) + 1;
+        uint32_t stride = 1, st3[3] = {0, 0, 0};
+        for (int d = 0; d < 3; d++)
+            if (stride <= hs) { st3[d] = stride; stride *= (res + 1); }
+        if (st3[0] != 1) return SDN_E_BADARG;
+        q.offset_q[l] = (uint32_t)ref_offsets_host[l] + 2u * l;
+        q.hsize[l] = hs; q.s1[l] = st3[1]; q.s2[l] = st3[2]; q.scale[l] = scale;
+    }
+    static int lv = 0;            // levels per lane: 4 (SDN_GRID_QUAD_LEVELS = 1 | 2 | 4 | 8 | 16 for measurements)
+    if (lv == 0) { const char *e = getenv("SDN_GRID_QUAD_LEVELS"); lv = e ? atoi(e) : 4; }
+    const dim3 b256(256);
+    hipStream_t st = (hipStream_t)stream;
+    const uint4 *qt = (const uint4 *)quad_table;
+    __half *o = (__half *)outputs;
+    switch (lv) {
+        case 1: hipLaunchKernelGGL(k_grid_fwd_quad<1>, dim3(sdn_div_up(B, 256u), 16), b256, 0, st, inputs, qt, o, B, q); break;
+        case 2: hipLaunchKernelGGL(k_grid_fwd_quad<2>, dim3(sdn_div_up(B, 256u), 8), b256, 0, st, inputs, qt, o, B, q); break;
+        case 8: hipLaunchKernelGGL(k_grid_fwd_quad<8>, dim3(sdn_div_up(B, 256u), 2), b256, 0, st, inputs, qt, o, B, q); break;
+        case 16: hipLaunchKernelGGL(k_grid_fwd_quad<16>, dim3(sdn_div_up(B, 256u), 1), b256, 0, st, inputs, qt, o, B, q); break;
+        default: hipLaunchKernelGGL(k_grid_fwd_quad<4>, dim3(sdn_div_up(B, 256u), 4), b256, 0, st, inputs, qt, o, B, q); break;
+    }
+    return sdn_launch_status();
+}
+
 
 int sdn_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets_host, void *outputs, uint32_t B,
                             uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx, uint32_t gridtype,

@@ -37,6 +37,44 @@ def _deterministic():
     return os.environ.get("SDN_DETERMINISTIC", "0") == "1" or torch.are_deterministic_algorithms_enabled()
 
 
+# Inference on a table that does not change between calls (every iteration of a render loop, every slice of a density-grid update):
+# the fp16 forward of the dnerf geometry (D = 3, C = 2, 16 tiled levels, linear, no align_corners) reads a QUAD copy of the table --
+# one 16-byte block per row = the four (x, y) corners of a cell, two gathers per (point, level) instead of four -- built once per
+# table version (address + torch version counter) on the SECOND call that sees it, and bit-identical to the plain kernel
+# (csrc/gridencoder.hip k_grid_fwd_quad).  It also replaces the reference's per-call `.half()` cast of the whole table (grid.py:43-44).
+_QUAD_TABLES = {}
+
+
+quad_forward = True        # (measurements: False keeps every forward on the plain kernel)
+
+
+def _quad_table_for(embeddings, offsets_host, off_ptr, S, H):
+    if not quad_forward:
+        return None
+    key = (embeddings.data_ptr(), str(embeddings.device))
+    ent = _QUAD_TABLES.get(key)
+    if ent is None or ent["version"] != embeddings._version or ent["rows"] != embeddings.shape[0]:
+        if len(_QUAD_TABLES) >= 4:
+            _QUAD_TABLES.clear()
+        _QUAD_TABLES[key] = {"version": embeddings._version, "rows": embeddings.shape[0], "seen": 1, "quad": None, "bad": False}
+        return None
+    ent["seen"] += 1
+    if ent["bad"]:
+        return None
+    if ent["quad"] is None:
+        quad = torch.empty(embeddings.shape[0] + 32, 4, 2, dtype=torch.float16, device=embeddings.device)
+        src = embeddings.detach()
+        if src.dtype not in (torch.float32, torch.float16):
+            src = src.float()
+        src = src.contiguous()
+        rc = _lib.sdn_field_build_quad_table(_ptr(src), _dtype_id(src.dtype), off_ptr, S, H, _ptr(quad), _stream())
+        if rc != 0:            # a geometry the quad layout does not cover (a capped level that is neither dense nor a power of two)
+            ent["bad"] = True
+            return None
+        ent["quad"] = quad
+    return ent["quad"]
+
+
 class _grid_encode(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
@@ -119,7 +157,41 @@ class _grid_encode(Function):
         return grad_inputs, grad_embeddings, None, None, None, None, None, None, None
 
 
-grid_encode = _grid_encode.apply
+def _forward_on_quad_copy(inputs, embeddings, offsets, per_level_scale, base_resolution, gridtype, align_corners, interpolation):
+    """The inference forward of the dnerf geometry under `-O` on the QUAD copy of the table (see _quad_table_for), or None."""
+    if not (inputs.is_cuda and inputs.dim() == 2 and inputs.shape[1] == 3 and embeddings.dim() == 2 and embeddings.shape[1] == 2
+            and offsets.shape[0] == 17 and int(gridtype) == 1 and not align_corners and int(interpolation) == 0 and embeddings.is_contiguous()
+            and inputs.shape[0] > 0):
+        return None
+    S, H = float(np.log2(per_level_scale)), int(base_resolution)
+    _, off_ptr = _host_offsets(offsets)
+    quad = _quad_table_for(embeddings, None, off_ptr, S, H)
+    if quad is None:
+        return None
+    inputs = inputs.contiguous()
+    if inputs.dtype != torch.float32:
+        inputs = inputs.float()
+    B = inputs.shape[0]
+    outputs = torch.empty(16, B, 2, device=inputs.device, dtype=torch.half)
+    with _sdn.timed("grid_encode_fwd_f16", B):
+        _check(_lib.sdn_grid_encode_forward_quad_f16(_ptr(inputs, torch.float32, "inputs"), _ptr(quad), off_ptr, _ptr(outputs), B, S, H,
+                                                     _stream()), "grid_encode_forward_quad_f16")
+    return outputs.permute(1, 0, 2).reshape(B, 32)
+
+
+def grid_encode(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0, align_corners=False,
+                interpolation=0):
+    """grid.py:27-93 (`grid_encode = _grid_encode.apply`).  A call that can need no gradient -- grad mode off, or neither the inputs nor the
+    table require one -- under fp16 autocast takes the QUAD-copy forward when the geometry has one; everything else is the autograd
+    Function as before."""
+    if (torch.is_autocast_enabled("cuda") and not calc_grad_inputs
+            and not (torch.is_grad_enabled() and (inputs.requires_grad or embeddings.requires_grad))):
+        require_device()
+        out = _forward_on_quad_copy(inputs, embeddings, offsets, per_level_scale, base_resolution, gridtype, align_corners, interpolation)
+        if out is not None:
+            return out
+    return _grid_encode.apply(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs, gridtype, align_corners,
+                              interpolation)
 
 
 class GridEncoder(nn.Module):

@@ -718,3 +718,54 @@ def test_grid_encode_backward_deterministic_mode(dtype, monkeypatch):
     rel = float((det[0].float() - plain[0].float()).norm() / plain[0].float().norm())
     assert rel < (2e-2 if dtype == torch.float16 else 1e-5), rel
     assert float(det[0].float().abs().max()) > 0
+
+
+def test_grid_encode_forward_on_the_quad_copy_is_the_plain_forward_bit_for_bit():
+    """Inference under `-O` on a table that does not change between calls (gridencoder/grid.py `_quad_table_for`): from the second call
+    on, the dnerf geometry's fp16 forward reads the QUAD copy of the table (two 16-byte gathers per point and level, csrc/gridencoder.hip
+    k_grid_fwd_quad) -- same bits as the plain kernel on the `.half()` table and as the oracle; an in-place update of the table is seen
+    (torch's version counter) and the copy rebuilt; calls that need a gradient never take it."""
+    from gridencoder import GridEncoder
+    from gridencoder import grid as G
+    import sdn_backend
+    torch.manual_seed(3)
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048,
+                      gridtype="tiled", align_corners=False).cuda()
+    with torch.no_grad():
+        enc.embeddings.uniform_(-1.0, 1.0)
+    rng = np.random.default_rng(8)
+    x = torch.from_numpy(np.concatenate([rng.uniform(-1, 1, (20000, 3)), rng.uniform(-1.3, 1.3, (501, 3)),
+                                         np.array([[1.0, 1.0, 1.0], [-1.0, -1.0, -1.0], [1.0, -1.0, 0.999999]])]).astype(np.float32)).cuda()
+    G._QUAD_TABLES.clear()
+
+    def run():
+        launches = []
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16), sdn_backend.launch_log(launches):
+            out = enc(x, bound=1)
+        return out, launches
+
+    a, _ = run()                                   # first sight of this table version: the plain kernel
+    ent = next(iter(G._QUAD_TABLES.values()))
+    assert ent["quad"] is None and ent["seen"] == 1
+    b, _ = run()                                   # second call: the copy is built and used
+    assert ent["quad"] is not None and a.dtype == torch.float16
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    c, _ = run()
+    assert torch.equal(a.view(torch.int16), c.view(torch.int16))
+    emb16 = enc.embeddings.detach().half().cpu().numpy()
+    off = enc.offsets.cpu().numpy().astype(np.int32)
+    xin = ((x + 1) / 2).cpu().numpy()
+    ref, _ = O.grid_encode_forward(xin[:3000], emb16, off, float(enc.per_level_scale), enc.base_resolution, False, 1, False, 0)
+    assert np.array_equal(b[:3000].cpu().numpy().view(np.uint16), ref.view(np.uint16))
+    with torch.no_grad():
+        enc.embeddings.mul_(0.5)                   # in place: same address, new version
+    d, _ = run()
+    ent = next(iter(G._QUAD_TABLES.values()))
+    assert ent["quad"] is None                     # the stale copy is gone; this call ran the plain kernel on the new values
+    e, _ = run()
+    assert torch.equal(d.view(torch.int16), e.view(torch.int16)) and not torch.equal(d, a)
+    # a call that needs the table gradient keeps the plain path (and its saved tensors)
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = enc(x[:1000], bound=1)
+    out.float().sum().backward()
+    assert enc.embeddings.grad is not None and float(enc.embeddings.grad.abs().sum()) > 0
