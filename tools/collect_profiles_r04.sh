@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects round 4's measurement artefacts on the GPU box into gpurun_out/profiles_r04/ (the summaries are copied into profiles/
 # afterwards).  rocprofv3: the profiled program comes right after `--`; counters in their own passes (with --kernel-trace only).
-#   bash tools/collect_profiles_r04.sh [bench|stats|pmc|grid|fp32|cpu800|modes|all]
+#   bash tools/collect_profiles_r04.sh [bench|stats|pmc|grid|fp32|pmc32|cpu800|modes|all]
 set -o pipefail
 OUT=gpurun_out/profiles_r04
 mkdir -p $OUT
@@ -60,6 +60,17 @@ if want fp32; then
 stats fp32 --fp32 --steps 20 --warmup 5 --no-cpu-baseline || exit 1
 python3 tools/field_f32_speed.py > $OUT/field_f32_speed.txt 2>/dev/null || exit 1
 echo "fp32 done"
+fi
+if want pmc32; then
+# the fp32 fused field kernel under counters: static frame, one loop at a time
+B32="python3 bench.py --fp32 --static-frame --steps 4 --warmup 1 --pipeline 0 --no-cpu-baseline --min-timed-s 0"
+$B32 > $OUT/bench_pmc32_command.json 2>/dev/null || exit 1
+timeout -k 10 900 python3 tools/pmc_passes.py $OUT/pmc_field32 $OUT/pmc_field_f32_raw.json \
+  --set A=SQ_WAVES,SQ_WAVE_CYCLES,SQ_BUSY_CYCLES,SQ_WAIT_ANY,SQ_WAIT_INST_ANY,SQ_ACTIVE_INST_ANY,SQ_INSTS_VALU,SQ_INSTS_LDS \
+  --set B=SQ_VALU_MFMA_BUSY_CYCLES,SQ_BUSY_CU_CYCLES,SQ_INSTS_MFMA,SQ_ACTIVE_INST_VALU,SQ_THREAD_CYCLES_VALU,SQ_INSTS_SALU,SQ_WAIT_INST_LDS,SQ_ACTIVE_INST_LDS \
+  --set D=GRBM_GUI_ACTIVE,GRBM_COUNT --set E=FETCH_SIZE --set F=WRITE_SIZE \
+  --kernel k_field_f32 --note "bench.py --fp32, static frame, one loop at a time" -- $B32 || exit 1
+echo "pmc32 done"
 fi
 if want cpu800; then
 python3 bench.py --steps 20 --warmup 5 --no-secondary --cpu-baseline-side 800 > $OUT/bench_cpu_baseline_800.json 2>/dev/null || exit 1
