@@ -5,6 +5,8 @@ Same API as /root/reference/gridencoder/grid.py: `grid_encode` (autograd Functio
 parameter / buffer names (`embeddings`, `offsets`) and initialisation, so reference
 checkpoints load unchanged.
 """
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -53,10 +55,13 @@ def _quad_table_for(embeddings, offsets_host, off_ptr, S, H):
         return None
     key = (embeddings.data_ptr(), str(embeddings.device))
     ent = _QUAD_TABLES.get(key)
-    if ent is None or ent["version"] != embeddings._version or ent["rows"] != embeddings.shape[0]:
+    # (the tensor OBJECT too, not only its address and version: the allocator hands a freed table's address to the next model's table,
+    #  and two fresh tables can carry the same version number)
+    if ent is None or ent["ref"]() is not embeddings or ent["version"] != embeddings._version or ent["rows"] != embeddings.shape[0]:
         if len(_QUAD_TABLES) >= 4:
             _QUAD_TABLES.clear()
-        _QUAD_TABLES[key] = {"version": embeddings._version, "rows": embeddings.shape[0], "seen": 1, "quad": None, "bad": False}
+        _QUAD_TABLES[key] = {"ref": weakref.ref(embeddings), "version": embeddings._version, "rows": embeddings.shape[0], "seen": 1,
+                             "quad": None, "bad": False}
         return None
     ent["seen"] += 1
     if ent["bad"]:

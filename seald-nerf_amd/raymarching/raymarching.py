@@ -11,6 +11,8 @@ all on the safe side of the reference's behaviour:
   * march_rays clears only the alignment tail of its outputs (the kernel writes the
     zeros for exhausted rays itself) instead of memset-ing three M-sized buffers.
 """
+import weakref
+
 import torch
 from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
@@ -215,13 +217,16 @@ def _cull_grid_of(bitfield, C, H):
         return None
     key = (bitfield.data_ptr(), bitfield.numel(), str(bitfield.device))
     hit = _CULL_CACHE.get(key)
-    if hit is not None and hit[0] == bitfield._version:
+    # (the buffer OBJECT too -- a slice is a fresh view per call, its base is not: the allocator hands a freed bitfield's address to the
+    #  next model's, and the version counters of two buffers can coincide)
+    owner = bitfield._base if bitfield._base is not None else bitfield
+    if hit is not None and hit[0] == bitfield._version and hit[2]() is owner:
         return hit[1]
     if len(_CULL_CACHE) >= 256:
         _CULL_CACHE.clear()
     grid = torch.empty(int(_lib.sdn_cull_grid_bytes()), dtype=torch.uint8, device=bitfield.device)
     _check(_lib.sdn_build_cull_grid(_ptr(bitfield), 128, _ptr(grid), _stream()), "build_cull_grid")
-    _CULL_CACHE[key] = (bitfield._version, grid)
+    _CULL_CACHE[key] = (bitfield._version, grid, weakref.ref(owner))
     return grid
 
 
