@@ -484,7 +484,7 @@ def main():
     # (N GPUs: 4 N frames' shards per loop, i.e. the same 2.56 M rays per loop as 4 full frames on one GPU -- one rank of 8 at --steps 20:
     # 0.0876 ms per frame with 5 frames per loop, 0.0713 with 10; profiles/r03_rank_frames_per_loop.txt)
     want_f = args.group_frames if args.group_frames > 0 else (min(16, 4 * world) if world > 1 else (4 if args.emulate_rank_of <= 1 else 1))
-    if args.group_frames == 0 and (args.field == "ops" or args.fp32 or args.loop == "host"):
+    if args.group_frames == 0 and (args.field == "ops" or args.loop == "host"):
         want_f = 1            # frame groups need the device loop with the fused field
     F = min((d for d in range(1, 17) if K % d == 0), key=lambda d: (abs(d - min(want_f, 16)), -d))    # the divisor of --steps nearest to it
     n_groups = K // F

@@ -407,7 +407,7 @@ typedef struct SdnRenderCtx {
     const void *frame_cull[SDN_MAX_GROUP_FRAMES];
     /* 0: the fp16 fused field (`-O`: field_weights / grid_table / grid_offsets are sdn_field_forward_f16's); 1: the fp32 fused field
      * (the reference without `-O`): field_weights = sdn_field_forward_f32's packed floats, field_bias0 [128] the fp32 bias row,
-     * grid_table the fp32 embeddings in the reference's layout, grid_offsets the reference's offsets; one frame per loop only */
+     * grid_table the fp32 embeddings in the reference's layout, grid_offsets the reference's offsets */
     int32_t field_f32;
     int32_t reserved2_;
 } SdnRenderCtx;

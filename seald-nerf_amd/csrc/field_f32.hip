@@ -39,6 +39,7 @@ constexpr int kWaves = SDN_F32_WAVES;          // waves per workgroup (8: one wo
 constexpr int kPieces = 16384 / (64 * kWaves * 4);   // 16-byte pieces per thread of a 64-KiB stage
 constexpr int kPointsPerWG = 32 * kWaves;
 constexpr int kStageFloats = 16384;   // 64 KiB: one 128 x 128 layer
+constexpr int kMaxFrames = 16;        // frames of a frame group (SDN_MAX_GROUP_FRAMES)
 
 // packed weights (floats), in stage order: D0 | D1 .. D6 | tail = D7 S0 S1 C0 C1 C2   (dnerf_amd/fused_f32.py: pack_weights_f32)
 constexpr int kD0 = 0, kD0Floats = 32 * 64 * 4;                  // 32 pairs x 4 m-tiles
@@ -58,7 +59,9 @@ struct F32Args {
     const float *weights, *bias0, *table;
     float *sigmas, *rgbs, *deform;      // deform: optional [M,3], the deformation network's output (zeros on the canonical frame)
     float bound, density_scale;
-    int zero_deform;
+    int zero_deform;              // bit f: frame f is the canonical frame (no deformation)
+    const uint8_t *slot_frame;    // frame group: frame of every sample slot (bias0 then holds n_frames rows), or nullptr = one frame
+    uint32_t n_frames;
 };
 
 // one layer: PAIRS k-pairs of B operands (registers) against the staged A operands, MT output tiles of 32 rows
@@ -86,7 +89,7 @@ __device__ __forceinline__ void relu_into(const float16_t (&acc)[MT], float (&b)
 
 __global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) k_field_f32(F32Args P, LevelParams lp) {
     __shared__ __attribute__((aligned(16))) float s_w[kStageFloats];
-    __shared__ float s_bias[128];
+    __shared__ float s_bias[kMaxFrames * 128];      // the frames' time-encoding bias rows (D0's initial accumulators)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t h = lane >> 5, n = lane & 31u;
     const uint32_t count = P.state ? P.live_count[P.state[3]] : (P.live_idx ? *P.live_count : P.M);
@@ -135,7 +138,9 @@ __global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) k_field_f32(F32Args P
     constexpr std::integral_constant<int, kD0Floats> c_d0{};
     constexpr std::integral_constant<int, kStageFloats> c_stage{};
     Pre pre = prefetch(P.weights + kD0, c_d0);
-    if (threadIdx.x < 128) s_bias[threadIdx.x] = P.bias0[threadIdx.x];
+    for (uint32_t k = threadIdx.x; k < P.n_frames * 128u; k += 64 * kWaves) s_bias[k] = P.bias0[k];
+    const uint32_t fr = (P.slot_frame && valid) ? (uint32_t)P.slot_frame[slot] : 0u;      // (< n_frames: written by the marcher)
+    const bool canonical = (P.zero_deform >> fr) & 1;
 
     // ---- deformation network: freq(x, 10) (time part folded into bias0) -> 128 x 7 -> 3 ----
     float bin[64];
@@ -152,7 +157,7 @@ __global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) k_field_f32(F32Args P
     #pragma unroll
     for (int mt = 0; mt < 4; mt++)
         #pragma unroll
-        for (int v = 0; v < 16; v++) acc[mt][v] = s_bias[mt * 32 + (v >> 2) * 8 + h * 4 + (v & 3)];
+        for (int v = 0; v < 16; v++) acc[mt][v] = s_bias[fr * 128u + mt * 32 + (v >> 2) * 8 + h * 4 + (v & 3)];
     {
         float b0[32];
         #pragma unroll
@@ -179,11 +184,12 @@ __global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) k_field_f32(F32Args P
     // rows 0..2 of the output live in registers 0..2 of the lower lane half; the upper half evaluates the same point
     if (P.deform && valid && h == 0) {      // dnerf/network.py:139-141: `deform = zeros` on the canonical frame
         #pragma unroll
-        for (int k = 0; k < 3; k++) P.deform[(size_t)slot * 3 + k] = P.zero_deform ? 0.0f : a1[0][k];
+        for (int k = 0; k < 3; k++) P.deform[(size_t)slot * 3 + k] = canonical ? 0.0f : a1[0][k];
     }
-    if (!P.zero_deform) {
-        #pragma unroll
-        for (int k = 0; k < 3; k++) x[k] = x[k] + __shfl(a1[0][k], (int)n, 64);
+    #pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float dk = __shfl(a1[0][k], (int)n, 64);
+        if (!canonical) x[k] = x[k] + dk;
     }
 
     // ---- sigma network: grid(x') -> 64 -> 16 ----
@@ -280,7 +286,8 @@ __global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) k_field_f32(F32Args P
 namespace sdn_int {
 int field_forward_f32(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count, const int32_t *state,
                       uint32_t M, const float *weights, const float *bias0, const float *table, const int32_t *offsets_host, float S,
-                      uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, float *deform, hipStream_t st) {
+                      uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, float *deform,
+                      const uint8_t *slot_frame, uint32_t n_frames, hipStream_t st) {
     LevelParams lp;
     int rc = sdn_grid::fill_levels(lp, offsets_host, 16u, S, H);
     if (rc) return rc;
@@ -288,6 +295,7 @@ int field_forward_f32(const float *xyzs, const float *dirs, const uint32_t *live
     a.xyzs = xyzs; a.dirs = dirs; a.live_idx = live_idx; a.live_count = live_count; a.state = state; a.M = M;
     a.weights = weights; a.bias0 = bias0; a.table = table; a.sigmas = sigmas; a.rgbs = rgbs; a.deform = deform;
     a.bound = bound; a.density_scale = density_scale; a.zero_deform = zero_deform;
+    a.slot_frame = slot_frame; a.n_frames = slot_frame ? (n_frames > (uint32_t)kMaxFrames ? (uint32_t)kMaxFrames : (n_frames ? n_frames : 1u)) : 1u;
     hipLaunchKernelGGL(k_field_f32, dim3(sdn_div_up(M, (uint32_t)kPointsPerWG)), dim3(64 * kWaves), 0, st, a, lp);
     return sdn_launch_status();
 }
@@ -305,7 +313,7 @@ int sdn_field_forward_f32(const float *xyzs, const float *dirs, const uint32_t *
     if ((live_idx == nullptr) != (live_count == nullptr)) return SDN_E_BADARG;
     if (((uintptr_t)weights & 15u) != 0 || ((uintptr_t)table & 3u) != 0) return SDN_E_BADARG;
     return sdn_int::field_forward_f32(xyzs, dirs, live_idx, live_count, nullptr, M, weights, bias0, table, offsets_host, S, H, bound,
-                                      density_scale, zero_deform ? 1 : 0, sigmas, rgbs, deform, (hipStream_t)stream);
+                                      density_scale, zero_deform ? 1 : 0, sigmas, rgbs, deform, nullptr, 1u, (hipStream_t)stream);
 }
 
 }  // extern "C"

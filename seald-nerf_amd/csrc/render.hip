@@ -89,7 +89,8 @@ static int launch_field(const SdnRenderCtx *c, uint32_t m_bound, uint32_t expect
     if (c->field_f32)
         return sdn_int::field_forward_f32(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, m_bound,
                                           (const float *)c->field_weights, c->field_bias0, (const float *)c->grid_table, c->grid_offsets, c->grid_S,
-                                          c->grid_H, c->bound, c->density_scale, c->zero_deform, c->sigmas, c->rgbs, nullptr, st);
+                                          c->grid_H, c->bound, c->density_scale, c->zero_deform, c->sigmas, c->rgbs, nullptr,
+                                          c->n_group_frames > 1 ? c->slot_frame : nullptr, c->n_group_frames > 1 ? c->n_group_frames : 1u, st);
     return sdn_int::field_forward_f16(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, m_bound, c->field_weights,
                                       c->field_bias0, c->grid_table, c->grid_offsets, c->grid_S, c->grid_H, c->bound, c->density_scale,
                                       c->zero_deform, c->sigmas, c->rgbs, expect_points, c->n_group_frames > 1 ? c->slot_frame : nullptr,
@@ -101,7 +102,6 @@ static bool ctx_ok(const SdnRenderCtx *c) {
           c->depth && c->image && c->state && c->live_counts && c->cull_bits))
         return false;
     if (c->n_group_frames > 1) {   // frame group: one occupancy slice per frame, rays split evenly, the per-slot frame scratch
-        if (c->field_f32) return false;                       // (the fp32 field kernel evaluates one frame's constants per launch)
         if (c->n_group_frames > SDN_MAX_GROUP_FRAMES || !c->slot_frame || c->rays_per_frame == 0 ||
             (uint64_t)c->n_group_frames * c->rays_per_frame != c->N)
             return false;

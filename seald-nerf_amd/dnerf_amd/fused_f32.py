@@ -94,7 +94,7 @@ class FusedFieldF32:
         self.H = int(enc.base_resolution)
         self.bound = float(model.bound)
         self.density_scale = float(model.density_scale)
-        self._time_cache = {}
+        self._time_cache, self._group_cache = {}, {}
         self.set_time(time)
         self._buf = None
         if max_points:
@@ -127,18 +127,25 @@ class FusedFieldF32:
         self.bias0, self.zero_deform, self.t_idx = self.time_constants(time)
 
     def group_constants(self, times):
-        """(bias0 [1,128], zero_deform bit, [slice index]) in the shape `renderer.DeviceLoop.frame_time` asks for; the fp32 kernel
-        evaluates ONE frame's constants per launch, so a group has one frame."""
-        if len(times) != 1:
-            raise NotImplementedError("the fp32 fused field renders one frame per loop (frame groups are a feature of the -O path)")
-        bias0, zero, t_idx = self.time_constants(times[0])
-        return bias0.reshape(1, 128), zero, [t_idx]
+        """(bias0 [F,128] contiguous, zero_deform bit mask, slice indices) for the F frames of a frame group; cached by value."""
+        key = tuple(self.time_value(t) for t in times)
+        hit = self._group_cache.get(key)
+        if hit is None:
+            parts = [self.time_constants(t) for t in key]
+            bias = torch.stack([p[0] for p in parts]).contiguous()
+            mask = sum(p[1] << f for f, p in enumerate(parts))
+            hit = (bias, mask, [p[2] for p in parts])
+            if len(self._group_cache) >= 1024:
+                self._group_cache.clear()
+            self._group_cache[key] = hit
+        return hit
 
     def refresh(self):
         """Re-pack after the weights changed (the table is read in place)."""
         self.weights.copy_(torch.from_numpy(pack_weights_f32(self.model)))
         self.table = self.model.encoder.embeddings.detach()
         self._time_cache.clear()
+        self._group_cache.clear()
 
     def _alloc(self, M):
         dev = self.weights.device

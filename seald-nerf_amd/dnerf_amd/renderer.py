@@ -521,8 +521,6 @@ class DeviceLoop:
         # the fp32 fused field (dnerf_amd.fused_f32.FusedFieldF32: the reference without -O) in the same loop: its packed floats, the
         # model's fp32 table in place, the reference's offsets
         c.field_f32 = 1 if type(field).__name__ == "FusedFieldF32" else 0
-        if c.field_f32 and self.frames > 1:
-            raise NotImplementedError("the fp32 fused field renders one frame per loop")
         self.ctx = c
         self.max_steps = int(max_steps)
         self.set_mapper(mapper)

@@ -114,8 +114,11 @@ def test_native_loops_with_the_fp32_field_equal_the_host_stepped_loop(small_scen
         b = one.render(sc.rays_o, sc.rays_d, t)
         torch.cuda.synchronize()
         assert torch.equal(b["image"], outs[k][0]), k
-    with pytest.raises(NotImplementedError):
-        DeviceLoop(sc.model, f, 2 * N, dev, frames=2)
+    # a frame group (three frames' rays in one loop, each at its own time incl. the canonical one): every frame bit-identical to the frame alone
+    grp = DeviceLoop(sc.model, f, 3 * N, dev, frames=3).render(sc.rays_o.repeat(3, 1), sc.rays_d.repeat(3, 1), times)
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert torch.equal(grp["image"][k * N:(k + 1) * N], outs[k][0]), k
 
 
 def test_forward_dispatches_to_the_fp32_kernel_when_asked(small_scene):
