@@ -778,7 +778,7 @@ def main():
                 + (f"; {n_excl} of them (the last" + (" and the quarter points" if n_excl > 2 else (" and the midpoint" if n_excl == 2 else "")) + ") rendered with nothing else in flight -- their launches give achieved / frac -- and "
                    f"{n_instrumented - n_excl} overlapped like the uninstrumented ones (the `overlapped` entry)" if ploop is not None else ""))
             # field FLOPs of the whole timed region over its wall time: a lower bound of the kernel's rate that no overlap can inflate
-            result["roofline"]["whole_job_mfma_frac"] = FIELD_FLOP_PER_POINT * n_samples / elapsed / 1e12 / (MFMA_F16_PEAK_TFLOPS if fp16 else MFMA_F32_PEAK_TFLOPS)
+            result["roofline"]["whole_job_mfma_frac"] = FIELD_FLOP_PER_POINT * n_samples / elapsed / 1e12 / result["roofline"]["peak"]
         if world == 1 and dloop is not None and not args.no_secondary and args.emulate_rank_of <= 1:
             result["roofline_secondary"] = marcher_roofline(dloop, grp_o, grp_d, grp_t, n_groups, distinct, frame_cam, F)
             result["grid_gather_rate"] = grid_gather_rate(sc, dev)
@@ -988,8 +988,10 @@ def roofline(timers, fp16, points_exclusive, points_overlapped=0):
                 "avg_launch_ms": s["avg_ms"], "avg_points_per_launch": s["avg_units"]}
     else:
         achieved = FIELD_FLOP_PER_POINT * s["avg_units"] / (s["avg_ms"] * 1e-3) / 1e12
-        peak = MFMA_F16_PEAK_TFLOPS if fp16 else MFMA_F32_PEAK_TFLOPS
-        roof = {"kernel": name if fp16 else "field_forward_f32", "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+        peak = MFMA_F16_PEAK_TFLOPS if fp16 else (MFMA_F16_PEAK_TFLOPS / 3.0 if os.environ.get("SDN_FIELD_F32", "mfma32") == "split" else MFMA_F32_PEAK_TFLOPS)
+        # (--fp32 with SDN_FIELD_F32=split: fp32 operands as fp16 pairs, THREE fp16 MFMAs per product -- the matrix roof of the network's
+        #  FLOPs is a third of the fp16 peak)
+        roof = {"kernel": name if fp16 else ("field_forward_f32x3" if os.environ.get("SDN_FIELD_F32", "mfma32") == "split" else "field_forward_f32"), "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": None, "flop_per_point": FIELD_FLOP_PER_POINT,
                 "avg_launch_ms": s["avg_ms"], "avg_points_per_launch": s["avg_units"]}
         pmc = os.path.join(ROOT, "profiles", PMC_SUMMARY)

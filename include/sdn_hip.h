@@ -239,6 +239,15 @@ int sdn_field_forward_f32(const float *xyzs, const float *dirs, const uint32_t *
                           const int32_t *offsets_host, float S, uint32_t H, float bound, float density_scale,
                           int zero_deform, float *sigmas, float *rgbs, float *deform, void *stream);
 
+/* The same fp32 network on the fp16 matrix pipes (csrc/field_f32x3.hip): every fp32 operand split into hi + lo fp16 values, three
+ * v_mfma_f32_32x32x16_f16 per product (hi.hi + hi.lo + lo.hi, fp32 accumulation; the dropped lo.lo term is 2^-22 relative) -- the
+ * accuracy of the fp32 kernel at 3 / 16 of its matrix time.  weights: sdn_field_weight_floats_f32() * 4 bytes in the order of
+ * dnerf_amd/fused_f32.py:pack_weights_f32_split; every other argument as sdn_field_forward_f32. */
+int sdn_field_forward_f32x3(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count,
+                            uint32_t M, const float *weights, const float *bias0, const float *table,
+                            const int32_t *offsets_host, float S, uint32_t H, float bound, float density_scale,
+                            int zero_deform, float *sigmas, float *rgbs, float *deform, void *stream);
+
 /* Which kernel large launches of the fused field network take: 1 = the persistent two-set ("ping-pong") kernel, the default for launches
  * of at least 4 tiles of 256 points per CU on a QUAD table; 0 = one tile per workgroup for every launch; -1 = environment SDN_FIELD_PP or
  * the default.  Both produce the same bits: a switch for tests and A/B measurements, not a tuning knob. */
@@ -405,7 +414,8 @@ typedef struct SdnRenderCtx {
     /* optional prebuilt cull grids (sdn_build_cull_grid) of `bitfield` (entry 0) / of frame_bitfield[f]: copied into cull_bits at the
      * start of a frame instead of being derived again; any NULL entry among the frames in use = derive */
     const void *frame_cull[SDN_MAX_GROUP_FRAMES];
-    /* 0: the fp16 fused field (`-O`: field_weights / grid_table / grid_offsets are sdn_field_forward_f16's); 1: the fp32 fused field
+    /* 0: the fp16 fused field (`-O`: field_weights / grid_table / grid_offsets are sdn_field_forward_f16's); 1 / 2: the fp32 fused field
+     * on fp32 MFMAs (sdn_field_forward_f32) / on split fp16 operands (sdn_field_forward_f32x3)
      * (the reference without `-O`): field_weights = sdn_field_forward_f32's packed floats, field_bias0 [128] the fp32 bias row,
      * grid_table the fp32 embeddings in the reference's layout, grid_offsets the reference's offsets */
     int32_t field_f32;

@@ -1,0 +1,371 @@
+// Fused field network with fp32 ACCURACY on the fp16 matrix pipes: every fp32 operand is split x = hi + lo (two fp16 values, 22 bits of
+// mantissa) and a product is three MFMAs -- hi.hi + hi.lo + lo.hi, accumulated in fp32 (the dropped lo.lo term is 2^-22 relative).
+// v_mfma_f32_32x32x16_f16 does 16 k-steps in 32 cycles where v_mfma_f32_32x32x2_f32 does 2 in 64: three of them are 3 / 16 of the fp32
+// MFMA time, paid for with three vector instructions per activation (max, convert, subtract-convert).  Same 1e-4 bar against the fp32
+// network as field_f32.hip, same encoders (the fp32 operators' expressions), same staging; the operand layout is the fp16 kernel's
+// (field.hip): accumulator registers 8 s .. 8 s + 7 of output tile t are k-step (t, s) of the next layer's B operand, the k-order baked
+// into the weight packing (dnerf_amd/fused.py kmaps, reused by fused_f32.py: pack_weights_f32_split).
+//
+// Scaling.  The fp16 MFMA flushes subnormal inputs, and the lo part of a value is 2^-12 of it: unscaled, every activation below 0.25 and
+// every weight below 0.25 would lose its lo part (measured: 2e-4 relative errors).  Activations travel as 2^6 x and weights as 2^8 w
+// (exact scalings), accumulators hold 2^14 times the layer's output and are brought back by the 2^-8 of the next split / the 2^-14 of an
+// output: lo parts stay normal down to |x| = 4e-3 and |w| = 1e-3, the hi parts fit fp16 up to |x| = 1023 and |w| = 255.
+//
+// Packed weights, per layer: [k-step][lane][m-tile][hi | lo][8 halves] -- one lane reads its 32 bytes per m-tile with two ds_read_b128.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "grid_common.h"
+#include "sdn_common.h"
+#include "sdn_internal.h"
+#include "sh_eval.h"
+
+namespace {
+
+using sdn_grid::LevelParams;
+typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+struct Split { half8_t hi, lo; };
+constexpr float kXS = 64.0f, kWS = 256.0f;            // operand scales (see "Scaling"); accumulators carry kXS * kWS
+constexpr float kAccToX = 1.0f / kWS, kAccToOut = 1.0f / (kXS * kWS);
+
+#ifndef SDN_F32_WAVES
+#define SDN_F32_WAVES 4
+#endif
+constexpr int kWaves = SDN_F32_WAVES;          // waves per workgroup (8: one workgroup per CU; 4: two, out of step with each other)
+constexpr int kPieces = 16384 / (64 * kWaves * 4);   // 16-byte pieces per thread of a 64-KiB stage
+constexpr int kPointsPerWG = 32 * kWaves;
+constexpr int kStageFloats = 16384;   // 64 KiB: one 128 x 128 layer
+constexpr int kMaxFrames = 16;        // frames of a frame group (SDN_MAX_GROUP_FRAMES)
+
+// packed weights (floats), in stage order: D0 | D1 .. D6 | tail = D7 S0 S1 C0 C1 C2   (dnerf_amd/fused_f32.py: pack_weights_f32)
+constexpr int kD0 = 0, kD0Floats = 4 * 64 * 4 * 8;                // 4 k-steps x 64 lanes x 4 m-tiles x 32 bytes, in floats
+constexpr int kD1 = kD0 + kD0Floats;                             // six stages of 8 k-steps x 4 m-tiles
+constexpr int kTail = kD1 + 6 * kStageFloats;
+constexpr int kBlk = 64 * 8;   // floats of one (k-step, m-tile): 64 lanes x 32 bytes
+constexpr int kT_D7 = 0, kT_S0 = kT_D7 + 8 * kBlk, kT_S1 = kT_S0 + 2 * 2 * kBlk, kT_C0 = kT_S1 + 4 * kBlk, kT_C1 = kT_C0 + 2 * 2 * kBlk,
+              kT_C2 = kT_C1 + 4 * 2 * kBlk, kTailFloats = kT_C2 + 4 * kBlk;
+static_assert(kTailFloats == kStageFloats, "the tail stage is one LDS buffer");
+static_assert(kTail == kD1 + 6 * kStageFloats, "the tail stage follows D6: the hidden-layer loop prefetches it as 'D7'");
+constexpr int kTotalFloats = kTail + kTailFloats;
+
+struct F32Args {
+    const float *xyzs, *dirs;
+    const uint32_t *live_idx, *live_count;
+    const int32_t *state;
+    uint32_t M;
+    const float *weights, *bias0, *table;
+    float *sigmas, *rgbs, *deform;      // deform: optional [M,3], the deformation network's output (zeros on the canonical frame)
+    float bound, density_scale;
+    int zero_deform;              // bit f: frame f is the canonical frame (no deformation)
+    const uint8_t *slot_frame;    // frame group: frame of every sample slot (bias0 then holds n_frames rows), or nullptr = one frame
+    uint32_t n_frames;
+};
+
+__device__ __forceinline__ Split split8(const float (&x)[8], float scale) {      // x * scale = hi + lo
+    Split r;
+    #pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float v = x[j] * scale;
+        r.hi[j] = (_Float16)v;
+        r.lo[j] = (_Float16)(v - (float)r.hi[j]);
+    }
+    return r;
+}
+
+// one layer: KS k-steps of 16 (B operands split in registers) against the staged split A operands, MT output tiles of 32 rows
+template <int KS, int MT>
+__device__ __forceinline__ void layer(const float *s_w, const Split (&b)[KS], float16_t (&acc)[MT], uint32_t lane) {
+    #pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(s_w) + ((size_t)ks * 64 + lane) * MT * 2;
+        half8_t ah[MT], al[MT];
+        #pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            ah[mt] = __builtin_bit_cast(half8_t, src[2 * mt]);
+            al[mt] = __builtin_bit_cast(half8_t, src[2 * mt + 1]);
+        }
+        #pragma unroll
+        for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], b[ks].hi, acc[mt], 0, 0, 0);
+        #pragma unroll
+        for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], b[ks].lo, acc[mt], 0, 0, 0);
+        #pragma unroll
+        for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], b[ks].hi, acc[mt], 0, 0, 0);
+#ifdef SDN_X3_LOLO
+        // (the fourth term, 2^-22 of the product: measured, changes no result at the test's resolution -- what separates this kernel from the
+        //  fp32 one is the 22-bit operands, not the dropped term)
+        #pragma unroll
+        for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], b[ks].lo, acc[mt], 0, 0, 0);
+#endif
+    }
+}
+
+// accumulator registers 8 s .. 8 s + 7 of tile t -> k-step 2 t + s of the next layer (ReLU, then the split)
+template <int MT, bool RELU>
+__device__ __forceinline__ void operands_from(const float16_t (&acc)[MT], Split (&b)[2 * MT]) {
+    #pragma unroll
+    for (int t = 0; t < MT; t++)
+        #pragma unroll
+        for (int sh = 0; sh < 2; sh++) {
+            float x[8];
+            #pragma unroll
+            for (int j = 0; j < 8; j++) x[j] = RELU ? fmaxf(acc[t][8 * sh + j], 0.0f) : acc[t][8 * sh + j];
+            b[2 * t + sh] = split8(x, kAccToX);       // accumulators hold kXS kWS y: the next operand is kXS y
+        }
+}
+
+__global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) k_field_f32x3(F32Args P, LevelParams lp) {
+    __shared__ __attribute__((aligned(16))) float s_w[kStageFloats];
+    __shared__ float s_bias[kMaxFrames * 128];      // the frames' time-encoding bias rows (D0's initial accumulators)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t h = lane >> 5, n = lane & 31u;
+    const uint32_t count = P.state ? P.live_count[P.state[3]] : (P.live_idx ? *P.live_count : P.M);
+    if (blockIdx.x * (uint32_t)kPointsPerWG >= count) return;            // workgroup-uniform, before any barrier
+    const uint32_t i = blockIdx.x * (uint32_t)kPointsPerWG + wave * 32u + n;
+    const bool valid = i < count;
+    const uint32_t slot = valid ? (P.live_idx ? P.live_idx[i] : i) : 0u;
+    float x[3] = {0, 0, 0}, d[3] = {0, 0, 1};
+    if (valid) {
+        x[0] = P.xyzs[(size_t)slot * 3]; x[1] = P.xyzs[(size_t)slot * 3 + 1]; x[2] = P.xyzs[(size_t)slot * 3 + 2];
+        d[0] = P.dirs[(size_t)slot * 3]; d[1] = P.dirs[(size_t)slot * 3 + 1]; d[2] = P.dirs[(size_t)slot * 3 + 2];
+    }
+    // Weight stages: the NEXT stage's 16-byte pieces are fetched into registers before a layer's MFMAs start (8 per thread for 64 KiB) and
+    // written to LDS when every wave is through with the current stage -- the global latency runs under the layer instead of in front of it
+    struct Pre { float4 v[kPieces]; };
+    // (stage sizes are multiples of one piece per thread, 2 048 floats: the guard is a compile-time one -- a lane-dependent guard made
+    //  every piece a predicated merge that waited for its load on the spot)
+    auto prefetch = [&](const float *src, auto floats_c) -> Pre {
+        constexpr int floats = decltype(floats_c)::value;
+        static_assert(floats % (64 * kWaves * 4) == 0, "whole pieces");
+        Pre r;
+        #pragma unroll
+        for (int q = 0; q < kPieces; q++)
+            r.v[q] = (q * 64 * kWaves * 4 < floats) ? *reinterpret_cast<const float4 *>(src + (q * 64 * kWaves + (int)threadIdx.x) * 4)
+                                                    : make_float4(0, 0, 0, 0);
+        // (left alone the scheduler sinks these loads to the end of the layer, where nothing hides them)
+        __builtin_amdgcn_sched_barrier(0);
+        return r;
+    };
+    // (a bare s_barrier behind the wave's own LDS traffic: __syncthreads() carries a fence that drains the global loads in flight --
+    //  exactly the prefetch -- at the first barrier after they were issued; measured 104 -> 93 TFLOP/s with it)
+    auto wg_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto commit = [&](const Pre &r, auto floats_c) {
+        constexpr int floats = decltype(floats_c)::value;
+        wg_barrier();                                      // every wave has finished reading the previous stage
+        #pragma unroll
+        for (int q = 0; q < kPieces; q++)
+            if (q * 64 * kWaves * 4 < floats) *reinterpret_cast<float4 *>(s_w + (q * 64 * kWaves + (int)threadIdx.x) * 4) = r.v[q];
+        wg_barrier();
+    };
+    constexpr std::integral_constant<int, kD0Floats> c_d0{};
+    constexpr std::integral_constant<int, kStageFloats> c_stage{};
+    Pre pre = prefetch(P.weights + kD0, c_d0);
+    for (uint32_t k = threadIdx.x; k < P.n_frames * 128u; k += 64 * kWaves) s_bias[k] = P.bias0[k];
+    const uint32_t fr = (P.slot_frame && valid) ? (uint32_t)P.slot_frame[slot] : 0u;      // (< n_frames: written by the marcher)
+    const bool canonical = (P.zero_deform >> fr) & 1;
+
+    // ---- deformation network: freq(x, 10) (time part folded into bias0) -> 128 x 7 -> 3 ----
+    // k position (k-step s, lane half h, j), q = 8 s + j: q < 30 -> pair (f, d) = (5 h + (q >> 1) / 3, (q >> 1) % 3), sine for even q, the
+    // reference's phase-shifted sine (the cosine) for odd q; q = 30 -> x0 | x2; q = 31 -> x1 | -   (fused.py _d0_kmap)
+    Split b8[8];
+    {
+        float f[32];
+        #pragma unroll
+        for (int q = 0; q < 30; q++) {
+            const int pr = q >> 1;
+            const float xa = h ? x[(15 + pr) % 3] : x[pr % 3];
+            const int fa = pr / 3, fb = 5 + pr / 3;
+            const float arg = h ? scalbnf(xa, fb) : scalbnf(xa, fa);
+            f[q] = sinf(arg + (float)(q & 1) * (3.141592653589793f / 2));
+        }
+        f[30] = h ? x[2] : x[0];
+        f[31] = h ? 0.0f : x[1];
+        #pragma unroll
+        for (int sk = 0; sk < 4; sk++) {
+            float xs[8];
+            #pragma unroll
+            for (int j = 0; j < 8; j++) xs[j] = f[8 * sk + j];
+            b8[sk] = split8(xs, kXS);
+        }
+    }
+    float16_t acc[4];
+    commit(pre, c_d0);
+    pre = prefetch(P.weights + kD1, c_stage);
+    #pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+        #pragma unroll
+        for (int v = 0; v < 16; v++) acc[mt][v] = s_bias[fr * 128u + mt * 32 + (v >> 2) * 8 + h * 4 + (v & 3)] * (kXS * kWS);
+    {
+        Split b4[4];
+        #pragma unroll
+        for (int sk = 0; sk < 4; sk++) b4[sk] = b8[sk];
+        layer<4, 4>(s_w, b4, acc, lane);
+    }
+    #pragma unroll 1
+    for (int l = 0; l < 6; l++) {
+        operands_from<4, true>(acc, b8);
+        commit(pre, c_stage);                                                     // D(l+1), fetched under the previous layer
+        pre = prefetch(P.weights + kD1 + (size_t)(l + 1) * kStageFloats, c_stage);      // D(l+2); after D6 the tail stage (kTail follows D6)
+        #pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+            #pragma unroll
+            for (int v = 0; v < 16; v++) acc[mt][v] = 0.0f;
+        layer<8, 4>(s_w, b8, acc, lane);
+    }
+    operands_from<4, true>(acc, b8);
+    commit(pre, c_stage);
+    float16_t a1[1];
+    #pragma unroll
+    for (int v = 0; v < 16; v++) a1[0][v] = 0.0f;
+    layer<8, 1>(s_w + kT_D7, b8, a1, lane);
+    // rows 0..2 of the output live in registers 0..2 of the lower lane half; the upper half evaluates the same point
+    if (P.deform && valid && h == 0) {      // dnerf/network.py:139-141: `deform = zeros` on the canonical frame
+        #pragma unroll
+        for (int k = 0; k < 3; k++) P.deform[(size_t)slot * 3 + k] = canonical ? 0.0f : a1[0][k] * kAccToOut;
+    }
+    #pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float dk = __shfl(a1[0][k], (int)n, 64) * kAccToOut;
+        if (!canonical) x[k] = x[k] + dk;
+    }
+
+    // ---- sigma network: grid(x') -> 64 -> 16.  Lane half h owns levels 8 h .. 8 h + 7, both channels (fused.py _s0_kmap:
+    //      k position (s, h, j) = level 8 h + 4 s + (j >> 1), channel j & 1) ----
+    Split b2[2];
+    {
+        float in[3];
+        bool oob = false;
+        #pragma unroll
+        for (int k = 0; k < 3; k++) {
+            in[k] = (x[k] + P.bound) / (2 * P.bound);            // grid.py:149
+            if (in[k] < 0 || in[k] > 1) oob = true;
+        }
+        #pragma unroll
+        for (int sk = 0; sk < 2; sk++) {
+            float g[8];
+            #pragma unroll
+            for (int lv = 0; lv < 4; lv++) {
+                const uint32_t level = 8u * h + 4u * sk + lv;
+                const float *grid = P.table + (size_t)lp.offset[level] * 2;
+                const uint32_t hashmap_size = lp.hashmap_size[level], resolution = lp.resolution[level];
+                const float scale = lp.scale[level];
+                float pos[3];
+                uint32_t pg[3];
+                #pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    pos[k] = in[k] * scale + 0.5f;
+                    pg[k] = (uint32_t)floorf(pos[k]);
+                    pos[k] -= (float)pg[k];
+                }
+                float r0 = 0, r1 = 0;
+                if (!oob) {
+                    float2 vals[8];
+                    float ws[8];
+                    #pragma unroll
+                    for (uint32_t idx = 0; idx < 8; idx++) {
+                        float w = 1;
+                        uint32_t pgl[3];
+                        #pragma unroll
+                        for (uint32_t k = 0; k < 3; k++) {
+                            w *= (idx & (1u << k)) ? pos[k] : 1 - pos[k];
+                            pgl[k] = pg[k] + ((idx >> k) & 1u);
+                        }
+                        ws[idx] = w;
+                        vals[idx] = *reinterpret_cast<const float2 *>(grid + sdn_grid::grid_index<3, 2>(1u, false, hashmap_size, resolution, pgl));
+                    }
+                    #pragma unroll
+                    for (uint32_t idx = 0; idx < 8; idx++) { r0 = r0 + ws[idx] * vals[idx].x; r1 = r1 + ws[idx] * vals[idx].y; }
+                }
+                g[2 * lv] = r0; g[2 * lv + 1] = r1;
+            }
+            b2[sk] = split8(g, kXS);
+        }
+    }
+    float16_t a2[2];
+    #pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+        #pragma unroll
+        for (int v = 0; v < 16; v++) a2[mt][v] = 0.0f;
+    layer<2, 2>(s_w + kT_S0, b2, a2, lane);
+    Split b4[4];
+    operands_from<2, true>(a2, b4);
+    #pragma unroll
+    for (int v = 0; v < 16; v++) a1[0][v] = 0.0f;
+    layer<4, 1>(s_w + kT_S1, b4, a1, lane);
+    const float sigma = expf(a1[0][0] * kAccToOut) * P.density_scale;     // row 0 (lower half); trunc_exp's forward is exp
+
+    // ---- colour network: k-step 0 = the sigma net's 16 outputs in accumulator order (raw; the density logit's column is zero),
+    //      k-step 1 = SH coefficient 8 h + j (fused.py _c0_kmap) -> 64 -> 64 -> 3 ----
+    {
+        float xs[8], sh[16], *nul = nullptr;
+        #pragma unroll
+        for (int j = 0; j < 8; j++) xs[j] = a1[0][j];
+        b2[0] = split8(xs, kAccToX);
+        sdn_sh::sh_eval<4, false>(d[0], d[1], d[2], sh, nul, nul, nul);
+        #pragma unroll
+        for (int j = 0; j < 8; j++) xs[j] = h ? sh[8 + j] : sh[j];
+        b2[1] = split8(xs, kXS);
+    }
+    #pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+        #pragma unroll
+        for (int v = 0; v < 16; v++) a2[mt][v] = 0.0f;
+    layer<2, 2>(s_w + kT_C0, b2, a2, lane);
+    operands_from<2, true>(a2, b4);
+    #pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+        #pragma unroll
+        for (int v = 0; v < 16; v++) a2[mt][v] = 0.0f;
+    layer<4, 2>(s_w + kT_C1, b4, a2, lane);
+    operands_from<2, true>(a2, b4);
+    #pragma unroll
+    for (int v = 0; v < 16; v++) a1[0][v] = 0.0f;
+    layer<4, 1>(s_w + kT_C2, b4, a1, lane);
+    if (valid && h == 0) {
+        P.sigmas[slot] = sigma;
+        #pragma unroll
+        for (int k = 0; k < 3; k++) P.rgbs[(size_t)slot * 3 + k] = 1.0f / (1.0f + expf(-a1[0][k] * kAccToOut));
+    }
+}
+
+}  // namespace
+
+namespace sdn_int {
+int field_forward_f32x3(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count, const int32_t *state,
+                      uint32_t M, const float *weights, const float *bias0, const float *table, const int32_t *offsets_host, float S,
+                      uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, float *deform,
+                      const uint8_t *slot_frame, uint32_t n_frames, hipStream_t st) {
+    LevelParams lp;
+    int rc = sdn_grid::fill_levels(lp, offsets_host, 16u, S, H);
+    if (rc) return rc;
+    F32Args a;
+    a.xyzs = xyzs; a.dirs = dirs; a.live_idx = live_idx; a.live_count = live_count; a.state = state; a.M = M;
+    a.weights = weights; a.bias0 = bias0; a.table = table; a.sigmas = sigmas; a.rgbs = rgbs; a.deform = deform;
+    a.bound = bound; a.density_scale = density_scale; a.zero_deform = zero_deform;
+    a.slot_frame = slot_frame; a.n_frames = slot_frame ? (n_frames > (uint32_t)kMaxFrames ? (uint32_t)kMaxFrames : (n_frames ? n_frames : 1u)) : 1u;
+    hipLaunchKernelGGL(k_field_f32x3, dim3(sdn_div_up(M, (uint32_t)kPointsPerWG)), dim3(64 * kWaves), 0, st, a, lp);
+    return sdn_launch_status();
+}
+}  // namespace sdn_int
+
+extern "C" {
+
+
+int sdn_field_forward_f32x3(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count, uint32_t M,
+                          const float *weights, const float *bias0, const float *table, const int32_t *offsets_host, float S, uint32_t H,
+                          float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, float *deform, void *stream) {
+    if (M == 0) return 0;
+    if (!xyzs || !dirs || !weights || !bias0 || !table || !offsets_host || !sigmas || !rgbs) return SDN_E_BADARG;
+    if ((live_idx == nullptr) != (live_count == nullptr)) return SDN_E_BADARG;
+    if (((uintptr_t)weights & 15u) != 0 || ((uintptr_t)table & 3u) != 0) return SDN_E_BADARG;
+    return sdn_int::field_forward_f32x3(xyzs, dirs, live_idx, live_count, nullptr, M, weights, bias0, table, offsets_host, S, H, bound,
+                                      density_scale, zero_deform ? 1 : 0, sigmas, rgbs, deform, nullptr, 1u, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -86,6 +86,11 @@ static int seal_color(const SdnRenderCtx *c, uint32_t m_slots, hipStream_t st) {
 
 // the fused field network on this iteration's samples (live list, count on the device): the `-O` kernel, or the fp32 one (ctx->field_f32)
 static int launch_field(const SdnRenderCtx *c, uint32_t m_bound, uint32_t expect_points, hipStream_t st) {
+    if (c->field_f32 == 2)
+        return sdn_int::field_forward_f32x3(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, m_bound,
+                                            (const float *)c->field_weights, c->field_bias0, (const float *)c->grid_table, c->grid_offsets, c->grid_S,
+                                            c->grid_H, c->bound, c->density_scale, c->zero_deform, c->sigmas, c->rgbs, nullptr,
+                                            c->n_group_frames > 1 ? c->slot_frame : nullptr, c->n_group_frames > 1 ? c->n_group_frames : 1u, st);
     if (c->field_f32)
         return sdn_int::field_forward_f32(c->xyzs, c->dirs, c->live_idx, (const uint32_t *)c->live_counts, c->state, m_bound,
                                           (const float *)c->field_weights, c->field_bias0, (const float *)c->grid_table, c->grid_offsets, c->grid_S,

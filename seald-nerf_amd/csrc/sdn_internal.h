@@ -57,6 +57,11 @@ int field_forward_f32(const float *xyzs, const float *dirs, const uint32_t *live
                       uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, float *deform,
                       const uint8_t *slot_frame, uint32_t n_frames, hipStream_t st);   // zero_deform: bit f = frame f is canonical
 
+int field_forward_f32x3(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count, const int32_t *state,
+                        uint32_t M, const float *weights, const float *bias0, const float *table, const int32_t *offsets_host, float S,
+                        uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, float *deform,
+                        const uint8_t *slot_frame, uint32_t n_frames, hipStream_t st);
+
 int field_cells_f16(const int32_t *cells, const uint32_t *cell_count, uint32_t n, const float *noise, uint32_t seed, uint32_t grid_size,
                     float cas_bound, const void *weights, const float *bias0, const void *table, const int32_t *offsets_host, float S,
                     uint32_t H, float bound, float density_scale, int zero_deform, float *tmp_slice, hipStream_t st);

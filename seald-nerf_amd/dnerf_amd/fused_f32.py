@@ -73,11 +73,49 @@ def pack_weights_f32(model):
     return flat
 
 
+def pack_weights_f32_split(model):
+    """The same weights for csrc/field_f32x3.hip: every fp32 weight as hi + lo (two fp16 values), in the fp16 kernel's operand order
+    (fused.py kmaps), per layer [k-step][lane][m-tile][hi | lo][8 halves]; flat uint16, stage order D0 | D1..D6 | D7 S0 S1 C0 C1 C2."""
+    from . import fused as F16
+    g = lambda lin: lin.weight.detach().float().cpu().numpy()   # noqa: E731
+    dn, sn, cn = model.deform_net, model.sigma_net, model.color_net
+    hidden128 = [F16._acc_kmap(t, s) for t in range(4) for s in range(2)]
+    hidden64 = [F16._acc_kmap(t, s) for t in range(2) for s in range(2)]
+
+    def layer(W, n_mt, kmaps):
+        W = np.asarray(W, dtype=np.float32) * np.float32(256.0)     # kWS of the kernel: keeps the lo parts out of the fp16 subnormals the MFMA flushes
+        hi = W.astype(np.float16)
+        lo = (W - hi.astype(np.float32)).astype(np.float16)
+        out = []
+        for part in (hi, lo):      # _pack_layer rounds its input to fp16: exact for both parts
+            blk = F16._pack_layer(part.astype(np.float32), n_mt, kmaps).reshape(n_mt, len(kmaps), 64, 8)
+            out.append(blk.transpose(1, 2, 0, 3))                       # [ks, lane, mt, 8]
+        return np.ascontiguousarray(np.stack(out, axis=3)).reshape(-1)   # [ks, lane, mt, 2, 8]
+
+    parts = [layer(g(dn[0])[:, :63], 4, [F16._d0_kmap(s) for s in range(4)])]
+    parts += [layer(g(dn[l]), 4, hidden128) for l in range(1, 7)]
+    parts.append(layer(g(dn[7]), 1, hidden128))
+    parts.append(layer(g(sn[0]), 2, [F16._s0_kmap(s) for s in range(2)]))
+    parts.append(layer(g(sn[1]), 1, hidden64))
+    parts.append(layer(g(cn[0]), 2, [F16._c0_kmap(s) for s in range(2)]))
+    parts.append(layer(g(cn[1]), 2, hidden64))
+    parts.append(layer(g(cn[2]), 1, hidden64))
+    flat = np.concatenate(parts).view(np.uint16)
+    assert flat.shape[0] * 2 == 4 * int(sdn_backend.lib.sdn_field_weight_floats_f32()), flat.shape
+    return flat
+
+
 class FusedFieldF32:
     """Callable (xyzs [M,3], dirs [M,3]) -> (sigmas [M] f32, rgbs [M,3] f32): the fp32 network (dnerf/network.py:123-169 without
     autocast) in one launch.  Same interface as `fused.FusedField` (time constants per value, live lists)."""
 
-    def __init__(self, model, time, max_points=None):
+    def __init__(self, model, time, max_points=None, variant=None):
+        """variant: "mfma32" (default; csrc/field_f32.hip: v_mfma_f32_32x32x2_f32, 1e-4 from the fp32 network) or "split"
+        (csrc/field_f32x3.hip: fp32 operands as hi + lo fp16 pairs on the fp16 MFMAs -- 22-bit operands: worst element 1.3e-4, faster);
+        SDN_FIELD_F32 in the environment overrides the default."""
+        import os
+        self.variant = variant or os.environ.get("SDN_FIELD_F32", "mfma32")
+        assert self.variant in ("split", "mfma32"), self.variant
         if not available():
             raise sdn_backend.SdnError("libsdn_hip was built without the fp32 fused field kernel")
         enc = model.encoder
@@ -87,7 +125,7 @@ class FusedFieldF32:
             raise sdn_backend.SdnError("the fp32 fused field reads the model's fp32 embedding table in place")
         dev = enc.embeddings.device
         self.model = model
-        self.weights = torch.from_numpy(pack_weights_f32(model)).to(dev).contiguous()
+        self.weights = self._packed().to(dev).contiguous()
         self.table = enc.embeddings.detach()
         self.offsets_host = np.ascontiguousarray(enc.offsets.cpu().numpy().astype(np.int32))
         self.S = float(np.log2(enc.per_level_scale))
@@ -99,6 +137,11 @@ class FusedFieldF32:
         self._buf = None
         if max_points:
             self._alloc(max_points)
+
+    def _packed(self):
+        if self.variant == "split":
+            return torch.from_numpy(pack_weights_f32_split(self.model).view(np.int16))
+        return torch.from_numpy(pack_weights_f32(self.model))
 
     @staticmethod
     def time_value(time):
@@ -142,7 +185,7 @@ class FusedFieldF32:
 
     def refresh(self):
         """Re-pack after the weights changed (the table is read in place)."""
-        self.weights.copy_(torch.from_numpy(pack_weights_f32(self.model)))
+        self.weights.copy_(self._packed())
         self.table = self.model.encoder.embeddings.detach()
         self._time_cache.clear()
         self._group_cache.clear()
@@ -158,7 +201,8 @@ class FusedFieldF32:
             self._alloc(M)
         sigmas, rgbs = self._buf[0][:M], self._buf[1][:M]
         with sdn_backend.timed("field_forward_f32", M):
-            check(sdn_backend.lib.sdn_field_forward_f32(ptr(xyzs, torch.float32, "xyzs"), ptr(dirs, torch.float32, "dirs"),
+            entry = sdn_backend.lib.sdn_field_forward_f32x3 if self.variant == "split" else sdn_backend.lib.sdn_field_forward_f32
+            check(entry(ptr(xyzs, torch.float32, "xyzs"), ptr(dirs, torch.float32, "dirs"),
                                                         ptr(live_idx), ptr(live_count), M, ptr(self.weights), ptr(self.bias0),
                                                         ptr(self.table, torch.float32, "embeddings"), self.offsets_host.ctypes.data,
                                                         self.S, self.H, self.bound, self.density_scale, self.zero_deform, ptr(sigmas),

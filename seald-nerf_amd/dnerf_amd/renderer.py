@@ -520,7 +520,7 @@ class DeviceLoop:
         c.n_group_frames, c.rays_per_frame = (self.frames, N // self.frames) if self.frames > 1 else (0, 0)
         # the fp32 fused field (dnerf_amd.fused_f32.FusedFieldF32: the reference without -O) in the same loop: its packed floats, the
         # model's fp32 table in place, the reference's offsets
-        c.field_f32 = 1 if type(field).__name__ == "FusedFieldF32" else 0
+        c.field_f32 = (2 if getattr(field, "variant", "") == "split" else 1) if type(field).__name__ == "FusedFieldF32" else 0
         self.ctx = c
         self.max_steps = int(max_steps)
         self.set_mapper(mapper)

@@ -21,7 +21,8 @@ out = {}
 for n in (65536, 262144, 1048576):
     x = torch.from_numpy(_probe_points(sc.bitfield, n, 3)).cuda()
     d = torch.nn.functional.normalize(torch.randn(n, 3, device="cuda"), dim=1).contiguous()
-    f32, f16 = FusedFieldF32(model, sc.time, max_points=n), fused.FusedField(model, sc.time, max_points=n)
+    f32, f16 = FusedFieldF32(model, sc.time, max_points=n, variant="mfma32"), fused.FusedField(model, sc.time, max_points=n)
+    f32s = FusedFieldF32(model, sc.time, max_points=n, variant="split")
 
     def ops():
         model.fused_inference = False
@@ -29,7 +30,7 @@ for n in (65536, 262144, 1048576):
             return model(x, d, sc.time)
 
     row = {}
-    for name, fn, reps in (("fused_f32", lambda: f32(x, d), 20), ("fused_f16", lambda: f16(x, d), 50), ("op_by_op_f32", ops, 5)):
+    for name, fn, reps in (("fused_f32_split", lambda: f32s(x, d), 30), ("fused_f32", lambda: f32(x, d), 20), ("fused_f16", lambda: f16(x, d), 50), ("op_by_op_f32", ops, 5)):
         for _ in range(3):
             fn()
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -40,7 +41,8 @@ for n in (65536, 262144, 1048576):
     out[str(n)] = row
     print(n, json.dumps(row), flush=True)
 frames = {}
-for name, kw in (("fused_f32", dict(fp16=False, field=FusedFieldF32(model, sc.time))), ("op_by_op_f32", dict(fp16=False)),
+for name, kw in (("fused_f32_split", dict(fp16=False, field=FusedFieldF32(model, sc.time, variant="split"))),
+                 ("fused_f32", dict(fp16=False, field=FusedFieldF32(model, sc.time, variant="mfma32"))), ("op_by_op_f32", dict(fp16=False)),
                  ("fused_f16", dict(fp16=True, field=fused.FusedField(model, sc.time)))):
     for _ in range(2):
         render_frame(model, sc.rays_o, sc.rays_d, sc.time, **kw)
