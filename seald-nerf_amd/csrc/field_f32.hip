@@ -64,6 +64,13 @@ struct F32Args {
     uint32_t n_frames;
 };
 
+// ReLU in ONE instruction: as signed integers, negative floats are negative and non-negative floats keep their order, so max(bits, 0)
+// is max(x, 0) (fmaxf compiles to a canonicalising v_max_f32 x, x in front of the real one; -0.0 and negative NaNs become +0.0)
+__device__ __forceinline__ float relu1(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
 // one layer: PAIRS k-pairs of B operands (registers) against the staged A operands, MT output tiles of 32 rows
 template <int PAIRS, int MT>
 __device__ __forceinline__ void layer(const float *s_w, const float (&b)[PAIRS], float16_t (&acc)[MT], uint32_t lane) {
@@ -84,7 +91,7 @@ __device__ __forceinline__ void relu_into(const float16_t (&acc)[MT], float (&b)
     #pragma unroll
     for (int mt = 0; mt < MT; mt++)
         #pragma unroll
-        for (int v = 0; v < 16; v++) b[mt * 16 + v] = fmaxf(acc[mt][v], 0.0f);
+        for (int v = 0; v < 16; v++) b[mt * 16 + v] = relu1(acc[mt][v]);
 }
 
 __global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) k_field_f32(F32Args P, LevelParams lp) {

@@ -63,13 +63,21 @@ struct F32Args {
     uint32_t n_frames;
 };
 
+// ReLU in ONE instruction: as signed integers, negative floats are negative and non-negative floats keep their order, so max(bits, 0)
+// is max(x, 0) (fmaxf compiles to a canonicalising v_max_f32 x, x in front of the real one; -0.0 and negative NaNs become +0.0)
+__device__ __forceinline__ float relu1(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
 __device__ __forceinline__ Split split8(const float (&x)[8], float scale) {      // x * scale = hi + lo
     Split r;
     #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const float v = x[j] * scale;
-        r.hi[j] = (_Float16)v;
-        r.lo[j] = (_Float16)(v - (float)r.hi[j]);
+        r.hi[j] = (_Float16)(x[j] * scale);
+        // (one fused multiply-add that reads the fp16 operand in place -- v_fma_mix_f32 -- instead of convert-back, multiply, subtract;
+        //  the scaling is by a power of two, so the product is exact either way)
+        r.lo[j] = (_Float16)__builtin_fmaf(x[j], scale, -(float)r.hi[j]);
     }
     return r;
 }
@@ -110,7 +118,7 @@ __device__ __forceinline__ void operands_from(const float16_t (&acc)[MT], Split 
         for (int sh = 0; sh < 2; sh++) {
             float x[8];
             #pragma unroll
-            for (int j = 0; j < 8; j++) x[j] = RELU ? fmaxf(acc[t][8 * sh + j], 0.0f) : acc[t][8 * sh + j];
+            for (int j = 0; j < 8; j++) x[j] = RELU ? relu1(acc[t][8 * sh + j]) : acc[t][8 * sh + j];
             b[2 * t + sh] = split8(x, kAccToX);       // accumulators hold kXS kWS y: the next operand is kXS y
         }
 }
