@@ -252,7 +252,9 @@ class NativeTrainStep:
         """The time stamp as a host float.  A host number costs nothing; a DEVICE tensor (what the reference's loader hands over,
         dnerf/provider.py) costs a blocking read-back, so its value is cached per tensor OBJECT and in-place version (the cache keeps
         the tensor alive: an address alone can be recycled by another tensor with another value): a loader that reuses its time
-        tensor, or passes a float, keeps the step free of host synchronisation."""
+        tensor, or passes a float, keeps the step free of host synchronisation.  The version counter only sees writes made through
+        torch: a time tensor changed behind torch's back (a raw pointer, DLPack, a custom kernel) must be handed over as a NEW tensor or
+        as a float, or the step trains at the stale time stamp."""
         if not isinstance(time, torch.Tensor):
             return float(np.float32(float(time)))
         if time.device.type != "cuda":
