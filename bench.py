@@ -787,6 +787,10 @@ def main():
             # the reference's own caller, unchanged, over the drop-in operators: model.render -> run_cuda's loop (dnerf/renderer.py:350-376),
             # eval + no_grad + fp16 autocast, NeRFNetwork.forward dispatching each iteration's field evaluation to the fused kernel
             result["reference_shaped"] = reference_shaped(sc, cam_o, cam_d, cam_t)
+        elif world == 1 and dloop is not None and not fp16 and args.emulate_rank_of <= 1:
+            # --fp32: one frame alone and the reference's caller (no autocast; forward dispatching to the fp32 fused kernel)
+            result["latency_ms_one_frame"] = one_frame_latency(sc, field, cam_o, cam_d, cam_t, dev)
+            result["reference_shaped"] = reference_shaped(sc, cam_o, cam_d, cam_t, fp32=True)
         if world > 1:
             result["ranks"] = all_rank_stats
         if world == 1 and not args.no_cpu_baseline:
@@ -814,7 +818,7 @@ def one_frame_latency(sc, field, cam_o, cam_d, cam_t, dev, frames=8):
     return sorted(lat)[len(lat) // 2]
 
 
-def reference_shaped(sc, cam_o, cam_d, cam_t, frames=4):
+def reference_shaped(sc, cam_o, cam_d, cam_t, frames=4, fp32=False):
     """ms per frame of `model.render` (the mirror of the reference's NeRFRenderer.render -> run_cuda, control flow unchanged: march_rays,
     self(xyzs, dirs, time), composite_rays, boolean-mask compaction with its host read-back every iteration) in the reference's `-O`
     inference mode: eval, no_grad, fp16 autocast."""
@@ -824,8 +828,10 @@ def reference_shaped(sc, cam_o, cam_d, cam_t, frames=4):
 
     def frame(i):
         t = torch.tensor([[cam_t[i]]], dtype=torch.float32, device=dev)
-        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=not fp32):
             return model.render(cam_o[i][None], cam_d[i][None], t, staged=False, perturb=False, bg_color=1, max_steps=1024)
+    if fp32:      # the reference without -O: NeRFNetwork.forward dispatches to the fp32 fused kernel when asked to (network.py)
+        model.fused_inference_f32 = True
     for i in range(k):
         frame(i)
     torch.cuda.synchronize()
@@ -834,8 +840,11 @@ def reference_shaped(sc, cam_o, cam_d, cam_t, frames=4):
         frame(i)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / k
+    if fp32:
+        model.fused_inference_f32 = False
     return {"ms_per_frame": ms, "rays_per_s": cam_o[0].shape[0] / ms * 1e3, "frames": k,
-            "path": "dnerf_amd.NeRFNetwork.render -> run_cuda (reference control flow) on the drop-in operators; field = fused dispatch of NeRFNetwork.forward (sdn_field_forward_f16)"}
+            "path": "dnerf_amd.NeRFNetwork.render -> run_cuda (reference control flow) on the drop-in operators; field = fused dispatch of NeRFNetwork.forward ("
+                    + ("sdn_field_forward_f32, model.fused_inference_f32 = True" if fp32 else "sdn_field_forward_f16") + ")"}
 
 
 MARCH_BYTES_PER_SAMPLE = 33.0       # 32 B written per emitted sample (xyz, dir, 2 deltas) + ~1 B of occupancy bits per probe
