@@ -18,58 +18,16 @@
 //
 // Bound: 1 920 MFMAs of 64 cycles per 32 points = 123 K matrix-pipe cycles per wave-tile (fp32 MFMA peak 157 TFLOP/s dense on MI355X);
 // 235 520 FLOP per point as in the fp16 kernel.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <type_traits>
-
-#include "grid_common.h"
-#include "sdn_common.h"
-#include "sdn_internal.h"
-#include "sh_eval.h"
+#include "field_f32_common.h"
 
 namespace {
 
-using sdn_grid::LevelParams;
-typedef float float16_t __attribute__((ext_vector_type(16)));
+using namespace sdn_f32;
 
-#ifndef SDN_F32_WAVES
-#define SDN_F32_WAVES 4
-#endif
-constexpr int kWaves = SDN_F32_WAVES;          // waves per workgroup (8: one workgroup per CU; 4: two, out of step with each other)
-constexpr int kPieces = 16384 / (64 * kWaves * 4);   // 16-byte pieces per thread of a 64-KiB stage
-constexpr int kPointsPerWG = 32 * kWaves;
-constexpr int kStageFloats = 16384;   // 64 KiB: one 128 x 128 layer
-constexpr int kMaxFrames = 16;        // frames of a frame group (SDN_MAX_GROUP_FRAMES)
-
-// packed weights (floats), in stage order: D0 | D1 .. D6 | tail = D7 S0 S1 C0 C1 C2   (dnerf_amd/fused_f32.py: pack_weights_f32)
-constexpr int kD0 = 0, kD0Floats = 32 * 64 * 4;                  // 32 pairs x 4 m-tiles
-constexpr int kD1 = kD0 + kD0Floats;                             // six stages of 64 pairs x 4 m-tiles
-constexpr int kTail = kD1 + 6 * kStageFloats;
+// offsets inside the tail stage (floats): [pair][lane][m-tile] blocks   (dnerf_amd/fused_f32.py: pack_weights_f32)
 constexpr int kT_D7 = 0, kT_S0 = kT_D7 + 64 * 64, kT_S1 = kT_S0 + 16 * 64 * 2, kT_C0 = kT_S1 + 32 * 64, kT_C1 = kT_C0 + 16 * 64 * 2,
-              kT_C2 = kT_C1 + 32 * 64 * 2, kTailFloats = kT_C2 + 32 * 64;
-static_assert(kTailFloats == kStageFloats, "the tail stage is one LDS buffer");
-static_assert(kTail == kD1 + 6 * kStageFloats, "the tail stage follows D6: the hidden-layer loop prefetches it as 'D7'");
-constexpr int kTotalFloats = kTail + kTailFloats;
-
-struct F32Args {
-    const float *xyzs, *dirs;
-    const uint32_t *live_idx, *live_count;
-    const int32_t *state;
-    uint32_t M;
-    const float *weights, *bias0, *table;
-    float *sigmas, *rgbs, *deform;      // deform: optional [M,3], the deformation network's output (zeros on the canonical frame)
-    float bound, density_scale;
-    int zero_deform;              // bit f: frame f is the canonical frame (no deformation)
-    const uint8_t *slot_frame;    // frame group: frame of every sample slot (bias0 then holds n_frames rows), or nullptr = one frame
-    uint32_t n_frames;
-};
-
-// ReLU in ONE instruction: as signed integers, negative floats are negative and non-negative floats keep their order, so max(bits, 0)
-// is max(x, 0) (fmaxf compiles to a canonicalising v_max_f32 x, x in front of the real one; -0.0 and negative NaNs become +0.0)
-__device__ __forceinline__ float relu1(float x) {
-    const int b = __builtin_bit_cast(int, x);
-    return __builtin_bit_cast(float, b > 0 ? b : 0);
-}
+              kT_C2 = kT_C1 + 32 * 64 * 2;
+static_assert(kT_C2 + 32 * 64 == kTailFloats && 32 * 64 * 4 == kD0Floats, "stage sizes");
 
 // one layer: PAIRS k-pairs of B operands (registers) against the staged A operands, MT output tiles of 32 rows
 template <int PAIRS, int MT>
@@ -97,57 +55,13 @@ __device__ __forceinline__ void relu_into(const float16_t (&acc)[MT], float (&b)
 __global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) k_field_f32(F32Args P, LevelParams lp) {
     __shared__ __attribute__((aligned(16))) float s_w[kStageFloats];
     __shared__ float s_bias[kMaxFrames * 128];      // the frames' time-encoding bias rows (D0's initial accumulators)
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t h = lane >> 5, n = lane & 31u;
-    const uint32_t count = P.state ? P.live_count[P.state[3]] : (P.live_idx ? *P.live_count : P.M);
-    if (blockIdx.x * (uint32_t)kPointsPerWG >= count) return;            // workgroup-uniform, before any barrier
-    const uint32_t i = blockIdx.x * (uint32_t)kPointsPerWG + wave * 32u + n;
-    const bool valid = i < count;
-    const uint32_t slot = valid ? (P.live_idx ? P.live_idx[i] : i) : 0u;
-    float x[3] = {0, 0, 0}, d[3] = {0, 0, 1};
-    if (valid) {
-        x[0] = P.xyzs[(size_t)slot * 3]; x[1] = P.xyzs[(size_t)slot * 3 + 1]; x[2] = P.xyzs[(size_t)slot * 3 + 2];
-        d[0] = P.dirs[(size_t)slot * 3]; d[1] = P.dirs[(size_t)slot * 3 + 1]; d[2] = P.dirs[(size_t)slot * 3 + 2];
-    }
-    // Weight stages: the NEXT stage's 16-byte pieces are fetched into registers before a layer's MFMAs start (8 per thread for 64 KiB) and
-    // written to LDS when every wave is through with the current stage -- the global latency runs under the layer instead of in front of it
-    struct Pre { float4 v[kPieces]; };
-    // (stage sizes are multiples of one piece per thread, 2 048 floats: the guard is a compile-time one -- a lane-dependent guard made
-    //  every piece a predicated merge that waited for its load on the spot)
-    auto prefetch = [&](const float *src, auto floats_c) -> Pre {
-        constexpr int floats = decltype(floats_c)::value;
-        static_assert(floats % (64 * kWaves * 4) == 0, "whole pieces");
-        Pre r;
-        #pragma unroll
-        for (int q = 0; q < kPieces; q++)
-            r.v[q] = (q * 64 * kWaves * 4 < floats) ? *reinterpret_cast<const float4 *>(src + (q * 64 * kWaves + (int)threadIdx.x) * 4)
-                                                    : make_float4(0, 0, 0, 0);
-        // (left alone the scheduler sinks these loads to the end of the layer, where nothing hides them)
-        __builtin_amdgcn_sched_barrier(0);
-        return r;
-    };
-    // (a bare s_barrier behind the wave's own LDS traffic: __syncthreads() carries a fence that drains the global loads in flight --
-    //  exactly the prefetch -- at the first barrier after they were issued; measured 104 -> 93 TFLOP/s with it)
-    auto wg_barrier = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto commit = [&](const Pre &r, auto floats_c) {
-        constexpr int floats = decltype(floats_c)::value;
-        wg_barrier();                                      // every wave has finished reading the previous stage
-        #pragma unroll
-        for (int q = 0; q < kPieces; q++)
-            if (q * 64 * kWaves * 4 < floats) *reinterpret_cast<float4 *>(s_w + (q * 64 * kWaves + (int)threadIdx.x) * 4) = r.v[q];
-        wg_barrier();
-    };
-    constexpr std::integral_constant<int, kD0Floats> c_d0{};
-    constexpr std::integral_constant<int, kStageFloats> c_stage{};
-    Pre pre = prefetch(P.weights + kD0, c_d0);
+    Point pt;
+    if (!load_point(P, pt)) return;                                  // workgroup-uniform, before any barrier
+    const uint32_t lane = pt.lane, h = pt.h, n = pt.n, slot = pt.slot, fr = pt.fr;
+    const bool valid = pt.valid, canonical = pt.canonical;
+    float x[3] = {pt.x[0], pt.x[1], pt.x[2]}, d[3] = {pt.d[0], pt.d[1], pt.d[2]};
+    Pre pre = stage_prefetch<kD0Floats>(P.weights + kD0);            // (see field_f32_common.h: the next stage travels under the layer)
     for (uint32_t k = threadIdx.x; k < P.n_frames * 128u; k += 64 * kWaves) s_bias[k] = P.bias0[k];
-    const uint32_t fr = (P.slot_frame && valid) ? (uint32_t)P.slot_frame[slot] : 0u;      // (< n_frames: written by the marcher)
-    const bool canonical = (P.zero_deform >> fr) & 1;
 
     // ---- deformation network: freq(x, 10) (time part folded into bias0) -> 128 x 7 -> 3 ----
     float bin[64];
@@ -159,8 +73,8 @@ __global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) k_field_f32(F32Args P
         bin[31] = h ? 0.0f : x[2];
     }
     float16_t acc[4];
-    commit(pre, c_d0);
-    pre = prefetch(P.weights + kD1, c_stage);
+    stage_commit<kD0Floats>(s_w, pre);
+    pre = stage_prefetch<kStageFloats>(P.weights + kD1);
     #pragma unroll
     for (int mt = 0; mt < 4; mt++)
         #pragma unroll
@@ -174,8 +88,8 @@ __global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) k_field_f32(F32Args P
     #pragma unroll 1
     for (int l = 0; l < 6; l++) {
         relu_into<4>(acc, bin);
-        commit(pre, c_stage);                                                     // D(l+1), fetched under the previous layer
-        pre = prefetch(P.weights + kD1 + (size_t)(l + 1) * kStageFloats, c_stage);      // D(l+2); after D6 the tail stage (kTail follows D6)
+        stage_commit<kStageFloats>(s_w, pre);                                                     // D(l+1), fetched under the previous layer
+        pre = stage_prefetch<kStageFloats>(P.weights + kD1 + (size_t)(l + 1) * kStageFloats);      // D(l+2); after D6 the tail stage (kTail follows D6)
         #pragma unroll
         for (int mt = 0; mt < 4; mt++)
             #pragma unroll
@@ -183,7 +97,7 @@ __global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) k_field_f32(F32Args P
         layer<64, 4>(s_w, bin, acc, lane);
     }
     relu_into<4>(acc, bin);
-    commit(pre, c_stage);
+    stage_commit<kStageFloats>(s_w, pre);
     float16_t a1[1];
     #pragma unroll
     for (int v = 0; v < 16; v++) a1[0][v] = 0.0f;
@@ -292,25 +206,22 @@ __global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) k_field_f32(F32Args P
 
 namespace sdn_int {
 int field_forward_f32(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count, const int32_t *state,
-                      uint32_t M, const float *weights, const float *bias0, const float *table, const int32_t *offsets_host, float S,
-                      uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, float *deform,
-                      const uint8_t *slot_frame, uint32_t n_frames, hipStream_t st) {
-    LevelParams lp;
-    int rc = sdn_grid::fill_levels(lp, offsets_host, 16u, S, H);
+       uint32_t M, const float *weights, const float *bias0, const float *table, const int32_t *offsets_host, float S,
+       uint32_t H, float bound, float density_scale, int zero_deform, float *sigmas, float *rgbs, float *deform,
+       const uint8_t *slot_frame, uint32_t n_frames, hipStream_t st) {
+    sdn_f32::LevelParams lp;
+    sdn_f32::F32Args a;
+    int rc = sdn_f32::fill_args(a, lp, xyzs, dirs, live_idx, live_count, state, M, weights, bias0, table, offsets_host, S, H, bound, density_scale,
+                                zero_deform, sigmas, rgbs, deform, slot_frame, n_frames);
     if (rc) return rc;
-    F32Args a;
-    a.xyzs = xyzs; a.dirs = dirs; a.live_idx = live_idx; a.live_count = live_count; a.state = state; a.M = M;
-    a.weights = weights; a.bias0 = bias0; a.table = table; a.sigmas = sigmas; a.rgbs = rgbs; a.deform = deform;
-    a.bound = bound; a.density_scale = density_scale; a.zero_deform = zero_deform;
-    a.slot_frame = slot_frame; a.n_frames = slot_frame ? (n_frames > (uint32_t)kMaxFrames ? (uint32_t)kMaxFrames : (n_frames ? n_frames : 1u)) : 1u;
-    hipLaunchKernelGGL(k_field_f32, dim3(sdn_div_up(M, (uint32_t)kPointsPerWG)), dim3(64 * kWaves), 0, st, a, lp);
+    hipLaunchKernelGGL(k_field_f32, dim3(sdn_div_up(M, (uint32_t)sdn_f32::kPointsPerWG)), dim3(64 * sdn_f32::kWaves), 0, st, a, lp);
     return sdn_launch_status();
 }
 }  // namespace sdn_int
 
 extern "C" {
 
-uint32_t sdn_field_weight_floats_f32(void) { return (uint32_t)kTotalFloats; }
+uint32_t sdn_field_weight_floats_f32(void) { return (uint32_t)sdn_f32::kTotalFloats; }
 
 int sdn_field_forward_f32(const float *xyzs, const float *dirs, const uint32_t *live_idx, const uint32_t *live_count, uint32_t M,
                           const float *weights, const float *bias0, const float *table, const int32_t *offsets_host, float S, uint32_t H,
