@@ -15,6 +15,8 @@ Two evaluation paths:
     from the op-by-op path; `model.fused_inference = False` switches it off.  Without autocast (no `-O`) the same dispatch goes to
     the fp32 fused kernel (csrc/field_f32.hip, 1e-4 from the op-by-op fp32 network) when `model.fused_inference_f32 = True`.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -149,6 +151,29 @@ class NeRFNetwork(NeRFRenderer):
                 return False
         return mode
 
+    # the same under -O: off by default -- that loop is bound by host time per call, and the list's two allocations + fill cost what the
+    # skipped slots save (800x800: 2.28 ms per frame without, 2.33 with; fp32: 6.69 -> 5.26; profiles/r04_reference_shaped_live_lists.json)
+    fused_live_lists_f16 = os.environ.get("SDN_LIVE_LISTS_F16", "0") == "1"
+    fused_live_lists = True      # evaluate only the slots the marcher filled when `x` is the marcher's own output tensor (below)
+
+    def _live_of(self, x):
+        """(slot list, count, version) the drop-in `raymarching.march_rays` hung on ITS output tensor, or None.  The reference's caller
+        (dnerf/renderer.py:350-376) pads every ray to n_step slots and evaluates the padding too; composite_rays stops at a ray's first
+        empty slot, so what the network returns there is never read.  With the list the fused kernels skip those slots (their outputs
+        are zeros).  A tensor that is not the marcher's (or was written since: version counter) has no list and is evaluated whole."""
+        if not self.fused_live_lists:
+            return None
+        live = getattr(x, "_sdn_live", None)
+        if live is None:
+            import raymarching
+            ll = raymarching.live_lists
+            if not ll["pinned"]:
+                ll["on"] = True      # from the next march_rays call on
+            return None
+        if live[2] != x._version or not x.is_contiguous() or live[0].shape[0] > x.shape[0]:
+            return None
+        return live
+
     def _parameter_epoch(self):
         ps = self.__dict__.get("_fused_params")
         if ps is None:         # the Parameter OBJECTS (load_state_dict, .to(), optimizer steps keep them; their address / version move)
@@ -181,8 +206,17 @@ class NeRFNetwork(NeRFRenderer):
         if field.__dict__.get("_time_set") != value:
             field.set_time(value)
             field._time_set = value
+        live = self._live_of(x)
+        M = x.shape[0]
+        if live is not None:
+            flat = torch.zeros(7 * M, dtype=torch.float32, device=x.device)      # one fill for the three outputs' skipped slots
+            field._buf = (flat[:M], flat[M:4 * M].view(M, 3))
+            deform = flat[4 * M:].view(M, 3)
+            sig, rgb = field(x, d.contiguous(), live[0], live[1], deform=deform)
+            field._buf = None
+            return sig, rgb, deform
         field._buf = None
-        deform = torch.empty(x.shape[0], 3, dtype=torch.float32, device=x.device)
+        deform = torch.empty(M, 3, dtype=torch.float32, device=x.device)
         sig, rgb = field(x.contiguous(), d.contiguous(), deform=deform)
         return sig, rgb, deform
 
@@ -218,8 +252,16 @@ class NeRFNetwork(NeRFRenderer):
         if cache[1].__dict__.get("_time_set") != value:
             field.set_time(value)
             field._time_set = value
-        # (Evaluating only the slots that hold a sample -- a list built from the zero direction vectors of a marcher's empty slots --
-        #  was measured and dropped: the list kernel and the zero fills cost more than the skipped slots save, 2.73 -> 3.08 ms per frame.)
+        # (Evaluating only the slots that hold a sample from a list built HERE -- a kernel over the zero direction vectors of the empty
+        #  slots -- was measured and dropped, 2.73 -> 3.08 ms per frame; the list the marcher builds as it goes costs no pass.)
+        live = self._live_of(x) if self.fused_live_lists_f16 else None
+        if live is not None:
+            M = x.shape[0]
+            flat = torch.zeros(4 * M, dtype=torch.float32, device=x.device)
+            field._buf = (flat[:M], flat[M:].view(M, 3))
+            sig, rgb = field(x, d.contiguous(), live[0], live[1])
+            field._buf = None
+            return sig, rgb, None
         field._buf = None          # fresh output tensors per call (caching allocator, no launch): the caller owns them, as on the op-by-op path
         sig, rgb = field(x.contiguous(), d.contiguous())
         return sig, rgb, None

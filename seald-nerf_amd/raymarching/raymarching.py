@@ -234,6 +234,14 @@ def _to_f32(t):
     return t if t.dtype == _f32 else t.float()
 
 
+# Live-sample lists for the fused field networks behind the reference's caller: `march_rays` returns exactly the reference's three
+# tensors; with the switch on it also hangs (slot list, count, tensor version) on the xyzs tensor as `_sdn_live`.  The caller
+# (dnerf/renderer.py:350-376) hands that same tensor to `self(xyzs, dirs, time)`; a tensor that was modified, copied or mapped in
+# between (SealD's mapper) carries no list and is evaluated slot by slot as before.  Off by default: two small allocations and one
+# 4-byte fill per call; NeRFNetwork's fused dispatch switches it on when it is used (set "pinned" to keep a manual choice).
+live_lists = {"on": False, "pinned": False}
+
+
 class _march_rays(Function):
     """The reference wraps the inference marcher in an autograd Function only for `custom_fwd(cast_inputs=float32)`; it has no
     backward (raymarching.py:300-346).  Here `march_rays` / `composite_rays` are plain functions that do the same cast themselves:
@@ -262,6 +270,12 @@ def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, densi
     noises = torch.rand(n_alive, dtype=_f32, device=dev) if perturb else None
     cull = _cull_grid_of(density_bitfield, C, H)
     if cull is not None:
+        live_idx = live_count = None
+        if live_lists["on"] and M0 > 0:
+            # the marcher appends every slot that receives a sample to a list as it goes (wave-aggregated, no extra pass); a fused
+            # field network that is handed THIS xyzs tensor evaluates the listed slots only (dnerf_amd/network.py)
+            live_idx = torch.empty(M0, dtype=_i32, device=dev)
+            live_count = torch.zeros(1, dtype=_i32, device=dev)
         # the exact cull grid (sdn_build_cull_grid, kept per occupancy slice and tensor version): rays whose remaining segment stays
         # clear of every occupied voxel retire at once instead of probing hundreds of empty voxels -- the same samples, bit for bit
         # (tests/test_gpu_ops_parity.py), 122 -> ~25 us per call in the reference-shaped loop of an 800x800 frame; the kernel also
@@ -270,7 +284,9 @@ def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, densi
                                       _ptr(rays_o, _f32, "rays_o"), _ptr(rays_d, _f32, "rays_d"), float(bound), float(dt_gamma),
                                       int(max_steps), int(C), int(H), _ptr(density_bitfield, torch.uint8, "density_bitfield"),
                                       _ptr(far, _f32, "far"), _ptr(xyzs), _ptr(dirs), _ptr(deltas), _ptr(noises), int(M), _ptr(cull),
-                                      None, None, _stream()), "march_rays_ex")
+                                      _ptr(live_idx), _ptr(live_count), _stream()), "march_rays_ex")
+        if live_idx is not None:
+            xyzs._sdn_live = (live_idx, live_count, xyzs._version)
         return xyzs, dirs, deltas
     if M > M0:  # the kernel writes every slot below n_alive*n_step; only the tail needs clearing
         xyzs[M0:].zero_(); dirs[M0:].zero_(); deltas[M0:].zero_()
