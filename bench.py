@@ -345,7 +345,7 @@ def density_mode(args):
         m.load_state_dict(sc.model.state_dict())
         m.reset_extra_state()
         if native:
-            m.use_native_density_update()
+            m.use_native_density_update(fp32=args.fp32)
         return m
 
     def timed(m, first_iter, steps):
@@ -355,7 +355,7 @@ def density_mode(args):
             gc.collect(); gc.disable()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            with torch.autocast("cuda", dtype=torch.float16):
+            with torch.autocast("cuda", dtype=torch.float16, enabled=not args.fp32):
                 m.update_extra_state()
             torch.cuda.synchronize()
             out.append(time.perf_counter() - t0)
@@ -372,14 +372,15 @@ def density_mode(args):
     t_full = res["native_full_ms"] * 1e-3
     # dominant kernel: the fused field kernel, sigma branch only: deform MLP + sigma MLP = 2 * (76*128 + 6*128*128 + 128*3 + 32*64 + 64*16) MAC
     flop = 2.0 * (76 * 128 + 6 * 128 * 128 + 128 * 3 + 32 * 64 + 64 * 16) * cells
+    peak = MFMA_F32_PEAK_TFLOPS if args.fp32 else MFMA_F16_PEAK_TFLOPS
     print(json.dumps({"metric": "density-grid full update (update_extra_state), 64 x 128^3 cells", "value": cells / t_full, "unit": "cells/s",
-                      "ms_per_step": res["native_full_ms"], "higher_is_better": True, "n_gpus": 1, "dtype": "f16", "data": "synthetic",
+                      "ms_per_step": res["native_full_ms"], "higher_is_better": True, "n_gpus": 1, "dtype": "f32" if args.fp32 else "f16", "data": "synthetic",
                       **{k: round(v, 3) for k, v in res.items()},
                       "speedup_full": res["op_by_op_full_ms"] / res["native_full_ms"], "speedup_partial": res["op_by_op_partial_ms"] / res["native_partial_ms"],
-                      "whole_pass_mfma": {"achieved": flop / t_full / 1e12, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / t_full / 1e12 / MFMA_F16_PEAK_TFLOPS},
+                      "whole_pass_mfma": {"achieved": flop / t_full / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flop / t_full / 1e12 / peak},
                       "config": {"workload": "SURVEY 8(f)2: density-grid maintenance", "time_slices": nat.time_size, "grid": nat.grid_size,
                                  "cells": cells, "partial_cells_per_slice": 2 * (nat.grid_size ** 3 // 4),
-                                 "native": "sdn_density_query_cells_f16 per slice + sdn_density_grid_ema + sdn_density_grid_pack, incl. weight re-pack",
+                                 "native": ("sdn_density_query_cells_f32" if args.fp32 else "sdn_density_query_cells_f16") + " per slice + sdn_density_grid_ema + sdn_density_grid_pack, incl. weight re-pack",
                                  "op_by_op": "renderer mirror on the HIP operators (the reference's structure)"}}))
 
 

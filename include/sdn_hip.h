@@ -280,6 +280,13 @@ int sdn_density_query_cells_f16(const int32_t *cells, const uint32_t *cell_count
                                 uint32_t grid_size, float cas_bound, const void *weights, const float *bias0, const void *table,
                                 const int32_t *offsets_host, float S, uint32_t H, float bound, float density_scale, int zero_deform,
                                 float *tmp_slice, void *stream);
+/* The same query for a model trained WITHOUT `-O`: the fp32 network of sdn_field_forward_f32 (weights = its packed floats, bias0 the
+ * fp32 bias row of the -- perturbed -- time, table = the model's fp32 embeddings in the reference layout with the reference's
+ * offsets), within 1e-4 of the op-by-op fp32 network of dnerf/network.py:171-206. */
+int sdn_density_query_cells_f32(const int32_t *cells, const uint32_t *cell_count, uint32_t n, const float *noise, uint32_t seed,
+                                uint32_t grid_size, float cas_bound, const float *weights, const float *bias0, const float *table,
+                                const int32_t *offsets_host, float S, uint32_t H, float bound, float density_scale, int zero_deform,
+                                float *tmp_slice, void *stream);
 /* :536-538  density = max(density * decay, tmp) where density >= 0 and tmp >= 0, over n cells (n % 4 == 0, 16-byte aligned);
  * *sum (device, fp64, zeroed by the caller before the first slice) += sum of clamp(density, 0) after the update. */
 int sdn_density_grid_ema(float *density_grid, const float *tmp_grid, uint64_t n, float decay, double *sum, void *stream);

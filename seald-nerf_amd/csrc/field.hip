@@ -35,6 +35,7 @@
 #include <stdlib.h>
 
 #include "sdn_common.h"
+#include "cell_points.h"
 #include "grid_common.h"
 #include "sh_eval.h"
 
@@ -121,25 +122,8 @@ struct FieldArgs {
     uint32_t pp_soft;         // persistent kernel: the workgroup count to stay within unless more workgroups save a whole round (0 = gridDim.x)
 };
 
-// Morton code -> one coordinate (bits 0, 3, 6, ...): raymarching.cu:282-289
-__device__ __forceinline__ uint32_t compact_bits3(uint32_t x) {
-    x &= 0x49249249u;
-    x = (x | (x >> 2)) & 0xc30c30c3u;
-    x = (x | (x >> 4)) & 0x0f00f00fu;
-    x = (x | (x >> 8)) & 0xff0000ffu;
-    return (x | (x >> 16)) & 0x0000ffffu;
-}
-
-// counter-based uniform [0,1): PCG output permutation of (seed, counter); 24 random mantissa bits
-__device__ __forceinline__ float cell_uniform(uint32_t seed, uint32_t counter) {
-    uint32_t v = (counter ^ seed) * 747796405u + 2891336453u;
-    v = ((v >> ((v >> 28u) + 4u)) ^ v) * 277803737u;
-    v = (v >> 22u) ^ v;
-    v = (v ^ seed) * 747796405u + 2891336453u;
-    v = ((v >> ((v >> 28u) + 4u)) ^ v) * 277803737u;
-    v = (v >> 22u) ^ v;
-    return (float)(v >> 8) * (1.0f / 16777216.0f);
-}
+using sdn_cells::cell_uniform;
+using sdn_cells::compact_bits3;
 
 __device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 

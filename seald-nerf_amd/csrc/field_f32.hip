@@ -52,11 +52,14 @@ __device__ __forceinline__ void relu_into(const float16_t (&acc)[MT], float (&b)
         for (int v = 0; v < 16; v++) b[mt * 16 + v] = relu1(acc[mt][v]);
 }
 
+// CELLS: the density-grid query of update_extra_state (dnerf/renderer.py:453-555) without -O: slot p is a Morton cell index, the point is
+// the cell's jittered centre (cell_points.h), the kernel stops behind the sigma network and writes sigma * density_scale only.
+template <bool CELLS>
 __global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) k_field_f32(F32Args P, LevelParams lp) {
     __shared__ __attribute__((aligned(16))) float s_w[kStageFloats];
     __shared__ float s_bias[kMaxFrames * 128];      // the frames' time-encoding bias rows (D0's initial accumulators)
     Point pt;
-    if (!load_point(P, pt)) return;                                  // workgroup-uniform, before any barrier
+    if (!load_point<CELLS>(P, pt)) return;                           // workgroup-uniform, before any barrier
     const uint32_t lane = pt.lane, h = pt.h, n = pt.n, slot = pt.slot, fr = pt.fr;
     const bool valid = pt.valid, canonical = pt.canonical;
     float x[3] = {pt.x[0], pt.x[1], pt.x[2]}, d[3] = {pt.d[0], pt.d[1], pt.d[2]};
@@ -169,6 +172,10 @@ __global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) k_field_f32(F32Args P
     for (int v = 0; v < 16; v++) a1[0][v] = 0.0f;
     layer<32, 1>(s_w + kT_S1, b32, a1, lane);
     const float sigma = expf(a1[0][0]) * P.density_scale;     // row 0 (lower half); trunc_exp's forward is exp
+    if constexpr (CELLS) {                                    // (every barrier of the workgroup lies behind this wave)
+        if (valid && h == 0) P.sigmas[slot] = sigma;
+        return;
+    }
 
     // ---- colour network: SH(d, 4) ++ geo_feat (rows 1..15, raw) -> 64 -> 64 -> 3 ----
     float cin[16];
@@ -214,7 +221,23 @@ int field_forward_f32(const float *xyzs, const float *dirs, const uint32_t *live
     int rc = sdn_f32::fill_args(a, lp, xyzs, dirs, live_idx, live_count, state, M, weights, bias0, table, offsets_host, S, H, bound, density_scale,
                                 zero_deform, sigmas, rgbs, deform, slot_frame, n_frames);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_field_f32, dim3(sdn_div_up(M, (uint32_t)sdn_f32::kPointsPerWG)), dim3(64 * sdn_f32::kWaves), 0, st, a, lp);
+    hipLaunchKernelGGL(k_field_f32<false>, dim3(sdn_div_up(M, (uint32_t)sdn_f32::kPointsPerWG)), dim3(64 * sdn_f32::kWaves), 0, st, a, lp);
+    return sdn_launch_status();
+}
+
+// sigma * density_scale of jittered occupancy-grid cell centres -> tmp_grid slice, fp32 network (the fp32 twin of field_cells_f16)
+int field_cells_f32(const int32_t *cells, const uint32_t *cell_count, uint32_t n, const float *noise, uint32_t seed, uint32_t grid_size,
+                    float cas_bound, const float *weights, const float *bias0, const float *table, const int32_t *offsets_host, float S,
+                    uint32_t H, float bound, float density_scale, int zero_deform, float *tmp_slice, hipStream_t st) {
+    sdn_f32::LevelParams lp;
+    sdn_f32::F32Args a;
+    int rc = sdn_f32::fill_args(a, lp, nullptr, nullptr, (const uint32_t *)cells, cell_count, nullptr, n, weights, bias0, table, offsets_host, S, H,
+                                bound, density_scale, zero_deform ? 1 : 0, tmp_slice, nullptr, nullptr, nullptr, 1u);
+    if (rc) return rc;
+    a.cell_noise = noise; a.cell_seed = seed;
+    const float half_grid = cas_bound / (float)grid_size;
+    a.cell_inv = 1.0f / (float)(grid_size - 1); a.cell_span = cas_bound - half_grid; a.cell_half = half_grid;
+    hipLaunchKernelGGL(k_field_f32<true>, dim3(sdn_div_up(n, (uint32_t)sdn_f32::kPointsPerWG)), dim3(64 * sdn_f32::kWaves), 0, st, a, lp);
     return sdn_launch_status();
 }
 }  // namespace sdn_int
@@ -232,6 +255,22 @@ int sdn_field_forward_f32(const float *xyzs, const float *dirs, const uint32_t *
     if (((uintptr_t)weights & 15u) != 0 || ((uintptr_t)table & 3u) != 0) return SDN_E_BADARG;
     return sdn_int::field_forward_f32(xyzs, dirs, live_idx, live_count, nullptr, M, weights, bias0, table, offsets_host, S, H, bound,
                                       density_scale, zero_deform ? 1 : 0, sigmas, rgbs, deform, nullptr, 1u, (hipStream_t)stream);
+}
+
+// The density-grid query of update_extra_state for a model trained WITHOUT -O: as sdn_density_query_cells_f16 with the fp32 network
+// (weights of sdn_field_weight_floats_f32 floats, the model's fp32 embedding table in the reference layout).
+int sdn_density_query_cells_f32(const int32_t *cells, const uint32_t *cell_count, uint32_t n, const float *noise, uint32_t seed,
+                                uint32_t grid_size, float cas_bound, const float *weights, const float *bias0, const float *table,
+                                const int32_t *offsets_host, float S, uint32_t H, float bound, float density_scale, int zero_deform,
+                                float *tmp_slice, void *stream) {
+    if (n == 0) return 0;
+    if (!weights || !bias0 || !table || !offsets_host || !tmp_slice) return SDN_E_BADARG;
+    if ((cells == nullptr) != (cell_count == nullptr)) return SDN_E_BADARG;
+    if (grid_size < 2 || grid_size > 1024 || !(cas_bound > 0)) return SDN_E_BADARG;
+    if (!cells && (uint64_t)n > (uint64_t)grid_size * grid_size * grid_size) return SDN_E_BADARG;   // without a list, slot p IS the Morton index
+    if (((uintptr_t)weights & 15u) != 0 || ((uintptr_t)table & 3u) != 0) return SDN_E_BADARG;
+    return sdn_int::field_cells_f32(cells, cell_count, n, noise, seed, grid_size, cas_bound, weights, bias0, table, offsets_host, S, H, bound,
+                                    density_scale, zero_deform, tmp_slice, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <type_traits>
 
+#include "cell_points.h"
 #include "grid_common.h"
 #include "sdn_common.h"
 #include "sdn_internal.h"
@@ -43,6 +44,11 @@ struct F32Args {
     int zero_deform;              // bit f: frame f is the canonical frame (no deformation)
     const uint8_t *slot_frame;    // frame group: frame of every sample slot (bias0 then holds n_frames rows), or nullptr = one frame
     uint32_t n_frames;
+    // density-grid query (CELLS kernels): slot = Morton cell index (live_idx = the cell list or nullptr = cells 0 .. M-1), the point
+    // is the cell's jittered centre built in the kernel (cell_points.h), only sigma * density_scale is written (to sigmas[cell])
+    const float *cell_noise;      // [count,3] uniform [0,1) by list position, or nullptr = counter-based generator on cell_seed
+    uint32_t cell_seed;
+    float cell_inv, cell_span, cell_half;
 };
 
 // ReLU in ONE instruction: as signed integers, negative floats are negative and non-negative floats keep their order, so max(bits, 0)
@@ -59,6 +65,7 @@ struct Point {
     bool valid, canonical;
 };
 // false: the whole workgroup lies beyond the live count (workgroup-uniform, before any barrier)
+template <bool CELLS = false>
 __device__ __forceinline__ bool load_point(const F32Args &P, Point &p) {
     p.lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -69,7 +76,15 @@ __device__ __forceinline__ bool load_point(const F32Args &P, Point &p) {
     p.valid = i < count;
     p.slot = p.valid ? (P.live_idx ? P.live_idx[i] : i) : 0u;
     p.x[0] = p.x[1] = p.x[2] = 0; p.d[0] = p.d[1] = 0; p.d[2] = 1;
-    if (p.valid) {
+    if constexpr (CELLS) {
+        if (p.valid) {
+            #pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const float r = P.cell_noise ? P.cell_noise[(size_t)i * 3 + d] : sdn_cells::cell_uniform(P.cell_seed, i * 3u + (uint32_t)d);
+                p.x[d] = sdn_cells::cell_coord(p.slot, d, r, P.cell_inv, P.cell_span, P.cell_half);
+            }
+        }
+    } else if (p.valid) {
         p.x[0] = P.xyzs[(size_t)p.slot * 3]; p.x[1] = P.xyzs[(size_t)p.slot * 3 + 1]; p.x[2] = P.xyzs[(size_t)p.slot * 3 + 2];
         p.d[0] = P.dirs[(size_t)p.slot * 3]; p.d[1] = P.dirs[(size_t)p.slot * 3 + 1]; p.d[2] = P.dirs[(size_t)p.slot * 3 + 2];
     }
@@ -122,6 +137,7 @@ inline int fill_args(F32Args &a, LevelParams &lp, const float *xyzs, const float
     a.weights = weights; a.bias0 = bias0; a.table = table; a.sigmas = sigmas; a.rgbs = rgbs; a.deform = deform;
     a.bound = bound; a.density_scale = density_scale; a.zero_deform = zero_deform;
     a.slot_frame = slot_frame; a.n_frames = slot_frame ? (n_frames > (uint32_t)kMaxFrames ? (uint32_t)kMaxFrames : (n_frames ? n_frames : 1u)) : 1u;
+    a.cell_noise = nullptr; a.cell_seed = 0; a.cell_inv = a.cell_span = a.cell_half = 0;
     return 0;
 }
 

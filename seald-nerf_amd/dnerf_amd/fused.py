@@ -241,10 +241,20 @@ class DensityGridUpdater:
     of `torch.nonzero`, which would synchronise once per slice, and hands the kernel the union sorted by Morton index.
     """
 
-    def __init__(self, model, field=None):
+    def __init__(self, model, field=None, fp32=False):
+        """fp32: the update of a model trained WITHOUT -O -- the queries go through the fp32 fused kernel (csrc/field_f32.hip, CELLS
+        variant: `sdn_density_query_cells_f32`, within 1e-4 of the op-by-op fp32 network) on the model's fp32 table in place."""
         self.model = model
         dev = model.density_grid.device
-        self.field = field if field is not None else FusedField(model, model.times[0].reshape(1, 1).to(dev), fp16=True)
+        if field is None:
+            t0 = model.times[0].reshape(1, 1).to(dev)
+            if fp32:
+                from .fused_f32 import FusedFieldF32
+                field = FusedFieldF32(model, t0, variant="mfma32")
+            else:
+                field = FusedField(model, t0, fp16=True)
+        self.field = field
+        self.fp32 = not isinstance(field, FusedField)
         n = model.grid_size ** 3
         self.tmp = torch.empty(n, dtype=torch.float32, device=dev)
         self.sum = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -254,6 +264,9 @@ class DensityGridUpdater:
     def refresh(self):
         """Re-pack the (trained) weights and the fp16 table; call after optimizer steps."""
         f, enc = self.field, self.model.encoder
+        if self.fp32:
+            f.refresh()
+            return
         f.weights.copy_(torch.from_numpy(pack_weights(self.model)))
         f.load_table(enc.embeddings.detach())
         f.invalidate_time_cache()
@@ -264,6 +277,8 @@ class DensityGridUpdater:
         with torch.no_grad(), torch.autocast("cuda", enabled=False):   # (the trainer calls update_extra_state under autocast)
             enc_t = freq_encode(times.reshape(-1, 1).float(), 6, 13)
             w = self.model.deform_net[0].weight.detach()[:, 63:76]
+            if self.fp32:
+                return (enc_t @ w.float().t()).contiguous()
             return (enc_t.to(torch.float16).float() @ w.to(torch.float16).float().t()).contiguous()
 
     def query_cells(self, out, bias0, zero_deform, cas_bound, cells=None, cell_count=None, n=None, noise=None, seed=0):
@@ -271,6 +286,14 @@ class DensityGridUpdater:
         f = self.field
         if cells is not None:
             n = cells.shape[0]
+        if self.fp32:
+            with sdn_backend.timed("density_query_cells_f32", n):
+                check(sdn_backend.lib.sdn_density_query_cells_f32(ptr(cells, torch.int32, "cells"), ptr(cell_count), n, ptr(noise, torch.float32, "noise"),
+                                                                  int(seed) & 0xFFFFFFFF, self.model.grid_size, float(cas_bound), ptr(f.weights),
+                                                                  ptr(bias0, torch.float32, "bias0"), ptr(f.table, torch.float32, "embeddings"),
+                                                                  f.offsets_host.ctypes.data, f.S, f.H, f.bound, f.density_scale, int(zero_deform),
+                                                                  ptr(out, torch.float32, "out"), stream()), "density_query_cells_f32")
+            return out
         with sdn_backend.timed("density_query_cells_f16", n):
             check(sdn_backend.lib.sdn_density_query_cells_f16(ptr(cells, torch.int32, "cells"), ptr(cell_count), n, ptr(noise, torch.float32, "noise"),
                                                               int(seed) & 0xFFFFFFFF, self.model.grid_size, float(cas_bound), ptr(f.weights),

@@ -83,10 +83,11 @@ class NeRFRenderer(nn.Module):
     def mean_density(self, value):
         self._mean_density, self._mean_density_dev = value, None
 
-    def use_native_density_update(self, field=None):
-        """Route update_extra_state through csrc/density.hip + the fused field kernel (`-O` numerics; dnerf_amd/fused.py)."""
+    def use_native_density_update(self, field=None, fp32=False):
+        """Route update_extra_state through csrc/density.hip + the fused field kernel (`-O` numerics; dnerf_amd/fused.py); fp32=True:
+        through the fp32 fused kernel instead (a model trained without -O: 1e-4 from the op-by-op fp32 network)."""
         from .fused import DensityGridUpdater
-        self._density_updater = DensityGridUpdater(self, field)
+        self._density_updater = DensityGridUpdater(self, field, fp32=fp32)
         return self._density_updater
 
     def forward(self, x, d, t):

@@ -245,3 +245,91 @@ def test_query_cells_against_the_cpu_oracle(scene):
     want = sigma * m.density_scale
     rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
     assert np.median(rel) < 2e-3 and rel.max() < 5e-2, (np.median(rel), rel.max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the fp32 twin (a model trained WITHOUT -O): sdn_density_query_cells_f32 = the CELLS variant of the fp32 fused kernel
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_fp32_query_cells_is_bit_exact_against_the_fp32_field_kernel(scene):
+    from dnerf_amd import fused
+    m = scene.model
+    up = fused.DensityGridUpdater(m, fp32=True)
+    f = up.field
+    assert up.fp32 and f.variant == "mfma32"
+    f.set_time(torch.tensor([[0.37]], device="cuda"))
+    H3 = m.grid_size ** 3
+    g = torch.Generator(device="cuda").manual_seed(5)
+    noise = torch.rand(H3, 3, device="cuda", generator=g)
+    out = torch.full((H3,), -1.0, device="cuda")
+    up.query_cells(out, f.bias0, f.zero_deform, 1.0, n=H3, noise=noise)
+    cells = torch.arange(H3, device="cuda", dtype=torch.int32)
+    x = _points(m, cells, noise).contiguous()
+    d = torch.zeros_like(x); d[:, 2] = 1
+    s, _ = f(x, d)
+    assert torch.equal(out, s), int((out != s).sum())
+    assert float(out.min()) > 0
+
+    # listed cells, live count on the device, canonical frame (t = 0: no deformation)
+    f.set_time(torch.tensor([[0.0]], device="cuda"))
+    assert f.zero_deform == 1
+    n_list, n_live = 30000, 21234
+    perm = torch.randperm(H3, device="cuda", generator=g)[:n_list].to(torch.int32).contiguous()
+    count = torch.tensor([n_live], dtype=torch.int32, device="cuda")
+    nz = torch.rand(n_list, 3, device="cuda", generator=g)
+    out2 = torch.full((H3,), -1.0, device="cuda")
+    up.query_cells(out2, f.bias0, f.zero_deform, 1.0, cells=perm, cell_count=count, noise=nz)
+    x2 = _points(m, perm[:n_live], nz[:n_live]).contiguous()
+    d2 = torch.zeros_like(x2); d2[:, 2] = 1
+    s2, _ = f(x2, d2)
+    live = perm[:n_live].long()
+    assert torch.equal(out2[live], s2)
+    rest = torch.ones(H3, dtype=torch.bool, device="cuda"); rest[live] = False
+    assert bool((out2[rest] == -1).all())
+
+    # against the op-by-op fp32 network of the mirror (dnerf/network.py:171-206): the north star's 1e-4
+    tt = torch.tensor([[0.37]], device="cuda")
+    f.set_time(tt)
+    up.query_cells(out, f.bias0, f.zero_deform, 1.0, n=H3, noise=noise)
+    sub = torch.randperm(H3, device="cuda", generator=g)[:20000]
+    with torch.no_grad():
+        ref = m.density(x[sub].contiguous(), tt)["sigma"].float() * m.density_scale
+    np.testing.assert_allclose(out[sub].cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+    import sdn_backend
+    with pytest.raises(sdn_backend.SdnError):
+        up.query_cells(out, f.bias0, 0, 1.0, n=H3 + 1)
+
+
+def test_fp32_full_update_matches_the_op_by_op_mirror(scene):
+    """The whole update without autocast: the native fp32 path against the mirror's op-by-op fp32 update, same torch.rand draws."""
+    import raymarching
+    a, b = _fresh_model(scene), _fresh_model(scene)
+    T, H3 = a.time_size, a.grid_size ** 3
+    torch.manual_seed(13)
+    a.update_extra_state()
+    torch.manual_seed(13)
+    noise = torch.empty(T, 1, H3, 3, device="cuda")
+    tn = torch.empty(T, 1)
+    for t in range(T):
+        noise[t, 0] = torch.rand(H3, 3, device="cuda")
+        tn[t, 0] = float(torch.rand(1, 1, device="cuda"))
+    ax = torch.arange(a.grid_size, dtype=torch.int32, device="cuda")
+    xx, yy, zz = torch.meshgrid(ax, ax, ax, indexing="ij")
+    morton_of_mesh = raymarching.morton3D(torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1).contiguous()).long()
+    by_cell = torch.empty_like(noise)
+    by_cell[:, :, morton_of_mesh] = noise
+    up = b.use_native_density_update(fp32=True)
+    assert up.fp32
+    mean = up.update(0.95, noise=by_cell, time_noise=tn)
+    da, db = a.density_grid, b.density_grid
+    rel = (da - db).abs() / da.abs().clamp(min=1e-3)
+    # fp32 both sides: 1e-4, except cells whose jittered centre lies within rounding of the grid's [0,1] boundary (zero features there)
+    off = (rel >= 1e-4).nonzero()
+    assert float(rel.median()) < 1e-5 and off.shape[0] <= 16, (float(rel.median()), off.shape[0])
+    if off.shape[0]:
+        c = raymarching.morton3D_invert(off[:, 2].to(torch.int32).contiguous())
+        assert bool(((c == 0) | (c == a.grid_size - 1)).any(dim=1).all())
+    assert abs(float(mean[0]) - a.mean_density) < 1e-4 * a.mean_density
+    diff = (a.density_bitfield ^ b.density_bitfield)
+    assert int(diff.count_nonzero()) <= 16
+    assert torch.equal(b.density_bitfield, torch.stack([raymarching.packbits(db[t], float(mean[1])) for t in range(T)]))

@@ -39,7 +39,6 @@ timeout -k 10 1000 python3 tools/pmc_passes.py $OUT/pmc_field $OUT/pmc_field_raw
   --set C=SQ_INSTS_VMEM_RD,SQ_INSTS_VMEM_WR,SQ_INSTS_SMEM,SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,SQ_VALU_MFMA_COEXEC_CYCLES,SQ_ACTIVE_INST_SCA \
   --set D=GRBM_GUI_ACTIVE,GRBM_COUNT --set E=FETCH_SIZE --set F=WRITE_SIZE \
   --set G=TCC_HIT_sum,TCC_MISS_sum,TCC_REQ_sum,TCC_READ_sum --set H=TCP_TOTAL_CACHE_ACCESSES_sum,TCP_TCC_READ_REQ_sum,TCP_TOTAL_ACCESSES_sum,TCP_TA_DATA_STALL_CYCLES_sum \
-  --set I=TA_TA_BUSY_sum,TA_BUSY_avr,TA_ADDR_STALLED_BY_TC_CYCLES_sum,TA_FLAT_READ_WAVEFRONTS_sum,TA_BUFFER_WAVEFRONTS_sum,TA_FLAT_WAVEFRONTS_sum \
   --kernel k_field --kernel k_composite_march --kernel k_march_rays \
   --note "static frame x 4 per loop, one loop at a time" -- $B || exit 1
 python3 tools/field_pmc_summary.py $OUT/pmc_field_raw.json $OUT/bench_pmc_command.json 6 $OUT/field_pmc_summary.json || exit 1
