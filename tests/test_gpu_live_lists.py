@@ -57,6 +57,7 @@ def test_forward_on_the_marchers_tensor_evaluates_the_listed_slots_only(model_bi
     filled = dl[:, 0] > 0
     assert 0 < int(filled.sum()) < x.shape[0]
     model.fused_inference_f32 = fp32
+    model.fused_live_lists_f16 = True       # (off by default under -O: the host-bound loop gains nothing from it)
     try:
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=not fp32):
             import sdn_backend
@@ -81,6 +82,7 @@ def test_forward_on_the_marchers_tensor_evaluates_the_listed_slots_only(model_bi
     finally:
         model.fused_inference_f32 = False
         model.__dict__.pop("fused_live_lists", None)
+        model.__dict__.pop("fused_live_lists_f16", None)
 
 
 @pytest.mark.parametrize("fp32", [False, True])
@@ -88,6 +90,7 @@ def test_reference_shaped_frame_is_the_same_with_and_without_lists(model_bits, l
     sc = fixture_scene("cuda", model_bits=model_bits, time=0.26)
     model = sc.model.eval()
     model.fused_inference_f32 = fp32
+    model.fused_live_lists_f16 = True
 
     def frame(on):
         lists["on"], lists["pinned"] = on, True
@@ -101,6 +104,7 @@ def test_reference_shaped_frame_is_the_same_with_and_without_lists(model_bits, l
         b, slots_b = frame(True)
     finally:
         model.fused_inference_f32 = False
+        model.__dict__.pop("fused_live_lists_f16", None)
     assert torch.equal(a["image"], b["image"]) and torch.equal(torch.nan_to_num(a["depth"]), torch.nan_to_num(b["depth"]))
     assert slots_a == slots_b        # the launches are sized by slots either way; the kernel leaves at the list's end
 
@@ -111,4 +115,12 @@ def test_dispatch_switches_the_lists_on_by_itself(model_bits, lists):
     model = sc.model.eval()
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         model.render(sc.rays_o[None], sc.rays_d[None], sc.time, staged=False, perturb=False, bg_color=None)
-    assert lists["on"] == bool(model.fused_live_lists_f16)
+    assert lists["on"] == bool(model.fused_live_lists_f16)      # under -O only when asked for (SDN_LIVE_LISTS_F16=1)
+    lists["on"] = False
+    model.fused_inference_f32 = True
+    try:
+        with torch.no_grad():
+            model.render(sc.rays_o[None], sc.rays_d[None], sc.time, staged=False, perturb=False, bg_color=None)
+    finally:
+        model.fused_inference_f32 = False
+    assert lists["on"]                                           # the fp32 dispatch uses them by default
