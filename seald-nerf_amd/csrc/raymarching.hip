@@ -2684,7 +2684,16 @@ static int launch_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *r
                              const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
                              const uint8_t *grid, const float *fars, float *xyzs, float *dirs, float *deltas, const float *noises,
                              uint32_t M_pad, const uint32_t *cull, uint32_t *live_idx, uint32_t *live_count, hipStream_t st) {
-    if (n_alive == 0 || n_step == 0) return 0;
+    if (n_alive == 0 || n_step == 0) {
+        // no sample slots: the M_pad padding slots are still the caller's to read -- the reference hands out zero-filled buffers
+        // (raymarching.py:333-335), and no kernel runs here that would clear them
+        if (M_pad && xyzs && dirs && deltas) {
+            if (hipMemsetAsync(xyzs, 0, (size_t)M_pad * 12, st) != hipSuccess || hipMemsetAsync(dirs, 0, (size_t)M_pad * 12, st) != hipSuccess ||
+                hipMemsetAsync(deltas, 0, (size_t)M_pad * 8, st) != hipSuccess)
+                return sdn_launch_status();
+        }
+        return 0;
+    }
     if (!rays_alive || !rays_t || !rays_o || !rays_d || !grid || !fars || !xyzs || !dirs || !deltas) return SDN_E_BADARG;
     if (C == 0 || C > 16 || H == 0 || max_steps == 0) return SDN_E_BADARG;
     if ((live_idx == nullptr) != (live_count == nullptr)) return SDN_E_BADARG;

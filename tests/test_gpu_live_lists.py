@@ -24,7 +24,7 @@ def lists():
     raymarching.live_lists.update(saved)
 
 
-def _march(sc, n_step, on, lists):
+def _march(sc, n_step, on, lists, perturb=False):
     import raymarching
     lists["on"], lists["pinned"] = on, True
     N = sc.rays_o.shape[0]
@@ -32,7 +32,7 @@ def _march(sc, n_step, on, lists):
     nears, fars = raymarching.near_far_from_aabb(sc.rays_o, sc.rays_d, m.aabb_infer, m.min_near)
     alive = torch.arange(N, dtype=torch.int32, device="cuda")
     return raymarching.march_rays(N, n_step, alive, nears.clone(), sc.rays_o, sc.rays_d, m.bound, sc.model.density_bitfield[sc.t_idx],
-                                  m.cascade, m.grid_size, nears, fars, 128, False, 0.0, 1024)
+                                  m.cascade, m.grid_size, nears, fars, 128, perturb, 0.0, 1024)
 
 
 @pytest.mark.parametrize("n_step", [1, 4])
@@ -47,6 +47,24 @@ def test_marcher_hangs_the_list_of_filled_slots_on_its_output(model_bits, lists,
     filled = torch.nonzero(dl1[:, 0] > 0).reshape(-1).to(torch.int32)
     assert ver == x1._version and n == filled.numel() and n > 0
     assert torch.equal(torch.sort(idx[:n]).values, filled)                               # unordered list of exactly the filled slots
+
+
+def test_list_with_perturbed_starts_and_with_no_ray_alive(model_bits, lists):
+    """perturb=True (the marcher draws a start offset per ray): the list still names exactly the filled slots; n_alive = 0: no list."""
+    import raymarching
+    sc = fixture_scene("cuda", model_bits=model_bits, time=0.5)
+    torch.manual_seed(4)
+    x, d, dl = _march(sc, 2, True, lists, perturb=True)
+    idx, cnt, _ = x._sdn_live
+    n = int(cnt.item())
+    filled = torch.nonzero(dl[:, 0] > 0).reshape(-1).to(torch.int32)
+    assert n == filled.numel() and n > 0 and torch.equal(torch.sort(idx[:n]).values, filled)
+    m = sc.model
+    nears, fars = raymarching.near_far_from_aabb(sc.rays_o, sc.rays_d, m.aabb_infer, m.min_near)
+    none = torch.empty(0, dtype=torch.int32, device="cuda")
+    x0, d0, dl0 = raymarching.march_rays(0, 8, none, nears.clone(), sc.rays_o, sc.rays_d, m.bound, m.density_bitfield[sc.t_idx], m.cascade,
+                                         m.grid_size, nears, fars, 128, False, 0.0, 1024)
+    assert x0.shape == (128, 3) and not x0.any() and not dl0.any() and getattr(x0, "_sdn_live", None) is None
 
 
 @pytest.mark.parametrize("fp32", [False, True])
