@@ -2654,7 +2654,8 @@ extern "C" {
 int sdn_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, uint32_t M,
                                      uint32_t N, float T_thresh, float *weights_sum, float *depth, float *image, void *stream) {
     if (N == 0) return 0;
-    if (!sigmas || !rgbs || !deltas || !rays || !weights_sum || !depth || !image) return SDN_E_BADARG;
+    // (M == 0: empty sample tensors have no address; every ray then takes the kernel's `offset + num_steps > M` exit and reads none)
+    if ((M != 0 && (!sigmas || !rgbs || !deltas)) || !rays || !weights_sum || !depth || !image) return SDN_E_BADARG;
     hipLaunchKernelGGL(k_composite_train_fwd, dim3(sdn_div_up(N, 256u)), dim3(256), 0, (hipStream_t)stream, sigmas, rgbs, deltas, rays, M, N,
                        T_thresh, weights_sum, depth, image);
     return sdn_launch_status();
@@ -2673,6 +2674,7 @@ int sdn_composite_rays_train_backward(const float *grad_weights_sum, const float
                                       const float *deltas, const int32_t *rays, const float *weights_sum, const float *image,
                                       uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas, float *grad_rgbs, void *stream) {
     if (N == 0) return 0;
+    if (M == 0) return 0;       // no sample, no gradient entry to write
     if (!grad_weights_sum || !grad_image || !sigmas || !rgbs || !deltas || !rays || !weights_sum || !image || !grad_sigmas || !grad_rgbs)
         return SDN_E_BADARG;
     hipLaunchKernelGGL(k_composite_train_bwd, dim3(sdn_div_up(N, 256u)), dim3(256), 0, (hipStream_t)stream, grad_weights_sum, grad_image,

@@ -769,3 +769,55 @@ def test_grid_encode_forward_on_the_quad_copy_is_the_plain_forward_bit_for_bit()
         out = enc(x[:1000], bound=1)
     out.float().sum().backward()
     assert enc.embeddings.grad is not None and float(enc.embeddings.grad.abs().sum()) > 0
+
+
+def test_empty_and_ragged_inputs_of_the_drop_in_operators():
+    """Zero-size inputs and leading batch dimensions through the operator layer (the reference's wrappers allocate outputs of the same
+    shapes and launch nothing: raymarching.py:40-56,300-370, grid.py:24-80, sphere_harmonics.py:14-50, freq.py:15-45)."""
+    import raymarching
+    from freqencoder import FreqEncoder
+    from gridencoder import GridEncoder
+    from shencoder import SHEncoder
+    dev = "cuda"
+    aabb = torch.tensor([-1., -1, -1, 1, 1, 1], device=dev)
+    e0 = torch.empty(0, 3, device=dev)
+    assert [tuple(t.shape) for t in raymarching.near_far_from_aabb(e0, e0, aabb, 0.2)] == [(0,), (0,)]
+    assert raymarching.morton3D(torch.empty(0, 3, dtype=torch.int32, device=dev)).shape == (0,)
+    assert raymarching.morton3D_invert(torch.empty(0, dtype=torch.int32, device=dev)).shape == (0, 3)
+    g = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048).to(dev)
+    assert g(e0, bound=1).shape == (0, 32)
+    x0 = e0.clone().requires_grad_(True)
+    g(x0, bound=1).sum().backward()
+    assert x0.grad.shape == (0, 3) and float(g.embeddings.grad.abs().sum()) == 0.0
+    x = torch.rand(4, 5, 3, device=dev) * 2 - 1
+    assert torch.equal(g(x, bound=1), g(x.view(-1, 3), bound=1).view(4, 5, 32))
+    xt = (torch.rand(3, 64, device=dev) * 2 - 1).t()                     # non-contiguous [64, 3]
+    assert torch.equal(g(xt, bound=1), g(xt.contiguous(), bound=1))
+    sh, fq = SHEncoder(input_dim=3, degree=4).to(dev), FreqEncoder(input_dim=3, degree=10).to(dev)
+    assert sh(e0).shape == (0, 16) and fq(e0).shape == (0, 63)
+    d = torch.nn.functional.normalize(torch.randn(4, 5, 3, device=dev), dim=-1)
+    assert torch.equal(sh(d), sh(d.view(-1, 3)).view(4, 5, 16)) and torch.equal(fq(d), fq(d.view(-1, 3)).view(4, 5, 63))
+    # no ray alive: padding only, zero-filled (the reference's torch.zeros buffers); nothing to composite
+    N = 5
+    ro = torch.tensor([[0., 0, -3]] * N, device=dev); rd = torch.tensor([[0., 0, 1]] * N, device=dev)
+    nears, fars = raymarching.near_far_from_aabb(ro, rd, aabb, 0.2)
+    full = torch.full((128 ** 3 // 8,), 255, dtype=torch.uint8, device=dev)
+    none = torch.empty(0, dtype=torch.int32, device=dev)
+    torch.empty(128, 8, device=dev).fill_(7.0)                           # (dirty the allocator's next blocks)
+    xs, ds, dl = raymarching.march_rays(0, 8, none, nears.clone(), ro, rd, 1.0, full, 1, 128, nears, fars, 128, False, 0, 1024)
+    assert xs.shape == (128, 3) and not xs.any() and not ds.any() and not dl.any()
+    z = torch.zeros(0, device=dev)
+    raymarching.composite_rays(0, 4, none, z, z, torch.zeros(0, 3, device=dev), torch.zeros(0, 2, device=dev), z, z, torch.zeros(0, 3, device=dev))
+    # align = -1: no padding; align dividing M: the reference adds a whole `align` (raymarching.py:331-332)
+    alive = torch.arange(N, dtype=torch.int32, device=dev)
+    assert raymarching.march_rays(N, 3, alive, nears.clone(), ro, rd, 1.0, full, 1, 128, nears, fars, -1, False, 0, 1024)[0].shape == (15, 3)
+    assert raymarching.march_rays(N, 3, alive, nears.clone(), ro, rd, 1.0, full, 1, 128, nears, fars, 5, False, 0, 1024)[0].shape == (20, 3)
+    # a training batch without a single sample (align = -1 on an empty grid): zero images, empty gradients
+    s = torch.zeros(0, device=dev, requires_grad=True)
+    c = torch.zeros(0, 3, device=dev, requires_grad=True)
+    rays = torch.zeros(64, 3, dtype=torch.int32, device=dev)
+    rays[:, 0] = torch.arange(64, dtype=torch.int32, device=dev)
+    w, dep, img = raymarching.composite_rays_train(s, c, torch.zeros(0, 2, device=dev), rays)
+    assert not w.any() and not dep.any() and not img.any() and img.shape == (64, 3)
+    (w.sum() + img.sum()).backward()
+    assert s.grad.shape == (0,) and c.grad.shape == (0, 3)
