@@ -668,3 +668,31 @@ def test_table_pass_on_a_second_stream_changes_nothing_but_the_schedule():
     for k in runs[0][1]:
         d = (runs[0][1][k] - runs[1][1][k]).abs()
         assert float(d.max()) <= (1.1e-1 if k == "encoder.embeddings" else 1.1e-2), k
+
+
+def test_a_batch_without_a_single_sample_is_a_finite_step():
+    """Empty occupancy (a freshly reset grid, or a batch of rays that all miss): the native step and the autograd step see the same loss --
+    every pixel is the background -- produce zero gradients, and the step leaves every parameter finite."""
+    from dnerf_amd.train_native import NativeTrainStep
+    sc, model, opt, scaler, target = _setup()
+    with torch.no_grad():
+        model.density_bitfield.zero_()
+    out, loss = _eager_backward(model, sc, target, scaler)
+    assert int(model.step_counter[0, 0]) == 0                       # no sample anywhere
+    np.testing.assert_allclose(float(loss.detach()), float(((1 - target) ** 2).mean()), rtol=1e-5)
+    model.local_step = 0
+    step = NativeTrainStep(model, opt, scaler, N_RAYS, "cuda", perturb=False)
+    got = step(sc.rays_o, sc.rays_d, target, sc.time, grads_only=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(got), float(loss.detach()), rtol=1e-5)
+    assert torch.equal(step.image, torch.ones_like(step.image))
+    grads = _native_grads(step, model)
+    assert all(not g.any() for g in grads.values())
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    got2 = step(sc.rays_o, sc.rays_d, target, sc.time)                 # the whole step: Adam on zero gradients
+    step.flush() if hasattr(step, "flush") else None
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(got2), float(loss.detach()), rtol=1e-5)
+    for k, v in model.named_parameters():
+        assert bool(torch.isfinite(v).all()), k
+        assert float((v.detach() - before[k]).abs().max()) <= 1e-6, k   # zero gradient, zero moments: nothing moves
