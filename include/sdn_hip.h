@@ -118,7 +118,8 @@ int sdn_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive,
 
 /* Extension of march_rays for the native render loop (same samples, bit for bit):
  *   M_pad      rows of xyzs/dirs/deltas; the rows [n_alive*n_step, M_pad) are cleared by the same launch
- *              (the reference wrapper memsets all three buffers before every call, raymarching.py:334-336);
+ *              (the reference wrapper memsets all three buffers before every call, raymarching.py:334-336); with no ray alive
+ *              (n_alive * n_step == 0) no kernel runs and the M_pad rows are cleared by three asynchronous fills instead;
  *   cull_grid  sdn_cull_grid_bytes() bytes from sdn_build_cull_grid, or NULL: exact early-out for rays whose remaining
  *              segment stays >= 2 voxels away from every occupied voxel (they produce no sample in the reference either);
  *   live_idx / live_count (both or neither): slot indices that received a sample are appended at
