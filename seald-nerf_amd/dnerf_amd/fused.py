@@ -255,6 +255,8 @@ class DensityGridUpdater:
                 field = FusedField(model, t0, fp16=True)
         self.field = field
         self.fp32 = not isinstance(field, FusedField)
+        if self.fp32 and getattr(field, "variant", "mfma32") != "mfma32":
+            raise sdn_backend.SdnError("the fp32 density query reads the fp32-MFMA kernel's weight packing (FusedFieldF32(variant='mfma32'))")
         n = model.grid_size ** 3
         self.tmp = torch.empty(n, dtype=torch.float32, device=dev)
         self.sum = torch.zeros(1, dtype=torch.float64, device=dev)
