@@ -821,3 +821,63 @@ def test_empty_and_ragged_inputs_of_the_drop_in_operators():
     assert not w.any() and not dep.any() and not img.any() and img.shape == (64, 3)
     (w.sum() + img.sum()).backward()
     assert s.grad.shape == (0,) and c.grad.shape == (0, 3)
+
+
+def test_large_batches_are_batch_independent():
+    """20 M points through the encoders, 24 M sample slots through the marcher: every row equals the row of a small batch holding the same
+    input (no index arithmetic wraps, no tail is dropped); the table gradient of 8 M points in one launch equals the sum over four
+    launches up to the order of the float atomics."""
+    import raymarching
+    from freqencoder import FreqEncoder
+    from gridencoder import GridEncoder
+    from shencoder import SHEncoder
+    dev = "cuda"
+    B = 20_000_007
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.rand(B, 3, device=dev, generator=g) * 2 - 1
+    sub = torch.randint(0, B, (50_000,), device=dev, generator=g)
+    sub[:3] = torch.tensor([0, B - 1, B - 2], device=dev)
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048).to(dev)
+    sh, fq = SHEncoder(3, 4).to(dev), FreqEncoder(3, 10).to(dev)
+    with torch.no_grad():
+        enc.embeddings.uniform_(-1, 1, generator=g)
+        y = enc(x, bound=1)
+        assert y.shape == (B, 32) and torch.equal(y[sub], enc(x[sub].contiguous(), bound=1))
+        del y
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = enc(x, bound=1)
+            assert y.dtype == torch.float16 and torch.equal(y[sub], enc(x[sub].contiguous(), bound=1))
+        del y
+        d = torch.nn.functional.normalize(x, dim=1)
+        y = sh(d)
+        assert torch.equal(y[sub], sh(d[sub].contiguous()))
+        del y
+        y = fq(x)
+        assert torch.equal(y[sub], fq(x[sub].contiguous()))
+        del y, d
+    xb = x[:8_000_003].contiguous()
+    del x
+    enc.zero_grad()
+    enc(xb, bound=1).sum().backward()
+    big = enc.embeddings.grad.clone()
+    enc.zero_grad()
+    for c in xb.split(2_000_001):
+        enc(c.contiguous(), bound=1).sum().backward()
+    chunks = enc.embeddings.grad
+    assert float((big - chunks).abs().max()) <= 1e-4 * float(chunks.abs().max())
+    del xb, big
+    N = 3_000_001
+    ro = torch.zeros(N, 3, device=dev); ro[:, 2] = -3; ro[:, 0] = torch.linspace(-0.9, 0.9, N, device=dev)
+    rd = torch.zeros(N, 3, device=dev); rd[:, 2] = 1
+    aabb = torch.tensor([-1., -1, -1, 1, 1, 1], device=dev)
+    nears, fars = raymarching.near_far_from_aabb(ro, rd, aabb, 0.2)
+    full = torch.full((128 ** 3 // 8,), 255, dtype=torch.uint8, device=dev)
+    xs, ds, dl = raymarching.march_rays(N, 8, torch.arange(N, dtype=torch.int32, device=dev), nears.clone(), ro, rd, 1.0, full, 1, 128, nears,
+                                        fars, 128, False, 0, 1024)
+    assert xs.shape == (N * 8 + 128 - (N * 8) % 128, 3)                 # raymarching.py:331-332
+    k = torch.tensor([0, N // 2, N - 1], device=dev)
+    x2, d2, dl2 = raymarching.march_rays(3, 8, torch.arange(3, dtype=torch.int32, device=dev), nears[k].clone(), ro[k].contiguous(),
+                                         rd[k].contiguous(), 1.0, full, 1, 128, nears[k].contiguous(), fars[k].contiguous(), 128, False, 0, 1024)
+    for i, r in enumerate(k.tolist()):
+        assert torch.equal(xs[r * 8:r * 8 + 8], x2[i * 8:i * 8 + 8]) and torch.equal(dl[r * 8:r * 8 + 8], dl2[i * 8:i * 8 + 8])
+    assert bool((dl2[:24, 0] > 0).all())
