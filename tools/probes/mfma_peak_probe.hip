@@ -1,0 +1,85 @@
+// What does v_mfma_f32_32x32x16_f16 sustain on this chip when NOTHING else competes -- the practical matrix roof under the 2.5 PFLOP/s
+// this repository prices against (MI355X_MICROARCH.md)?
+//   A: 4 waves per SIMD, each a stream of independent MFMAs from registers (4 accumulators in rotation): pure issue / pipe rate
+//   B: as A, but every MFMA's A operand comes from a ds_read_b128 of a 32-KiB LDS stage (the fused field kernel's weight path)
+//   C: as B plus the accumulator -> fp16 operand conversion of a layer boundary (32 v_cvt_pk_f16_f32 + 32 v_pk_max_f16 per 32 MFMAs)
+// Also prints the shader clock seen by s_memtime over the launch (a power-capped clock moves the roof, not the kernel).
+//   hipcc --offload-arch=gfx950 -O3 -o mfma_peak_probe mfma_peak_probe.hip
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdio.h>
+#include <stdint.h>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) k_mfma(float *out, unsigned long long *clk, int iters) {
+    __shared__ __attribute__((aligned(16))) _Float16 s_w[16384];      // 32 KiB
+    const uint32_t lane = threadIdx.x & 63u;
+    for (int i = threadIdx.x; i < 16384; i += 256) s_w[i] = (_Float16)(0.001f * (float)(i & 63));
+    __syncthreads();
+    half8 a, b;
+    for (int k = 0; k < 8; k++) { a[k] = (_Float16)(0.01f * (float)(lane + k)); b[k] = (_Float16)(0.02f * (float)(lane ^ k)); }
+    f32x16 acc[4];
+    for (int m = 0; m < 4; m++) for (int v = 0; v < 16; v++) acc[m][v] = 0.0f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+        #pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+            #pragma unroll
+            for (int m = 0; m < 4; m++) {
+                if (MODE >= 1) a = *reinterpret_cast<const half8 *>(s_w + (((ks * 4 + m) * 64 + lane) * 8 & 16383));
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[m], 0, 0, 0);
+            }
+        }
+        if (MODE == 2) {      // a layer boundary: 64 accumulator registers -> 32 packed fp16 pairs with ReLU, folded back into b
+            uint32_t x = 0;
+            #pragma unroll
+            for (int m = 0; m < 4; m++)
+                #pragma unroll
+                for (int v = 0; v < 16; v += 2) {
+                    half2v p = {(_Float16)acc[m][v], (_Float16)acc[m][v + 1]};
+                    const half2v z = {(_Float16)0.0f, (_Float16)0.0f};
+                    p = __builtin_elementwise_max(p, z);
+                    x ^= __builtin_bit_cast(uint32_t, p);
+                }
+            b[0] = __builtin_bit_cast(half2v, x)[0];
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0;
+    for (int m = 0; m < 4; m++) for (int v = 0; v < 16; v++) s += acc[m][v];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;
+}
+
+template <int MODE>
+static void run(const char *name, int cus) {
+    const int iters = 2000, wgs = cus * 2 * 8;       // 2 workgroups of 4 waves per CU resident (8 waves = 2 per SIMD ... x 2), 8 rounds
+    float *out; unsigned long long *clk;
+    (void)hipMalloc(&out, (size_t)wgs * 256 * 4); (void)hipMalloc(&clk, 8);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e9f; unsigned long long c = 0;
+    for (int rep = 0; rep < 3; rep++) {
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_mfma<MODE>, dim3(wgs), dim3(256), 0, 0, out, clk, iters);
+        (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) { best = ms; (void)hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost); }
+    }
+    const double flop = (double)wgs * 4 /*waves*/ * iters * 32 /*mfma*/ * 32768.0;
+    printf("%-64s %8.3f ms  %7.1f TFLOP/s  = %.3f of 2500\n", name, best, flop / best / 1e9, flop / best / 1e9 / 2500.0);
+    (void)hipFree(out); (void)hipFree(clk);
+}
+
+int main() {
+    int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+    int khz = 0; (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, 0);
+    printf("CUs %d, reported peak shader clock %.0f MHz\n", cus, khz / 1000.0);
+    run<0>("A  MFMA from registers, 4 accumulators in rotation", cus);
+    run<1>("B  A operand from LDS (ds_read_b128 per MFMA)", cus);
+    run<2>("C  B + accumulator -> fp16 + ReLU conversion every 32 MFMAs", cus);
+    return 0;
+}
