@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(256, 2) k_mfma(float *out, unsigned long long 
     for (int k = 0; k < 8; k++) { a[k] = (_Float16)(0.01f * (float)(lane + k)); b[k] = (_Float16)(0.02f * (float)(lane ^ k)); }
     f32x16 acc[4];
     for (int m = 0; m < 4; m++) for (int v = 0; v < 16; v++) acc[m][v] = 0.0f;
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), w0 = wall_clock64();
     for (int it = 0; it < iters; it++) {
         #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
@@ -48,29 +48,32 @@ __global__ void __launch_bounds__(256, 2) k_mfma(float *out, unsigned long long 
             b[0] = __builtin_bit_cast(half2v, x)[0];
         }
     }
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), w1 = wall_clock64();
     float s = 0;
     for (int m = 0; m < 4; m++) for (int v = 0; v < 16; v++) s += acc[m][v];
     out[blockIdx.x * 256 + threadIdx.x] = s;
-    if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
 }
 
 template <int MODE>
 static void run(const char *name, int cus) {
     const int iters = 2000, wgs = cus * 2 * 8;       // 2 workgroups of 4 waves per CU resident (8 waves = 2 per SIMD ... x 2), 8 rounds
     float *out; unsigned long long *clk;
-    (void)hipMalloc(&out, (size_t)wgs * 256 * 4); (void)hipMalloc(&clk, 8);
+    (void)hipMalloc(&out, (size_t)wgs * 256 * 4); (void)hipMalloc(&clk, 16);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    float best = 1e9f; unsigned long long c = 0;
+    float best = 1e9f; unsigned long long c[2] = {0, 0};
     for (int rep = 0; rep < 3; rep++) {
         (void)hipEventRecord(e0, 0);
         hipLaunchKernelGGL(k_mfma<MODE>, dim3(wgs), dim3(256), 0, 0, out, clk, iters);
         (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-        if (ms < best) { best = ms; (void)hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost); }
+        if (ms < best) { best = ms; (void)hipMemcpy(c, clk, 16, hipMemcpyDeviceToHost); }
     }
     const double flop = (double)wgs * 4 /*waves*/ * iters * 32 /*mfma*/ * 32768.0;
-    printf("%-64s %8.3f ms  %7.1f TFLOP/s  = %.3f of 2500\n", name, best, flop / best / 1e9, flop / best / 1e9 / 2500.0);
+    // workgroup 0: s_memtime ticks over its life against the 100 MHz wall clock, and against the ticks its MFMAs need when 4 waves share a pipe
+    const double mhz = c[1] ? (double)c[0] / (double)c[1] * 100.0 : 0.0;
+    printf("%-64s %8.3f ms  %7.1f TFLOP/s  = %.3f of 2500 | wg0: %.2f M s_memtime ticks (%.0f MHz against the wall clock); 4 waves x %d MFMAs x 32 cycles = %.2f M\n",
+           name, best, flop / best / 1e9, flop / best / 1e9 / 2500.0, c[0] / 1e6, mhz, iters * 32, 4.0 * iters * 32 * 32 / 1e6);
     (void)hipFree(out); (void)hipFree(clk);
 }
 
