@@ -55,6 +55,40 @@ __global__ void __launch_bounds__(256, 2) k_mfma(float *out, unsigned long long 
     if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
 }
 
+// D: the fp32 matrix instruction of the fp32 fused field kernel (v_mfma_f32_32x32x2_f32: 64 cycles, 4 096 FLOP), from registers
+__global__ void __launch_bounds__(256, 2) k_mfma_f32(float *out, int iters) {
+    const uint32_t lane = threadIdx.x & 63u;
+    float a = 0.01f * (float)lane, b = 0.02f * (float)(lane ^ 5u);
+    f32x16 acc[4];
+    for (int m = 0; m < 4; m++) for (int v = 0; v < 16; v++) acc[m][v] = 0.0f;
+    for (int it = 0; it < iters; it++) {
+        #pragma unroll
+        for (int ks = 0; ks < 8; ks++)
+            #pragma unroll
+            for (int m = 0; m < 4; m++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m], 0, 0, 0);
+    }
+    float s = 0;
+    for (int m = 0; m < 4; m++) for (int v = 0; v < 16; v++) s += acc[m][v];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+static void run_f32(int cus) {
+    const int iters = 1000, wgs = cus * 16;
+    float *out; (void)hipMalloc(&out, (size_t)wgs * 256 * 4);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; rep++) {
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_mfma_f32, dim3(wgs), dim3(256), 0, 0, out, iters);
+        (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double flop = (double)wgs * 4 * iters * 32 * 4096.0;
+    printf("%-64s %8.3f ms  %7.1f TFLOP/s  = %.3f of 157.3\n", "D  v_mfma_f32_32x32x2_f32 from registers", best, flop / best / 1e9, flop / best / 1e9 / 157.3);
+    (void)hipFree(out);
+}
+
 template <int MODE>
 static void run(const char *name, int cus) {
     const int iters = 2000, wgs = cus * 2 * 8;       // 2 workgroups of 4 waves per CU resident (8 waves = 2 per SIMD ... x 2), 8 rounds
@@ -84,5 +118,6 @@ int main() {
     run<0>("A  MFMA from registers, 4 accumulators in rotation", cus);
     run<1>("B  A operand from LDS (ds_read_b128 per MFMA)", cus);
     run<2>("C  B + accumulator -> fp16 + ReLU conversion every 32 MFMAs", cus);
+    run_f32(cus);
     return 0;
 }
