@@ -72,6 +72,42 @@ __global__ void __launch_bounds__(256, 2) k_mfma_f32(float *out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// E: v_mfma_f32_16x16x32_f16 (16 384 FLOP, a quarter of the accumulator registers per tile), 8 accumulators in rotation, from registers
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256, 2) k_mfma_16(float *out, int iters) {
+    const uint32_t lane = threadIdx.x & 63u;
+    half8 a, b;
+    for (int k = 0; k < 8; k++) { a[k] = (_Float16)(0.01f * (float)(lane + k)); b[k] = (_Float16)(0.02f * (float)(lane ^ k)); }
+    f32x4 acc[8];
+    for (int m = 0; m < 8; m++) for (int v = 0; v < 4; v++) acc[m][v] = 0.0f;
+    for (int it = 0; it < iters; it++) {
+        #pragma unroll
+        for (int ks = 0; ks < 8; ks++)
+            #pragma unroll
+            for (int m = 0; m < 8; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[m], 0, 0, 0);
+    }
+    float s = 0;
+    for (int m = 0; m < 8; m++) for (int v = 0; v < 4; v++) s += acc[m][v];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+static void run_16(int cus) {
+    const int iters = 2000, wgs = cus * 16;
+    float *out; (void)hipMalloc(&out, (size_t)wgs * 256 * 4);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; rep++) {
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_mfma_16, dim3(wgs), dim3(256), 0, 0, out, iters);
+        (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double flop = (double)wgs * 4 * iters * 64 * 16384.0;
+    printf("%-64s %8.3f ms  %7.1f TFLOP/s  = %.3f of 2500\n", "E  v_mfma_f32_16x16x32_f16 from registers, 8 accumulators", best, flop / best / 1e9, flop / best / 1e9 / 2500.0);
+    (void)hipFree(out);
+}
+
 static void run_f32(int cus) {
     const int iters = 1000, wgs = cus * 16;
     float *out; (void)hipMalloc(&out, (size_t)wgs * 256 * 4);
@@ -119,5 +155,6 @@ int main() {
     run<1>("B  A operand from LDS (ds_read_b128 per MFMA)", cus);
     run<2>("C  B + accumulator -> fp16 + ReLU conversion every 32 MFMAs", cus);
     run_f32(cus);
+    run_16(cus);
     return 0;
 }
