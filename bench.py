@@ -1018,7 +1018,7 @@ def roofline(timers, fp16, points_exclusive, points_overlapped=0):
                                                        "source": f"profiles/{PMC_SUMMARY} (frame groups of 4, one loop at a time)"}
             # (static: what a kernel of nothing but v_mfma_f32_32x32x16_f16 sustains on this pool's boxes -- the shader clock under matrix load
             #  is 1.74-1.77 GHz, not the 2.4 GHz of the nominal peak that `frac` keeps as its denominator)
-            roof["sustained_mfma_only_static"] = {"tflops": 1798.0, "frac_of_peak": 0.72, "shader_mhz_under_load": 1774,
+            roof["sustained_mfma_only_static"] = {"tflops": 1754.0, "frac_of_peak": 0.70, "shader_mhz_under_load": 1734, "boxes": "0.70-0.72 over five boxes",
                                                   "source": "profiles/r04_mfma_roof_probe.txt (tools/probes/mfma_peak_probe.hip)"}
             roof["traffic_unit"] = f"HBM bytes per launch = bytes per point of profiles/{PMC_SUMMARY} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command) x points per launch; static, not measured in this run"
         if over and points_overlapped:  # the same launches while other loops' kernels share the device: durations are not the kernel's own
