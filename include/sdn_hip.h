@@ -42,6 +42,10 @@ extern "C" {
 
 /* Library / build identification ("gfx950"), for load checks. */
 const char *sdn_version(void);
+/* Measurement aid (no reference counterpart): one wave on `stream` that idles for wall_ticks of the 100 MHz wall clock (<= 1e8) and
+ * writes {shader-clock ticks, wall ticks, first shader stamp, first wall stamp} to out4 (device, 4 x uint64): the shader clock granted
+ * while other streams' kernels run. */
+int sdn_debug_shader_clock(unsigned long long *out4, uint32_t wall_ticks, void *stream);
 
 /* ---------------------------------------------------------------------------
  * raymarching  (reference: raymarching/src/raymarching.h:7-17, bindings.cpp:5-19)

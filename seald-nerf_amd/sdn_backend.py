@@ -60,6 +60,7 @@ PROTOTYPES = {
     "sdn_field_build_quad_table": [_vp, _i32, _vp, _f32, _u32, _vp, _vp],
     "sdn_grid_encode_forward_quad_f16": [_vp, _vp, _vp, _vp, _u32, _f32, _u32, _vp],
     "sdn_density_query_cells_f16": [_vp, _vp, _u32, _vp, _u32, _u32, _f32, _vp, _vp, _vp, _vp, _f32, _u32, _f32, _f32, _i32, _vp, _vp],
+    "sdn_debug_shader_clock": [_vp, _u32, _vp],
     "sdn_density_query_cells_f32": [_vp, _vp, _u32, _vp, _u32, _u32, _f32, _vp, _vp, _vp, _vp, _f32, _u32, _f32, _f32, _i32, _vp, _vp],
     "sdn_density_grid_ema": [_vp, _vp, ctypes.c_uint64, _f32, _vp, _vp],
     "sdn_density_grid_pack": [_vp, ctypes.c_uint64, _vp, _f32, _vp, _vp, _vp],
